@@ -1,0 +1,129 @@
+/*
+ * vsr_hip.h -- C ABI of libvsr_hip.so, the MI355X (gfx950) device path of the
+ * per-frame video-SR forward (`VSR.forward`, reference
+ * network/video_super_resolution.py:23-69).
+ *
+ * Conventions ("C-ABI the build exports"):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer owned by
+ *     the caller (PyTorch on the Python side) unless the name says `host_`;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and the
+ *     functions never synchronise, allocate or free: they are graph-capturable;
+ *   - return value 0 = enqueued, negative = VSR_E_* (nothing was launched);
+ *     `vsr_last_error()` gives a thread-local message.  This replaces the
+ *     reference convention "return int 1 and swallow CUDA errors"
+ *     (correlation_cuda.cc:80-83, resample2d_kernel.cu:238-240).
+ *   - dense row-major tensors; "NCHW" / "NHWC" as stated per function.
+ *
+ * All file:line citations are relative to the reference repository root.
+ */
+#ifndef VSR_HIP_H
+#define VSR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSR_ABI_VERSION 1
+
+#define VSR_OK 0
+#define VSR_E_ARG (-1)     /* null pointer / non-positive size / unsupported parameter */
+#define VSR_E_LAUNCH (-2)  /* hipGetLastError() after the launch was not hipSuccess */
+#define VSR_E_UNSUPPORTED (-3)
+
+typedef void* vsr_stream_t; /* hipStream_t */
+
+int vsr_abi_version(void);
+const char* vsr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * FlowNet2's three native operators.  Each replaces one pybind entry point of the reference.
+ * ------------------------------------------------------------------------------------------ */
+
+/* resample2d_cuda.forward(input1, input2, output, kernel_size, bilinear)
+ *   resample2d_package/resample2d_cuda.cc:6-13, resample2d_kernel.cu:16-72,200-242.
+ * img [B,C,H,W], flow [B,2,H,W] -> out [B,C,H,W], float32 NCHW.  Backward warp with the four
+ * neighbour indices clamped independently; weights formed in double like the reference. */
+int vsr_resample2d_f32(const float* img, const float* flow, float* out, int B, int C, int H, int W,
+                       int kernel_size, int bilinear, vsr_stream_t stream);
+
+/* channelnorm_cuda.forward(input1, output, norm_deg)
+ *   channelnorm_package/channelnorm_cuda.cc:6-14, channelnorm_kernel.cu:19-60.
+ * in [B,C,H,W] -> out [B,1,H,W]; L2 norm over C (norm_deg is ignored by the reference, :26). */
+int vsr_channelnorm_f32(const float* in, float* out, int B, int C, int H, int W, vsr_stream_t stream);
+
+/* correlation_cuda.forward(input1, input2, rbot1, rbot2, output, pad, k, max_disp, s1, s2, mult)
+ *   correlation_package/correlation_cuda.cc:10-87, correlation_cuda_kernel.cu:47-147,336-427.
+ * The reference's padded NHWC scratch copies (rbot1/rbot2) do not exist here: tiles are read
+ * from NCHW directly.  Output geometry: vsr_correlation_out_shape (correlation_cuda.cc:26-34). */
+int vsr_correlation_out_shape(int H, int W, int pad_size, int kernel_size, int max_displacement, int stride1,
+                              int stride2, int* out_channels, int* out_h, int* out_w);
+int vsr_correlation_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int pad_size,
+                        int kernel_size, int max_displacement, int stride1, int stride2, vsr_stream_t stream);
+
+/* Fused form of FlowNet2.forward's "warp, diff, channel-norm, concat" (models.py:86-91,98-103):
+ *   out12 = cat(x6, warp(x6[:,3:6], flow), flow * inv_div, |x6[:,0:3] - warp|_2)   [B,12,H,W]
+ * one pass instead of Resample2d + sub + ChannelNorm + div + cat. */
+int vsr_flownet_warp_concat_f32(const float* x6, const float* flow, float inv_div, float* out12, int B, int H, int W,
+                                vsr_stream_t stream);
+
+/* Fused form of models.py:107-112 / :116-121:  given flow [B,2,H,W] and x6 [B,6,H,W] write
+ *   norm_flow = |flow|_2 [B,1,H,W]  and  norm_diff = |x6[:,0:3] - warp(x6[:,3:6], flow)|_2 [B,1,H,W]. */
+int vsr_flownet_warp_norms_f32(const float* x6, const float* flow, float* norm_flow, float* norm_diff, int B, int H,
+                               int W, vsr_stream_t stream);
+
+/* utils/flow_utils.py:4-62 flow2img (+ compute_color :27-62, colour wheel :65-112) on the device,
+ * replacing the host round-trip of FlowProjectionModule.py:31-32.
+ * flow: [2,H,W] planar float32 (FlowNet2's output for B=1); out: [H,W,3] float32 holding the uint8
+ * values.  workspace: >= 16 bytes, zeroed by this call.  float64 math like numpy. */
+int vsr_flow2img_f32(const float* flow, float* out_hwc, void* workspace, int H, int W, vsr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SRProjectionModule (SRProjectionModule.py:96-150, blocks.py:7-74): exact-fp32 building blocks.
+ * NCHW float32, 32 feature channels ("nf"), x4 geometry (kernel 8, stride 4, pad 2).
+ * ------------------------------------------------------------------------------------------ */
+
+/* sub_mean (per-channel scale+bias) -> conv_in 3x3 (3->nmid) + PReLU -> feat_in 1x1 (nmid->32) + PReLU
+ *   SRProjectionModule.py:135,137-138.  x [N,3,h,w] -> out [N,32,h,w]. */
+int vsr_sr_head_f32(const float* x, const float* sub_scale3, const float* sub_bias3, const float* w_in,
+                    const float* b_in, float slope_in, int nmid, const float* w_feat, const float* b_feat,
+                    float slope_feat, float* out, int N, int h, int w, vsr_stream_t stream);
+
+/* 1x1 conv over up to three 32-channel inputs + bias (+ optional per-position constant map) + PReLU:
+ *   out[n,co,p] = prelu( sum_k sum_ci Wk[co*ldw_k + ci] * in_k[n,ci,p] + bias[co] + cmap[co,p] )
+ * covers compress_in (:49-53), the live 32-channel slice of uptran/downtran (:62-63,:77-78 under the
+ * zero-fill semantic D1) and compress_out (:85-88).  in_k [N,32,P]; unused inputs are NULL. */
+int vsr_sr_conv1x1_f32(const float* in0, const float* w0, int ldw0, const float* in1, const float* w1, int ldw1,
+                       const float* in2, const float* w2, int ldw2, const float* bias, const float* cmap,
+                       float slope, float* out, int N, int P, vsr_stream_t stream);
+
+/* DeconvBlock: ConvTranspose2d(32,32,k8,s4,p2) + PReLU (:22-24,:64; blocks.py:30-43).
+ * in [N,32,h,w] -> out [N,32,4h,4w].  weight_packed = the ConvTranspose2d weight [32(in),32(out),8,8]
+ * permuted to [ky][kx][in][out] (the host does `.permute(2,3,0,1).contiguous()` once per weight). */
+int vsr_sr_deconv8s4_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
+                         int h, int w, vsr_stream_t stream);
+
+/* ConvBlock: Conv2d(32,32,k8,s4,p2) + PReLU (:25-27,:79).  in [N,32,4h,4w] -> out [N,32,h,w].
+ * weight_packed = the Conv2d weight [32(out),32(in),8,8] permuted to [ky][kx][in][out]. */
+int vsr_sr_conv8s4_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
+                       int h, int w, vsr_stream_t stream);
+
+/* conv_out 3x3 (32->3, no activation) + bilinear x4 skip of sub_mean(x) + add_mean (:136,:142-143).
+ * hr [N,32,4h,4w] (output of the `out` DeconvBlock), x [N,3,h,w] -> prefc [N,3,4h,4w]. */
+int vsr_sr_tail_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
+                    const float* sub_bias3, const float* add_scale3, const float* add_bias3, float* prefc, int N,
+                    int h, int w, vsr_stream_t stream);
+
+/* The fusion MLP over the batch axis (:126-131,:146; tools.py:118-123):
+ *   out[c,p] = relu( w2 . relu(W1 v + b1) + b2 ),  v = prefc[0..nplanes-1, c, p]
+ * prefc [nplanes,3,P] -> out [3,P] (NCHW) or, if out_nhwc != 0, [P,3] (the layout VSR.forward
+ * returns after transpose1312, video_super_resolution.py:64). */
+int vsr_sr_fc_fuse_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,
+                       int nplanes, int hidden, float* out, int P, int out_nhwc, vsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSR_HIP_H */

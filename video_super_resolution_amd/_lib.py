@@ -1,0 +1,83 @@
+"""ctypes binding of libvsr_hip.so (the C ABI declared in include/vsr_hip.h).
+
+There is deliberately no CPU or eager-PyTorch fallback behind these entry points: if the
+shared library is missing, or an operator is handed a non-CUDA tensor, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libvsr_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "vsr_hip.h")
+_lib = None
+
+
+class VsrHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into the in-tree libvsr_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def declared_symbols() -> list:
+    """Entry points include/vsr_hip.h declares (used by the export test and by `load`)."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(vsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VsrHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the device path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.vsr_last_error.restype = ctypes.c_char_p
+        if lib.vsr_abi_version() != 1:
+            raise VsrHipError("libvsr_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().vsr_last_error().decode("utf-8", "replace")
+        raise VsrHipError(f"{what or 'vsr'} failed ({rc}): {msg}")
+
+
+def dptr(t: torch.Tensor, dtype=torch.float32) -> ctypes.c_void_p:
+    """Device pointer of a dense tensor; refuses anything the kernels' indexing does not assume."""
+    if not t.is_cuda:
+        raise VsrHipError("device path called with a CPU tensor (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise VsrHipError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise VsrHipError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def optr(t, dtype=torch.float32):
+    return ctypes.c_void_p(0) if t is None else dptr(t, dtype)
+
+
+def stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def cf(v: float) -> ctypes.c_float:
+    return ctypes.c_float(float(v))

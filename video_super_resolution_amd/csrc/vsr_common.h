@@ -1,0 +1,40 @@
+// vsr_common.h -- shared host-side helpers for the gfx950 kernels behind include/vsr_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/vsr_hip.h"
+
+namespace vsr {
+
+inline char* err_buf() {
+    static thread_local char buf[256] = "";
+    return buf;
+}
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 256, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// Called right after a kernel launch: reports launch-configuration errors without synchronising.
+inline int launched(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VSR_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return VSR_OK;
+}
+
+inline hipStream_t S(vsr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace vsr
+
+#define VSR_REQUIRE(cond, ...) \
+    do {                       \
+        if (!(cond)) return vsr::fail(VSR_E_ARG, __VA_ARGS__); \
+    } while (0)

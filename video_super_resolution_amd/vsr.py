@@ -1,0 +1,119 @@
+"""`VSR`: the per-frame video-SR forward of the reference behind its own `nn.Module` API.
+
+Drop-in for `network/video_super_resolution.py:12-69`:
+
+    VSR()                                            no-arg constructor, is an nn.Module       (:13-21)
+    forward(data, target, high_frames, estimated_image, train=True) -> (output, loss)            (:23-69)
+        data            [3,h,w,3]  float 0..255 LR frames (NHWC)
+        high_frames     [3,4h,4w,3]; slot 1 is overwritten with the output in place            (:66)
+        estimated_image None | [1,4h,4w,3] (the previous output, fed back verbatim, main.py:199-203)
+        output          [1,4h,4w,3] float32 on the module's device
+    sub-module names .model .FlowModule .DepthModule .VOSModule are kept; `.model.state_dict()` has the
+    reference's keys (main.py:118,235).
+
+What differs, on purpose:
+  * everything stays on the device: the four host round trips of the flow colour coding, the two of the
+    VOS wrapper and the numpy masked-array fill (:58-60) are device kernels / device tensor ops;
+  * the depth trunk is evaluated once per distinct frame (the reference evaluates frame 1 of every
+    triplet twice and frame 2 again in the second pass: 8 trunk runs, 4-5 distinct inputs);
+  * the loss branch (`train=True`, :67,:71-80) needs the VGG16-perceptual networks of loss_function.py,
+    which are out of this path's scope: with `train=True` the call raises unless a
+    `loss_fn(target, high_frames)` callable has been attached.  Inference (`train=False`) returns
+    `loss=None` exactly like the reference.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .depth import DepthProjectionModule
+from .flownet import FlowProjectionModule
+from .sr import SRProjectionModule
+from .vos import VOSProjectionModule
+
+
+def maskprocess(mask: torch.Tensor) -> torch.Tensor:
+    """utils/tools.py:76-77: replicate a [h,w] map to three channels."""
+    return torch.stack((mask,) * 3)
+
+
+class VSR(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.model = SRProjectionModule()
+        self.FlowModule = FlowProjectionModule().eval()
+        self.DepthModule = DepthProjectionModule().eval()
+        self.VOSModule = VOSProjectionModule().eval()
+        self.loss_fn: Optional[Callable] = None
+
+    def train(self, mode: bool = True):
+        # main.py:178 calls model.train(), which would flip the frozen guidance networks (HG BatchNorm!)
+        # out of eval mode; the reference's constructor intends them frozen (:16-21).  Keep them in eval.
+        super().train(mode)
+        self.FlowModule.eval()
+        self.DepthModule.eval()
+        self.VOSModule.eval()
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _guidance(self, trip, depth_cache):
+        """trip: three [h,w,3] frames -> (flow pictures [2,3,h,w], depth planes [2,3,h,w])."""
+        h, w = trip[0].shape[:2]
+        pics = torch.stack([self.FlowModule(trip[0], trip[1]), self.FlowModule(trip[1], trip[2])])  # [2,h',w',3]
+        pics = F.interpolate(pics.permute(0, 3, 1, 2), (h, w))  # nearest back to h x w (:35,:52)
+        z = []
+        for f in trip:
+            key = f.data_ptr()
+            if key not in depth_cache:
+                depth_cache[key] = (f, self.DepthModule.predict(f))  # keep f alive so the pointer stays unique
+            z.append(depth_cache[key][1])
+        depth = torch.stack([maskprocess(self.DepthModule.combine(z[0], z[1])),
+                             maskprocess(self.DepthModule.combine(z[1], z[2]))])
+        return pics, depth
+
+    def forward(self, data, target, high_frames, estimated_image, train=True):
+        if data.dim() != 4 or data.shape[0] != 3 or data.shape[3] != 3:
+            raise ValueError(f"data must be [3,h,w,3], got {tuple(data.shape)}")
+        if not data.is_cuda:
+            raise RuntimeError("VSR runs on the GPU through hand-written HIP kernels; there is no CPU fallback "
+                               "(move the module and its inputs to the device first)")
+        with torch.no_grad():
+            h, w = data.shape[1], data.shape[2]
+            d = data.detach().to(torch.float32).contiguous()
+            f0, f1, f2 = d[0], d[1], d[2]
+            depth_cache = {}
+            frames = d.permute(0, 3, 1, 2)  # [3,3,h,w]
+
+            # ---- pass 1 (:26-41)
+            pics, depth = self._guidance((f0, f1, f2), depth_cache)
+            if estimated_image is None:
+                est = frames[0:1]
+                est_hw3 = f0
+            else:
+                est = F.interpolate(estimated_image.detach().to(torch.float32).permute(0, 3, 1, 2), (h, w))  # :37
+                est_hw3 = est[0].permute(1, 2, 0).contiguous()
+            out1 = self.model(torch.cat((frames, pics, depth, est), 0))  # [1,3,4h,4w]
+
+            # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
+            mid = F.interpolate(out1, (h, w))[0]  # nearest: HR pixel (4i,4j)
+            mid_hw3 = mid.permute(1, 2, 0).contiguous()
+            pics2, depth2 = self._guidance((est_hw3, mid_hw3, f2), depth_cache)
+            mask = self.VOSModule(est_hw3, mid_hw3)  # [h,w] in {0,1}
+            masked = torch.where(maskprocess(mask) != 0, torch.zeros_like(mid), mid).unsqueeze(0)  # :58-60
+
+            # ---- pass 2 SR (:62-64)
+            out = self.model(torch.cat((frames, pics2, depth2, masked), 0)).permute(0, 2, 3, 1)
+            if high_frames is not None:
+                high_frames[1] = out  # :66
+        loss = None
+        if train:
+            if self.loss_fn is None:
+                raise NotImplementedError("train=True needs the reference's VGG16-perceptual loss networks "
+                                          "(loss_function.py), which are outside this path; attach `loss_fn` "
+                                          "or call with train=False (inference returns loss=None like the reference)")
+            loss = self.loss_fn(target, high_frames)
+        return out, loss
