@@ -45,7 +45,8 @@ const char* vsr_last_error(void);
 /* resample2d_cuda.forward(input1, input2, output, kernel_size, bilinear)
  *   resample2d_package/resample2d_cuda.cc:6-13, resample2d_kernel.cu:16-72,200-242.
  * img [B,C,H,W], flow [B,2,H,W] -> out [B,C,H,W], float32 NCHW.  Backward warp with the four
- * neighbour indices clamped independently; weights formed in double like the reference. */
+ * neighbour indices clamped independently; the weights follow the reference's mixed float/double
+ * promotion (three of them double, alpha*beta float), so results are bit-identical to it. */
 int vsr_resample2d_f32(const float* img, const float* flow, float* out, int B, int C, int H, int W,
                        int kernel_size, int bilinear, vsr_stream_t stream);
 

@@ -1,4 +1,7 @@
 import os
+
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")  # must precede `import torch` (read at library load)
+os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")
 import sys
 
 import numpy as np

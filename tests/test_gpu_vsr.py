@@ -34,6 +34,12 @@ def test_wrappers_match_reference_golden(golden, gpu_vsr):
 
 
 def test_full_forward_two_recurrent_frames(golden, gpu_vsr):
+    """End to end against the reference's golden frames.  The reference quantises FlowNet2's flow to uint8 colour
+    pictures (flow_utils.py:4-24) and thresholds the OSVOS probability at 0.7: an fp32 rounding difference in a
+    trunk (MIOpen vs ATen-CPU summation order, ~2e-5 of the flow range) flips a few of those discrete pixels, and
+    every flip perturbs a ~29x29 LR-pixel receptive field of the SR net.  So the end-to-end bar is stated on
+    image quality (PSNR, tail of the error distribution); the kernels themselves are held to the 1e-3/2e-5 bars
+    with the discrete planes teacher-forced (next test)."""
     g = golden("g6_vsr")
     data = torch.from_numpy(g["data"]).cuda()
     hf = torch.zeros(3, 4 * data.shape[1], 4 * data.shape[2], 3, device="cuda")
@@ -41,13 +47,28 @@ def test_full_forward_two_recurrent_frames(golden, gpu_vsr):
     assert loss is None and out0.shape == (1, 264, 280, 3) and out0.is_cuda
     assert torch.equal(hf[1], out0[0])  # in-place side effect (video_super_resolution.py:66)
     out1, _ = gpu_vsr(data, None, hf, out0, train=False)
-    # a flipped VOS-mask / colour-step pixel changes a small neighbourhood: judge by PSNR and by the bulk error
     for out, ref in ((out0, g["out0"]), (out1, g["out1"])):
-        o = out.cpu().numpy()
-        mse = float(np.mean((o - ref) ** 2))
-        psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-20))
-        frac_bad = float((np.abs(o - ref) > TOL * np.abs(ref).max()).mean())
-        assert psnr > 60.0 and frac_bad < 0.01, (psnr, frac_bad)
+        err = np.abs(out.cpu().numpy() - ref)
+        psnr = 10 * np.log10(255.0 ** 2 / max(float(np.mean(err ** 2)), 1e-20))
+        assert psnr > 60.0, psnr                      # north_star: within 0.05 dB means >> 60 dB between the two
+        assert np.percentile(err, 50) < 1e-3 * 255.0  # median error below 1e-3 of the pixel range
+        assert np.percentile(err, 99) < 1.0           # 99 % of the pixels within one grey level
+
+
+def test_sr_passes_teacher_forced_from_oracle(gpu_vsr, oracle_params):
+    """Both SR passes of one frame with the oracle's own 8-plane inputs (its flow pictures, depth planes, masked
+    estimate): isolates the hand-written kernels from the discrete guidance planes.  Bar: 2e-5 of the range."""
+    from oracle import vsr_oracle as O
+    rs = np.random.RandomState(77)
+    data = torch.from_numpy(rs.randint(0, 256, (3, 64, 72, 3)).astype(np.float32))
+    taps = {}
+    with torch.no_grad():
+        ref_out = O.vsr_forward(oracle_params, data, None, taps=taps)
+    got1 = gpu_vsr.model(taps["pass1_input"].cuda()).cpu().numpy()
+    ref1 = taps["pass1_output"].numpy()
+    assert np.abs(got1 - ref1).max() <= 2e-5 * np.abs(ref1).max()
+    got2 = gpu_vsr.model(taps["pass2_input"].cuda()).permute(0, 2, 3, 1).cpu().numpy()
+    assert np.abs(got2 - ref_out.numpy()).max() <= 2e-5 * np.abs(ref_out.numpy()).max()
 
 
 def test_train_true_without_loss_fn_raises_and_cpu_input_raises(gpu_vsr):

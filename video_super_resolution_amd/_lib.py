@@ -81,3 +81,36 @@ def stream() -> ctypes.c_void_p:
 
 def cf(v: float) -> ctypes.c_float:
     return ctypes.c_float(float(v))
+
+
+class EventTimer:
+    """HIP-event timing of selected kernel launches on the current stream (used by bench.py for the roofline
+    leg).  Disabled (no events, no overhead) unless `enabled` is set."""
+
+    def __init__(self):
+        self.enabled = False
+        self._pairs = {}
+
+    def reset(self):
+        self._pairs = {}
+
+    def start(self, name: str):
+        if not self.enabled:
+            return None
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        self._pairs.setdefault(name, []).append((a, b))
+        return b
+
+    @staticmethod
+    def stop(tok):
+        if tok is not None:
+            tok.record()
+
+    def summary(self):
+        """{name: (launches, mean milliseconds)} -- call after a device synchronise."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self._pairs.items()}
+
+
+TIMER = EventTimer()

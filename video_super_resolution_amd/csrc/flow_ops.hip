@@ -12,11 +12,13 @@ constexpr int kBlock = 256;
 
 struct Bilerp {
     int xL, xR, yT, yB;
-    double w00, w01, w10, w11;
+    double w00, w01, w10;
+    float w11;
 };
 
 // reference resample2d_kernel.cu:41-53: float coordinates, float fractional parts, the four
-// indices clamped independently; :56-59 the weights are products of doubles.
+// indices clamped independently; :56-59 the three weights that contain the literal `1.` are formed
+// in double, while `(alpha)*(beta)` is a float product (C promotion rules) -- kept as such.
 __device__ __forceinline__ Bilerp bilerp_setup(int x, int y, float dx, float dy, int H, int W) {
     Bilerp s;
     const float xf = (float)x + dx;
@@ -33,7 +35,7 @@ __device__ __forceinline__ Bilerp bilerp_setup(int x, int y, float dx, float dy,
     s.w00 = (1. - a) * (1. - b);
     s.w01 = a * (1. - b);
     s.w10 = (1. - a) * b;
-    s.w11 = a * b;
+    s.w11 = alpha * beta;
     return s;
 }
 
@@ -43,7 +45,7 @@ __device__ __forceinline__ float bilerp_sample(const float* __restrict__ plane, 
     v += (float)(s.w00 * (double)plane[(size_t)s.yT * W + s.xL]);
     v += (float)(s.w01 * (double)plane[(size_t)s.yT * W + s.xR]);
     v += (float)(s.w10 * (double)plane[(size_t)s.yB * W + s.xL]);
-    v += (float)(s.w11 * (double)plane[(size_t)s.yB * W + s.xR]);
+    v += s.w11 * plane[(size_t)s.yB * W + s.xR];
     return v;
 }
 

@@ -180,15 +180,19 @@ class SRProjectionModule(nn.Module):
     @staticmethod
     def _up(x, w, b, a, N, h, w_):
         out = torch.empty((N, _NF, 4 * h, 4 * w_), dtype=torch.float32, device=x.device)
+        tok = L.TIMER.start("sr_deconv8s4_f32")
         L.check(L.load().vsr_sr_deconv8s4_f32(L.dptr(x), L.dptr(w), L.dptr(b), L.cf(a), L.dptr(out), N, h, w_, L.stream()),
                 "sr_deconv8s4")
+        L.TIMER.stop(tok)
         return out
 
     @staticmethod
     def _down(x, w, b, a, N, h, w_):
         out = torch.empty((N, _NF, h, w_), dtype=torch.float32, device=x.device)
+        tok = L.TIMER.start("sr_conv8s4_f32")
         L.check(L.load().vsr_sr_conv8s4_f32(L.dptr(x), L.dptr(w), L.dptr(b), L.cf(a), L.dptr(out), N, h, w_, L.stream()),
                 "sr_conv8s4")
+        L.TIMER.stop(tok)
         return out
 
     # ------------------------------------------------------------------ group recurrences
