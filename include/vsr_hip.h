@@ -124,6 +124,42 @@ int vsr_sr_tail_f32(const float* hr, const float* w_out, const float* b_out, con
 int vsr_sr_fc_fuse_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,
                        int nplanes, int hidden, float* out, int P, int out_nhwc, vsr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SRProjectionModule, MFMA path: fp16 storage (NHWC, 32 channels = 64 B per pixel), fp32 accumulate.
+ * Same reference lines as the fp32 blocks above; this is the path the headline throughput is quoted on.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Packed weights of one fused stage (host builds it once per weight set; video_super_resolution_amd/sr.py
+ * pack_utd_blob documents the element order): per wave 16 deconv + 16 conv MFMA A-fragments of 64 lanes x 8 fp16,
+ * 2 fragments of the 1x1, then fp32 b_up[32] b_tr[32] b_dn[32] slope_up slope_tr slope_dn.  16-byte aligned. */
+size_t vsr_sr_utd_blob_bytes(void);
+int vsr_sr_utd_strip_width(void); /* LR columns one workgroup marches down (31) */
+
+/* Fused   in -> up_i (ConvTranspose2d k8 s4 p2 + PReLU) -> 1x1 slice of downtran + PReLU -> down_j (Conv2d k8 s4 p2 +
+ * PReLU)   (SRProjectionModule.py:64,77-80 for the live chain under zero fill).  The x4 feature map stays in LDS.
+ * in [N,h,w,32] fp16 -> out [N,h,w,32] fp16.  deconv_only != 0: only up_i + PReLU, out [N,4h,4w,32] fp16 (the
+ * `out` DeconvBlock, :118-120,142).  rows_per_seg: LR rows one workgroup marches (h = one march per strip). */
+int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int deconv_only,
+                   vsr_stream_t stream);
+
+/* vsr_sr_conv1x1_f32 for NHWC fp16 tensors [N,P,32]; weights/bias fp32, cmap_nhwc fp32 [P,32] or NULL. */
+int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* in1, const float* w1, int ldw1,
+                       const void* in2, const float* w2, int ldw2, const float* bias, const float* cmap_nhwc, float slope,
+                       void* out, int N, int P, vsr_stream_t stream);
+
+/* vsr_sr_head_f32 writing NHWC fp16 [N,h,w,32]. */
+int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bias3, const float* w_in, const float* b_in,
+                    float slope_in, int nmid, const float* w_feat, const float* b_feat, float slope_feat, void* out_nhwc,
+                    int N, int h, int w, vsr_stream_t stream);
+
+/* conv_out 3x3 + bilinear skip + add_mean + fusion MLP in one pass over the HR map of all planes
+ * (SRProjectionModule.py:136,142-143,146).  hr_nhwc [8,4h,4w,32] fp16; w_out_packed = conv_out weight [3,32,3,3]
+ * permuted to [dy][dx][ci][3]; out [3,4h,4w] (or [4h,4w,3] if out_nhwc); prefc_or_null: optional [8,3,4h,4w] tap. */
+int vsr_sr_tail_fc_f16(const void* hr_nhwc, const float* w_out_packed, const float* b_out, const float* x,
+                       const float* sub_scale3, const float* sub_bias3, const float* add_scale3, const float* add_bias3,
+                       const float* w1, const float* b1, const float* w2, const float* b2, int nplanes, int hidden,
+                       float* out, float* prefc_or_null, int h, int w, int out_nhwc, vsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

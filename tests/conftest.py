@@ -49,4 +49,18 @@ def gpu_vsr(cpu_vsr):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    return copy.deepcopy(cpu_vsr).cuda().eval()
+    m = copy.deepcopy(cpu_vsr).cuda().eval()
+    m.model.precision = "fp32"  # the exact path: strict parity bars
+    return m
+
+
+@pytest.fixture(scope="session")
+def gpu_vsr_f16(cpu_vsr):
+    """Same weights, SR stack on the fp16/MFMA throughput path (the headline configuration)."""
+    import copy
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    m = copy.deepcopy(cpu_vsr).cuda().eval()
+    m.model.precision = "fp16"
+    return m

@@ -1,5 +1,6 @@
 """Stage-by-stage wall times of one VSR.forward at a given LR size (prints progressively)."""
 import sys, time, os
+os.environ.setdefault('MIOPEN_FIND_MODE','2'); os.environ.setdefault('MIOPEN_LOG_LEVEL','2')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_super_resolution_amd import VSR, _lib
@@ -9,7 +10,7 @@ def log(*a):
     print(f"[{time.time()-T0:7.2f}s]", *a, flush=True)
 T0 = time.time()
 torch.set_grad_enabled(False)
-m = fill_module_(VSR().eval(), 0).cuda(); log("model ready")
+m = fill_module_(VSR().eval(), 0).cuda(); m.model.precision = sys.argv[3] if len(sys.argv) > 3 else 'fp16'; log('model ready', m.model.precision)
 d = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (3, h, w, 3)).astype(np.float32)).cuda()
 def timed(name, fn, n=2):
     for i in range(n):

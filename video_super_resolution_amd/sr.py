@@ -103,9 +103,13 @@ class SRProjectionModule(nn.Module):
         self.conv_out = _conv_act(num_features, out_channels, 3, padding=1, act=False)
         self.add_mean = MeanShift(rgb_mean, rgb_std, 1)
         self.fc = nn.Sequential(nn.Linear(8, 32), nn.ReLU(), nn.Linear(32, 1), nn.ReLU())
+        # "fp16": fp16 storage / fp32 accumulate on the MFMA path (the headline configuration);
+        # "fp32": every product and sum in float32 (the parity configuration, ~60x slower).
+        self.precision = "fp16"
         self._pack: Optional[dict] = None
         self._pack_key = None
         self._const: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._const_nhwc: Dict[Tuple[int, int], torch.Tensor] = {}
 
     # ------------------------------------------------------------------ weight packing (cached)
     def _weights_key(self):
@@ -153,8 +157,18 @@ class SRProjectionModule(nn.Module):
         P["fc_w1"], P["fc_b1"] = f(self.fc[0].weight), f(self.fc[0].bias)
         P["fc_w2"], P["fc_b2"] = f(self.fc[2].weight.reshape(-1)), f(self.fc[2].bias)
         P["zero_b"] = torch.zeros(_NF, dtype=torch.float32, device=wci.device)
+        # ---- MFMA path: one packed blob per live chain  lr[j] -> hr[j+1] -> lr[j+3]  and one for the tail deconv
+        G = b.num_groups
+        P["utd"] = {}
+        for j in range(0, G - 2, 3):
+            P["utd"][j] = pack_utd_blob(b.upBlocks[j + 1][0].weight, b.upBlocks[j + 1][0].bias, P["up_a"][j + 1],
+                                        P["dt_w"][j + 1], _NF * (j + 2), P["dt_b"][j + 1], P["dt_a"][j + 1],
+                                        b.downBlocks[j + 2][0].weight, b.downBlocks[j + 2][0].bias, P["dn_a"][j + 2])
+        P["utd_out"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0)
+        P["cv_w_pk"] = f(self.conv_out[0].weight.permute(2, 3, 1, 0))  # [dy][dx][ci][3]
         self._pack, self._pack_key = P, key
         self._const.clear()
+        self._const_nhwc.clear()
         return P
 
     # ------------------------------------------------------------------ kernel wrappers (fp32 exact path)
@@ -249,6 +263,10 @@ class SRProjectionModule(nn.Module):
         dev = x.device
         G = self.block.num_groups
         cmap = self._const_map(P, h, w, dev)
+        if self.precision == "fp16":
+            return self._forward_f16(x, P, cmap, taps)
+        if self.precision != "fp32":
+            raise ValueError(f"precision must be 'fp16' or 'fp32', got {self.precision!r}")
         nmid = P["w_in"].shape[0]
         feat = torch.empty((N, _NF, h, w), dtype=torch.float32, device=dev)
         L.check(lib.vsr_sr_head_f32(L.dptr(x), L.dptr(P["sub_s"]), L.dptr(P["sub_b"]), L.dptr(P["w_in"]), L.dptr(P["b_in"]),
@@ -293,6 +311,86 @@ class SRProjectionModule(nn.Module):
                 "sr_fc_fuse")
         return out
 
+    # ------------------------------------------------------------------ MFMA path (fp16 storage, NHWC)
+    @staticmethod
+    def _c1h(ins, bias, slope, N, P, cmap=None):
+        """1x1 over NHWC fp16 inputs; ins: list of (tensor [N,P,32] half, weight matrix [32,ld] float, first column)."""
+        out = torch.empty((N, P, _NF), dtype=torch.float16, device=bias.device)
+        args = []
+        keep = []
+        for k in range(3):
+            if k < len(ins):
+                t, w, col = ins[k]
+                ws = w[:, col:col + _NF]
+                keep.append(ws)
+                args += [L.dptr(t, torch.float16), ctypes_ptr(ws), w.shape[1]]
+            else:
+                args += [L.optr(None), L.optr(None), 0]
+        L.check(L.load().vsr_sr_conv1x1_f16(*args, L.dptr(bias), L.optr(cmap), L.cf(slope), L.dptr(out, torch.float16), N, P,
+                                            L.stream()), "sr_conv1x1_f16")
+        return out
+
+    @staticmethod
+    def _rows_per_segment(N, h, w):
+        strips = -(-w // L.load().vsr_sr_utd_strip_width())
+        wgs = strips * N
+        if wgs >= 192:  # one march per (strip, image) already covers the 256 CUs
+            return h
+        segs = max(1, min(-(-h // 8), -(-256 // wgs)))
+        return -(-h // segs)
+
+    def _utd(self, a, blob, N, h, w, deconv_only=False):
+        out = torch.empty((N, 4 * h, 4 * w, _NF) if deconv_only else (N, h, w, _NF), dtype=torch.float16, device=a.device)
+        tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else "sr_utd_f16")
+        L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
+                                        self._rows_per_segment(N, h, w), int(deconv_only), L.stream()), "sr_utd_f16")
+        L.TIMER.stop(tok)
+        return out
+
+    def _forward_f16(self, x, P, cmap, taps):
+        lib = L.load()
+        N, _, h, w = x.shape
+        dev = x.device
+        G = self.block.num_groups
+        hp = h * w
+        if (h, w) not in self._const_nhwc:
+            self._const_nhwc[(h, w)] = cmap.t().contiguous()  # [h*w, 32] fp32, added before the activation
+        cmap_nhwc = self._const_nhwc[(h, w)]
+        feat = torch.empty((N, hp, _NF), dtype=torch.float16, device=dev)
+        L.check(lib.vsr_sr_head_f16(L.dptr(x), L.dptr(P["sub_s"]), L.dptr(P["sub_b"]), L.dptr(P["w_in"]), L.dptr(P["b_in"]),
+                                    L.cf(P["a_in"]), P["w_in"].shape[0], L.dptr(P["w_feat"]), L.dptr(P["b_feat"]),
+                                    L.cf(P["a_feat"]), L.dptr(feat, torch.float16), N, h, w, L.stream()), "sr_head_f16")
+        nchw = lambda t: t.view(N, h, w, _NF).permute(0, 3, 1, 2).float()
+        if taps is not None:
+            taps["feat_in"] = nchw(feat)
+        last = feat
+        hid = None
+        for step in range(self.num_steps):
+            live = {0: self._c1h([(feat, P["ci_w"], 0), (last, P["ci_w"], _NF)], P["ci_b"], P["ci_a"], N, hp)}
+            j = 0
+            while j + 3 <= G:
+                a = self._c1h([(live[j], P["ut_w"][j], _NF * (j + 1))], P["ut_b"][j], P["ut_a"][j], N, hp)
+                live[j + 3] = self._utd(a, P["utd"][j], N, h, w).view(N, hp, _NF)
+                j += 3
+            ins = [(live[k], P["co_w"], _NF * (k - 1)) for k in sorted(live) if k > 0]
+            hid = self._c1h(ins, P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
+            last = hid
+            if taps is not None:
+                taps[f"block{step}"] = nchw(hid)
+                if step == self.num_steps - 1:
+                    for k, v in live.items():
+                        taps[f"lr{k}"] = nchw(v)
+        hr = self._utd(hid, P["utd_out"], N, h, w, deconv_only=True)
+        prefc = torch.empty((N, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev) if taps is not None else None
+        out = torch.empty((1, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev)
+        L.check(lib.vsr_sr_tail_fc_f16(L.dptr(hr, torch.float16), L.dptr(P["cv_w_pk"]), L.dptr(P["cv_b"]), L.dptr(x),
+                                       L.dptr(P["sub_s"]), L.dptr(P["sub_b"]), L.dptr(P["add_s"]), L.dptr(P["add_b"]),
+                                       L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]), L.dptr(P["fc_w2"]), L.dptr(P["fc_b2"]), N,
+                                       P["fc_w1"].shape[0], L.dptr(out), L.optr(prefc), h, w, 0, L.stream()), "sr_tail_fc_f16")
+        if taps is not None:
+            taps[f"prefc{self.num_steps - 1}"] = prefc
+        return out
+
     def _reset_state(self):  # API parity with SRProjectionModule.py:149-150; the state never outlives a forward here
         return None
 
@@ -302,3 +400,70 @@ def ctypes_ptr(view: torch.Tensor):
     if not view.is_cuda or view.dtype != torch.float32 or view.stride(-1) != 1:
         raise L.VsrHipError("weight view must be a CUDA float32 matrix with unit column stride")
     return ctypes.c_void_p(view.data_ptr())
+
+
+def _chunk_channel_order(device):
+    """Channel held at position j of 16-byte chunk g in the HR ring / the MFMA k index (g, j): the accumulator of a
+    16x16 MFMA gives lane group g the output rows {4g..4g+3} of tile 0 and {16+4g..16+4g+3} of tile 1, and that
+    register block is used as-is as the next product's operand (csrc/sr_f16.hip)."""
+    g = torch.arange(4, device=device).view(4, 1)
+    j = torch.arange(8, device=device).view(1, 8)
+    return torch.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4))  # [4,8]
+
+
+def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a) -> torch.Tensor:
+    """Weights of one fused up->tran->down stage in the per-wave MFMA fragment order of csrc/sr_f16.hip.
+
+    up_w [32(in),32(out),8,8] ConvTranspose2d weight; tr_w [32,ld] 1x1 weight whose live slice starts at column
+    tr_col0; dn_w [32(out),32(in),8,8] Conv2d weight.  tr_w/dn_w None -> deconv-only blob (tail).
+    """
+    dev = up_w.device
+    nbytes = int(L.load().vsr_sr_utd_blob_bytes())
+    lane = torch.arange(64, device=dev)
+    col_l, g = lane & 15, lane >> 4
+    j8 = torch.arange(8, device=dev)
+    perm = _chunk_channel_order(dev)  # [4,8]
+    # ---- deconv fragments [w 8][c 2][t 4][mt 2][lane 64][j 8]: A[co][k = 8g + j] for tap t of phase (py, px)
+    W = torch.arange(8, device=dev).view(8, 1, 1, 1, 1, 1)
+    C = torch.arange(2, device=dev).view(1, 2, 1, 1, 1, 1)
+    T = torch.arange(4, device=dev).view(1, 1, 4, 1, 1, 1)
+    MT = torch.arange(2, device=dev).view(1, 1, 1, 2, 1, 1)
+    LN = lane.view(1, 1, 1, 1, 64, 1)
+    J = j8.view(1, 1, 1, 1, 1, 8)
+    ci = 8 * (LN >> 4) + J
+    co = 16 * MT + (LN & 15)
+    ky = (W >> 1) + 4 * (T >> 1)
+    kx = 2 * (W & 1) + C + 4 * (T & 1)
+    ci, co, ky, kx = torch.broadcast_tensors(ci, co, ky, kx)
+    up_frag = up_w.detach().float()[ci, co, ky, kx].to(torch.float16).contiguous()
+    blob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    off_dn = 8 * 16 * 1024
+    off_dt = off_dn + 8 * 16 * 1024
+    off_f = off_dt + 2 * 1024
+    blob[0:off_dn] = up_frag.view(torch.uint8).reshape(-1)
+    fpar = torch.zeros(128, dtype=torch.float32, device=dev)
+    fpar[0:32] = up_b.detach().float()
+    fpar[96] = float(up_a)
+    if dn_w is not None:
+        # ---- down fragments [w 8][kx 8][mt 2][lane 64][j 8]: A[co][k = (g, j)] with the ring's channel order
+        W = torch.arange(8, device=dev).view(8, 1, 1, 1, 1)
+        KX = torch.arange(8, device=dev).view(1, 8, 1, 1, 1)
+        MT = torch.arange(2, device=dev).view(1, 1, 2, 1, 1)
+        co = 16 * MT + col_l.view(1, 1, 1, 64, 1)
+        ci = perm[g].view(1, 1, 1, 64, 8)
+        co, ci, ky, kx = torch.broadcast_tensors(co, ci, W, KX)
+        dn_frag = dn_w.detach().float()[co, ci, ky, kx].to(torch.float16).contiguous()
+        blob[off_dn:off_dt] = dn_frag.view(torch.uint8).reshape(-1)
+        # ---- 1x1 fragments [mt 2][lane 64][j 8]
+        MT = torch.arange(2, device=dev).view(2, 1, 1)
+        co = 16 * MT + col_l.view(1, 64, 1)
+        ci = tr_col0 + perm[g].view(1, 64, 8)
+        co, ci = torch.broadcast_tensors(co, ci)
+        dt_frag = tr_w.detach().float()[co, ci].to(torch.float16).contiguous()
+        blob[off_dt:off_f] = dt_frag.view(torch.uint8).reshape(-1)
+        fpar[32:64] = tr_b.detach().float()
+        fpar[64:96] = dn_b.detach().float()
+        fpar[97] = float(tr_a)
+        fpar[98] = float(dn_a)
+    blob[off_f:off_f + 512] = fpar.view(torch.uint8)
+    return blob
