@@ -1,0 +1,97 @@
+"""CPU-side checks: the C-ABI library builds for gfx950, loads, and exports every symbol include/vsr_hip.h declares
+(no compute without a GPU); host logic of the product modules (state_dict layout, caches, error behaviour)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from video_super_resolution_amd import _lib
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = _lib.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 20 and "vsr_resample2d_f32" in declared and "vsr_sr_utd_f16" in declared
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.vsr_abi_version() == 1
+    lib.vsr_sr_utd_blob_bytes.restype = ctypes.c_size_t
+    assert lib.vsr_sr_utd_blob_bytes() % 16 == 0
+    # code object is built for gfx950 only
+    out = subprocess.run(["strings", path], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_argument_validation_without_a_gpu():
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    assert lib.vsr_resample2d_f32(null, null, null, 1, 3, 8, 8, 1, 1, null) == -1  # VSR_E_ARG, nothing launched
+    assert b"null" in lib.vsr_last_error()
+    oc, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.vsr_correlation_out_shape(64, 120, 20, 1, 20, 1, 2, ctypes.byref(oc), ctypes.byref(oh), ctypes.byref(ow)) == 0
+    assert (oc.value, oh.value, ow.value) == (441, 64, 120)  # reference correlation_cuda.cc:31-34 at 960x512 / 8
+
+
+def test_sr_state_dict_has_the_reference_layout(cpu_vsr):
+    sd = cpu_vsr.model.state_dict()
+    expect = {"sub_mean.weight": (3, 3, 1, 1), "conv_in.0.weight": (128, 3, 3, 3), "conv_in.1.weight": (1,),
+              "feat_in.0.weight": (32, 128, 1, 1), "block.compress_in.0.weight": (32, 64, 1, 1),
+              "block.upBlocks.5.0.weight": (32, 32, 8, 8), "block.downBlocks.0.0.bias": (32,),
+              "block.uptranBlocks.4.0.weight": (32, 192, 1, 1), "block.downtranBlocks.0.0.weight": (32, 64, 1, 1),
+              "block.compress_out.0.weight": (32, 192, 1, 1), "out.0.weight": (32, 32, 8, 8), "out.1.weight": (1,),
+              "conv_out.0.weight": (3, 32, 3, 3), "add_mean.bias": (3,), "fc.0.weight": (32, 8), "fc.2.weight": (1, 32)}
+    for k, shp in expect.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert sum(v.numel() for v in sd.values()) == 910871
+    assert len(cpu_vsr.state_dict()) == 1142 and {"model", "FlowModule", "DepthModule", "VOSModule"} == {
+        k.split(".")[0] for k in cpu_vsr.state_dict()}
+
+
+def test_synthetic_weights_are_name_keyed_and_reproducible(cpu_vsr):
+    from video_super_resolution_amd import SRProjectionModule
+    from video_super_resolution_amd.weights import fill_module_
+    a = fill_module_(SRProjectionModule(), seed=0, prefix="model.").state_dict()
+    for k, v in a.items():
+        assert torch.equal(v, cpu_vsr.model.state_dict()[k]), k
+    b = fill_module_(SRProjectionModule(), seed=1, prefix="model.").state_dict()
+    assert not torch.equal(a["conv_in.0.weight"], b["conv_in.0.weight"])
+    assert torch.equal(a["sub_mean.bias"], b["sub_mean.bias"])  # frozen MeanShift is never regenerated
+
+
+def test_product_refuses_cpu_execution(cpu_vsr):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cpu_vsr(torch.zeros(3, 64, 64, 3), None, None, None, train=False)
+    with pytest.raises(_lib.VsrHipError):
+        cpu_vsr.model(torch.zeros(8, 3, 4, 4))
+    with pytest.raises(ValueError):
+        cpu_vsr(torch.zeros(2, 64, 64, 3), None, None, None, train=False)
+
+
+def test_unsupported_geometries_fail_loudly():
+    from video_super_resolution_amd import SRProjectionModule
+    with pytest.raises(NotImplementedError):
+        SRProjectionModule(upscale_factor=2)  # crashes with a shape mismatch in the reference too
+    with pytest.raises(NotImplementedError):
+        SRProjectionModule(num_features=16)
+
+
+def test_import_path_shim_and_train_mode_keeps_guidance_frozen(cpu_vsr):
+    from network.video_super_resolution import VSR
+    assert VSR is type(cpu_vsr)
+    import copy
+    m = copy.copy(cpu_vsr)
+    m.train()
+    assert not m.DepthModule.training and not m.FlowModule.training and not m.VOSModule.training
+    m.eval()
+
+
+def test_chunk_channel_order_is_a_permutation():
+    from video_super_resolution_amd.sr import _chunk_channel_order
+    p = _chunk_channel_order("cpu")
+    assert sorted(p.reshape(-1).tolist()) == list(range(32))
+    assert p[1].tolist() == [4, 5, 6, 7, 20, 21, 22, 23]
