@@ -50,7 +50,7 @@ def test_stage_row_segments_agree(gpu_vsr_f16):
     for rps in (h, 16, 5, 1):
         out = torch.empty((N, h, w, 32), dtype=torch.float16, device="cuda")
         L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(P["utd"][0], torch.uint8), L.dptr(out, torch.float16),
-                                        N, h, w, rps, 0, L.stream()))
+                                        N, h, w, rps, 0, 1, L.stream()))
         outs.append(out)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])

@@ -7,17 +7,19 @@
 // leaves the CU: a workgroup marches down a strip of 31 LR columns, keeps a ring of 8 HR rows (two groups of
 // four) in LDS, and every LR output row costs one group of new HR rows.
 //
-//   step i (LR output row i), 8 waves, two phases separated by workgroup barriers:
-//     P1  wave w -> HR row 4i+2+(w>>1), column phases 2(w&1), 2(w&1)+1 of the 128-column ring:
+//   One workgroup barrier per LR row.  Between barriers every wave runs two independent pieces of work:
+//     P2(i-1) wave w -> row r' = w&3 of the COMPLETE group G(i-1) = HR rows 4(i-1)+2..+5, out-channel half w>>2 of the
+//           stride-4 conv: M = 16 out-channels, N = 32 LR outputs, K = 8 taps x 32 ch, B straight from the ring
+//           (ds_read_b128, conflict-free by an 80-byte column pitch plus an XOR of the 16-byte chunk index with bits
+//           3-4 of the column).  The same B fragment feeds kernel row ky = r'+4 of output row i-1 (accumulator
+//           carried in registers from the previous step) and kernel row ky = r' of output row i (new carry): each
+//           output row is summed over both groups it touches inside ONE wave, so only a 4-way cross-wave sum is left.
+//     P1(i)   wave w -> HR row 4i+2+(w>>1), column phases 2(w&1), 2(w&1)+1 of the other ring slot:
 //           deconv as 16x16x32 MFMA, M = 32 out-channels (A = weights, register resident), N = 32 LR positions
 //           (B = LR pixels from LDS), K = 4 taps x 32 ch;  PReLU;  the accumulator tile is re-used in place as
 //           the B operand of the 1x1 (K = 32, channel order permuted consistently in the packed weights);
 //           PReLU; 16-byte store of 8 channels into the ring (zero outside the image = the conv's padding).
-//     P2  wave w -> kernel row ky = w of the stride-4 conv: M = 32 out-channels, N = 32 LR outputs, K = 8 taps
-//           x 32 ch, B straight from the ring (ds_read_b128, conflict-free by an 80-byte column pitch plus an
-//           XOR of the 16-byte chunk index with bits 4-5 of the column); fp32 partial tile to LDS.
-//     the 8 partial tiles are summed in a fixed order (deterministic), bias + PReLU, fp16 store (overlaps the
-//     next step's P1).
+//     the 4 partial tiles of the previous row are summed in a fixed order (deterministic), bias + PReLU, fp16 store.
 //   All 64+64+8 weight fragments of a wave stay in VGPRs for the whole march: weights are read from HBM/L2
 //   once per workgroup, activations once per strip (+2 halo columns).
 //
@@ -41,15 +43,17 @@ constexpr int SLOT_PITCH = 4 * ROW_PITCH;
 constexpr int RING_BYTES = 2 * SLOT_PITCH;
 constexpr int PART_PX_PITCH = 144;  // bytes per pixel row of a partial tile (32 fp32 + 16 pad)
 constexpr int PART_W_PITCH = 32 * PART_PX_PITCH;
-constexpr int PART_BYTES = 8 * PART_W_PITCH;
+constexpr int PART_BUF = 4 * PART_W_PITCH;  // one output row: 4 partial tiles (kernel-row pairs)
+constexpr int PART_BYTES = 2 * PART_BUF;    // double buffered
 constexpr int LR_COLS = 33;         // LR columns x0-1 .. x0+31
 constexpr int LR_SLOT = LR_COLS * 64;
 constexpr int LR_BYTES = 3 * LR_SLOT;
-constexpr int UTD_LDS = RING_BYTES + PART_BYTES + LR_BYTES;
+constexpr int BIAS_BYTES = 256 + 2048;  // b_up[32], b_dt[32] fp32 + the two 1x1 weight fragments (re-read per use: VGPR cap)
+constexpr int UTD_LDS = RING_BYTES + PART_BYTES + LR_BYTES + BIAS_BYTES;
 
 // packed weight blob (built by the host, see vsr_sr_utd_blob_layout in include/vsr_hip.h)
 constexpr int BLOB_UP = 0;                    // [wave 8][phase 2][tap 4][mt 2][lane 64][8] fp16
-constexpr int BLOB_DN = 8 * 16 * 1024;        // [wave 8][kx 8][mt 2][lane 64][8] fp16
+constexpr int BLOB_DN = 8 * 16 * 1024;        // [wave 8][lo/hi 2][kx 8][lane 64][8] fp16 (kernel rows w&3, (w&3)+4; co half w>>2)
 constexpr int BLOB_DT = BLOB_DN + 8 * 16 * 1024;  // [mt 2][lane 64][8] fp16
 constexpr int BLOB_F32 = BLOB_DT + 2 * 1024;  // b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn
 constexpr int BLOB_BYTES = BLOB_F32 + 512;
@@ -59,14 +63,42 @@ static_assert(UTD_LDS <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ float prelu(float v, float a) { return v >= 0.0f ? v : v * a; }
 
+// PReLU on packed fp16 pairs: max(v, a*v) for a <= 1, min(v, a*v) for a > 1 (one v_pk_mul + one v_pk_max/min per pair)
+__device__ __forceinline__ h2 prelu_h2(h2 v, h2 a, bool use_max) {
+    const h2 m = v * a;
+    return use_max ? __builtin_elementwise_max(v, m) : __builtin_elementwise_min(v, m);
+}
+
+// Two accumulator registers blocks (rows 4g..4g+3 of tile 0 and tile 1) -> PReLU -> 8 packed fp16, the operand /
+// ring order of this lane.  v_cvt_pk_f16_f32 (round to nearest even) + packed PReLU: 3 VALU per value pair.
+__device__ __forceinline__ h8 act_pack(f4 lo, f4 hi, h2 a, bool use_max) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const h2 p0 = prelu_h2(__builtin_convertvector(f2v{lo[0], lo[1]}, h2), a, use_max);
+    const h2 p1 = prelu_h2(__builtin_convertvector(f2v{lo[2], lo[3]}, h2), a, use_max);
+    const h2 p2 = prelu_h2(__builtin_convertvector(f2v{hi[0], hi[1]}, h2), a, use_max);
+    const h2 p3 = prelu_h2(__builtin_convertvector(f2v{hi[2], hi[3]}, h2), a, use_max);
+    return h8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+}
+
 __device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // byte offset of (column cc, 16-byte chunk) inside a ring row
-__device__ __forceinline__ int ring_off(int cc, int chunk) { return cc * COL_PITCH + ((chunk ^ ((cc >> 4) & 3)) << 4); }
+// (80-byte pitch + chunk XOR column bits 3-4: every ds_read_b128 / ds_write_b128 lane group of the access patterns
+// below lands on distinct banks -- checked by exhaustive simulation of the gfx950 lane groups, tools/lds_bank_sim.py)
+__device__ __forceinline__ int ring_off(int cc, int chunk) { return cc * COL_PITCH + ((chunk ^ ((cc >> 3) & 3)) << 4); }
+// byte offset of (pixel p, 16-byte chunk) inside an LR ring slot (64-byte pitch, chunk XOR pixel bits 1-2)
+__device__ __forceinline__ int lr_off(int p, int chunk) { return p * 64 + ((chunk ^ ((p >> 1) & 3)) << 4); }
+
+constexpr bool kBranchFree = false;
+
+template <bool B>
+struct BoolC { static constexpr bool value = B; };
 
 // MODE 0: full up -> tran -> down stage, `out` = LR map [N,h,w,32] fp16.
 // MODE 1: deconv + PReLU only, `out` = HR map [N,4h,4w,32] fp16 (used for the `out` DeconvBlock of the tail).
-template <int MODE>
+// ALLMAX: every PReLU slope of the stage is <= 1, so prelu(v) = max(v, a*v) (one compare-free packed op);
+//         otherwise both max and min forms are evaluated and selected per slope.
+template <int MODE, bool ALLMAX>
 __global__ void __launch_bounds__(512, 2)
 k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _Float16* __restrict__ out, int h, int w,
       int rows_per_seg) {
@@ -74,6 +106,7 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
     unsigned char* const ring = smem;
     unsigned char* const part = smem + RING_BYTES;
     unsigned char* const lrr = smem + RING_BYTES + PART_BYTES;
+    float* const bias_s = reinterpret_cast<float*>(smem + RING_BYTES + PART_BYTES + LR_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,8 +120,7 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
 
     // ---- weights -> registers (once per workgroup)
     h8 Aup[2][4][2];
-    h8 Adn[8][2];
-    h8 Adt[2];
+    h8 Adn[2][8];  // [0] kernel row w&3 (feeds the next output row), [1] kernel row (w&3)+4 (finishes the current one)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -98,57 +130,77 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
                 Aup[c][t][mt] = *reinterpret_cast<const h8*>(blob + BLOB_UP + ((((wv * 2 + c) * 4 + t) * 2 + mt) * 64 + lane) * 16);
     if (MODE == 0) {
 #pragma unroll
-        for (int kx = 0; kx < 8; ++kx)
+        for (int hl = 0; hl < 2; ++hl)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                Adn[kx][mt] = *reinterpret_cast<const h8*>(blob + BLOB_DN + (((wv * 8 + kx) * 2 + mt) * 64 + lane) * 16);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) Adt[mt] = *reinterpret_cast<const h8*>(blob + BLOB_DT + (mt * 64 + lane) * 16);
+            for (int kx = 0; kx < 8; ++kx)
+                Adn[hl][kx] = *reinterpret_cast<const h8*>(blob + BLOB_DN + (((wv * 2 + hl) * 8 + kx) * 64 + lane) * 16);
+        if (tid < 128) *reinterpret_cast<uint4*>(smem + RING_BYTES + PART_BYTES + LR_BYTES + 256 + tid * 16) =
+            *reinterpret_cast<const uint4*>(blob + BLOB_DT + tid * 16);
     }
+    const unsigned char* const adt_s = smem + RING_BYTES + PART_BYTES + LR_BYTES + 256 + lane * 16;
     const float* fpar = reinterpret_cast<const float*>(blob + BLOB_F32);
-    f4 bup[2], bdt[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bup[mt][r] = fpar[16 * mt + 4 * g + r];
-            bdt[mt][r] = fpar[32 + 16 * mt + 4 * g + r];
-        }
+    if (tid < 64) bias_s[tid] = fpar[tid];
+    // this lane's accumulator rows are channels {4g..4g+3} (tile 0) and {16+4g..16+4g+3} (tile 1)
+    auto bias_up = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f4*>(bias_s + 16 * mt + 4 * g); };
+    auto bias_dt = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f4*>(bias_s + 32 + 16 * mt + 4 * g); };
     const float a_up = fpar[96], a_dt = fpar[97], a_dn = fpar[98];
-    const int rj = tid >> 4, rcp = tid & 15;  // reduce stage: output pixel, channel pair
+    const h2 a_up2 = {(_Float16)a_up, (_Float16)a_up}, a_dt2 = {(_Float16)a_dt, (_Float16)a_dt};
+    const bool up_max = ALLMAX || a_up <= 1.0f, dt_max = ALLMAX || a_dt <= 1.0f;
+    // strips touching the left/right image border are the only ones whose ring holds out-of-image columns
+    const bool edge_strip = (x0 == 0) || (4 * (x0 + 32) - 2 >= 4 * w);
+    // per-lane LDS byte offsets, constant over the march (tap / phase add an immediate):
+    //   ring column cc = 4*j + k, k < 4: (cc>>3)&3 == (j>>1)&3;  4 <= k < 8: == ((j+1)>>1)&3
+    int ring_lo[2], ring_hi[2], lr_b[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = 16 * nt + l15;
+        ring_lo[nt] = j * (4 * COL_PITCH) + ((g ^ ((j >> 1) & 3)) << 4);
+        ring_hi[nt] = j * (4 * COL_PITCH) + ((g ^ (((j + 1) >> 1) & 3)) << 4);
+        lr_b[0][nt] = lr_off(j + 1, g);
+        lr_b[1][nt] = lr_off(j, g);
+    }
+    const int py = wv >> 1, pxb = (wv & 1) * 2;   // P1 role: HR row of the group, first of two column phases
+    const int rr = wv & 3, mth = wv >> 2;         // P2 role: ring row, out-channel half
+    const int rj = tid >> 4, rcp = tid & 15;      // reduce role: output pixel, channel pair
     const float bdn0 = fpar[64 + 2 * rcp], bdn1 = fpar[64 + 2 * rcp + 1];
+    const bool red_ok = (rj < TX) && (x0 + rj < w);
+    const int part_wr = rr * PART_W_PITCH + l15 * PART_PX_PITCH + (16 * mth + 4 * g) * 4;  // + 16*nt*PART_PX_PITCH
+    const int part_rd = rj * PART_PX_PITCH + rcp * 8;                                       // + k*PART_W_PITCH
 
     const _Float16* in_n = in + (size_t)n * h * w * NF;
+    const bool lr_loader = tid < LR_COLS * 4;  // waves 0,1 and four lanes of wave 2
+    const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 1 + lr_px;
+    const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
+    const int lr_st = lr_off(lr_px, lr_ch);
 
-    // LR row r -> 16-byte piece for thread tid (< 132): pixel tid>>2 (column x0-1+px), chunk tid&3; zero outside
+    // LR row r -> 16-byte piece of this thread (zero outside the image)
     auto fetch_lr = [&](int r) __attribute__((always_inline)) -> uint4 {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (tid < LR_COLS * 4) {
-            const int px = tid >> 2, ch = tid & 3, col = x0 - 1 + px;
-            if (r >= 0 && r < h && col >= 0 && col < w)
-                v = *reinterpret_cast<const uint4*>(in_n + ((size_t)r * w + col) * NF + ch * 8);
-        }
+        if (lr_col_ok && r >= 0 && r < h) v = *reinterpret_cast<const uint4*>(in_n + ((size_t)r * w + lr_col) * NF + lr_ch * 8);
         return v;
     };
-    auto stash_lr = [&](int r, uint4 v) __attribute__((always_inline)) {
-        if (tid < LR_COLS * 4) *reinterpret_cast<uint4*>(lrr + ((r + 1) % 3) * LR_SLOT + tid * 16) = v;
-    };
+    // LR ring slot byte offsets rotate with the march (no modulo in the loop): row r lives in slot (r+1) % 3
+    auto lr_slot = [&](int r) __attribute__((always_inline)) { return ((r + 1) % 3) * LR_SLOT; };
 
-    // ---- P1: HR rows of group G(i) = {4i+2 .. 4i+5}
-    auto phase1 = [&](int i) __attribute__((always_inline)) {
-        const int py = wv >> 1, pxb = (wv & 1) * 2;
+    f4 carry[2] = {f4{0.0f, 0.0f, 0.0f, 0.0f}, f4{0.0f, 0.0f, 0.0f, 0.0f}};
+
+    // ---- P1(i): HR rows of group G(i) = {4i+2 .. 4i+5}: reads LR rows i (slot s_i) and i+1 (slot s_i1), writes ring slot
+    //      `rbase`.  CHECK: rows may lie outside the image (first / last group) -> zeros.  EDGE: border strip -> zero
+    //      the out-of-image columns.
+    auto phase1 = [&](int i, int s_i, int s_i1, unsigned char* rbase, auto checkc, auto edgec) __attribute__((always_inline)) {
+        constexpr bool CHECK = decltype(checkc)::value;
+        constexpr bool EDGE = decltype(edgec)::value;
         const int r_hr = 4 * i + 2 + py;
-        unsigned char* const rowbase = ring + (i & 1) * SLOT_PITCH + py * ROW_PITCH;
-        const bool row_ok = (r_hr >= 0) && (r_hr < 4 * h);
+        unsigned char* const rowbase = rbase + py * ROW_PITCH;
+        const bool row_ok = !CHECK || ((r_hr >= 0) && (r_hr < 4 * h));
         if (row_ok) {
             h8 Bf[4][2];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int dy = t >> 1, dx = t & 1;
-                const unsigned char* base = lrr + ((i + 1 - dy + 1) % 3) * LR_SLOT;
+                const unsigned char* base = lrr + (dy ? s_i : s_i1);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    Bf[t][nt] = *reinterpret_cast<const h8*>(base + (16 * nt + l15 - dx + 1) * 64 + g * 16);
+                for (int nt = 0; nt < 2; ++nt) Bf[t][nt] = *reinterpret_cast<const h8*>(base + lr_b[dx][nt]);
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -157,7 +209,7 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = bup[mt];
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = bias_up(mt);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -166,27 +218,20 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
                         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(Aup[c][t][mt], Bf[t][nt], acc[mt][nt]);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    h8 hb;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        hb[r] = (_Float16)prelu(acc[0][nt][r], a_up);
-                        hb[4 + r] = (_Float16)prelu(acc[1][nt][r], a_up);
-                    }
-                    const int q = 16 * nt + l15;
-                    const int c_hr = 4 * (x0 + q) + px - 2;
-                    const bool col_ok = (c_hr >= 0) && (c_hr < 4 * w);
+                    const h8 hb = act_pack(acc[0][nt], acc[1][nt], a_up2, up_max);
+                    const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
                     if (MODE == 0) {
-                        f4 a2[2] = {bdt[0], bdt[1]};
+                        f4 a2[2] = {bias_dt(0), bias_dt(1)};
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) a2[mt] = mfma16(Adt[mt], hb, a2[mt]);
-                        h8 ob;
+                        for (int mt = 0; mt < 2; ++mt) a2[mt] = mfma16(*reinterpret_cast<const h8*>(adt_s + mt * 1024), hb, a2[mt]);
+                        h8 ob = act_pack(a2[0], a2[1], a_dt2, dt_max);
+                        if (EDGE) {
+                            const bool col_ok = (c_hr >= 0) && (c_hr < 4 * w);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            ob[r] = col_ok ? (_Float16)prelu(a2[0][r], a_dt) : (_Float16)0.0f;
-                            ob[4 + r] = col_ok ? (_Float16)prelu(a2[1][r], a_dt) : (_Float16)0.0f;
+                            for (int e = 0; e < 8; ++e) ob[e] = col_ok ? ob[e] : (_Float16)0.0f;
                         }
-                        *reinterpret_cast<h8*>(rowbase + ring_off(4 * q + px, g)) = ob;
-                    } else if (col_ok) {
+                        *reinterpret_cast<h8*>(rowbase + ring_lo[nt] + px * COL_PITCH) = ob;
+                    } else if ((c_hr >= 0) && (c_hr < 4 * w)) {
                         // lane holds channels {4g..4g+3} and {16+4g..16+4g+3} of HR pixel (r_hr, c_hr)
                         _Float16* dst = out + (((size_t)n * 4 * h + r_hr) * (size_t)(4 * w) + c_hr) * NF;
                         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -203,79 +248,102 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    *reinterpret_cast<h8*>(rowbase + ring_off(4 * (16 * nt + l15) + pxb + c, g)) = z;
+                for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<h8*>(rowbase + ring_lo[nt] + (pxb + c) * COL_PITCH) = z;
         }
     };
 
-    // ---- P2: kernel row ky = wv of the stride-4 conv for LR output row i -> fp32 partial tile
-    auto phase2 = [&](int i) __attribute__((always_inline)) {
-        const int ky = wv;
-        const int slot = (ky < 4) ? ((i - 1) & 1) : (i & 1);
-        const unsigned char* const rowbase = ring + slot * SLOT_PITCH + (ky & 3) * ROW_PITCH;
-        f4 acc[2][2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    // ---- P2: row w&3 of the complete group in ring slot `rbase`, out-channel half w>>2.  Finishes an output row (carry +
+    //      upper kernel rows) -> partial tile in `pbase`, and starts the next one (lower kernel rows) -> new carry.
+    auto phase2 = [&](const unsigned char* rbase, unsigned char* pbase) __attribute__((always_inline)) {
+        const unsigned char* const rowbase = rbase + rr * ROW_PITCH;
+        f4 acc[2] = {carry[0], carry[1]};
+        f4 nc[2] = {f4{0.0f, 0.0f, 0.0f, 0.0f}, f4{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
         for (int kx = 0; kx < 8; ++kx)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int cc = 4 * (16 * nt + l15) + kx;
-                const h8 b = *reinterpret_cast<const h8*>(rowbase + ring_off(cc, g));
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma16(Adn[kx][mt], b, acc[mt][nt]);
+                const h8 b = *reinterpret_cast<const h8*>(rowbase + (kx < 4 ? ring_lo[nt] : ring_hi[nt]) + kx * COL_PITCH);
+                acc[nt] = mfma16(Adn[1][kx], b, acc[nt]);
+                nc[nt] = mfma16(Adn[0][kx], b, nc[nt]);
             }
+        carry[0] = nc[0];
+        carry[1] = nc[1];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                *reinterpret_cast<f4*>(part + wv * PART_W_PITCH + (16 * nt + l15) * PART_PX_PITCH + (16 * mt + 4 * g) * 4) =
-                    acc[mt][nt];
+        for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f4*>(pbase + part_wr + 16 * nt * PART_PX_PITCH) = acc[nt];
     };
 
-    // ---- sum the 8 partial tiles of LR row i in a fixed order, bias + PReLU, store
-    auto reduce_store = [&](int i) __attribute__((always_inline)) {
+    // ---- sum the 4 partial tiles of LR row i (buffer `pbase`) in a fixed order, bias + PReLU, store
+    auto reduce_store = [&](int i, const unsigned char* pbase) __attribute__((always_inline)) {
         f2 s = {0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const f2 v = *reinterpret_cast<const f2*>(part + k * PART_W_PITCH + rj * PART_PX_PITCH + rcp * 8);
+        for (int k = 0; k < 4; ++k) {
+            const f2 v = *reinterpret_cast<const f2*>(pbase + part_rd + k * PART_W_PITCH);
             s[0] += v[0];
             s[1] += v[1];
         }
-        if (rj < TX && x0 + rj < w) {
-            h2 o = {(_Float16)prelu(s[0] + bdn0, a_dn), (_Float16)prelu(s[1] + bdn1, a_dn)};
-            *reinterpret_cast<h2*>(out + (((size_t)n * h + i) * w + x0 + rj) * NF + 2 * rcp) = o;
-        }
+        const h2 o = {(_Float16)prelu(s[0] + bdn0, a_dn), (_Float16)prelu(s[1] + bdn1, a_dn)};
+        if (red_ok) *reinterpret_cast<h2*>(out + (((size_t)n * h + i) * w + x0 + rj) * NF + 2 * rcp) = o;
     };
 
-    // ---- prologue: LR rows r0-1, r0 -> LDS (row i+2 is fetched during step i)
-    stash_lr(r0 - 1, fetch_lr(r0 - 1));
-    stash_lr(r0, fetch_lr(r0));
+    // ---- prologue: LR rows r0-1, r0 (and r0+1 for the fused stage, whose first loop step is i = r0) -> LDS;
+    //      row i+2 is fetched during step i
+    if (lr_loader) {
+        *reinterpret_cast<uint4*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
+        *reinterpret_cast<uint4*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
+        if (MODE == 0) *reinterpret_cast<uint4*>(lrr + lr_slot(r0 + 1) + lr_st) = fetch_lr(r0 + 1);
+    }
     __syncthreads();
 
     if (MODE == 0) {
-        // step r0-1 only builds group G(r0-1); steps r0..r1-1 each build G(i) and consume G(i-1), G(i)
-        for (int i = r0 - 1; i < r1; ++i) {
-            const uint4 nxt = fetch_lr(i + 2);  // in flight during the step
-            phase1(i);                          // reads LR rows i, i+1; writes ring slot i&1
-            if (i > r0) reduce_store(i - 1);    // partial tiles of the previous step
-            __syncthreads();
-            if (i >= r0) phase2(i);             // reads both ring slots, writes the partial tiles
-            stash_lr(i + 2, nxt);               // slot of LR row i-1, last read by phase1(i-1)
-            __syncthreads();
-        }
-        reduce_store(r1 - 1);
+        // group G(r0-1): rows 4r0-2 .. 4r0+1 (recomputed halo of the segment, zeros above the image)
+        phase1(r0 - 1, lr_slot(r0 - 1), lr_slot(r0), ring + ((r0 - 1) & 1) * SLOT_PITCH, BoolC<true>{}, BoolC<true>{});
+        __syncthreads();
+        // rotating slot offsets: LR rows i-1, i, i+1; ring / partial buffers of parity i&1 and (i-1)&1
+        int s_im1 = lr_slot(r0 - 1), s_i = lr_slot(r0), s_i1 = lr_slot(r0 + 1);
+        int ring_cur = (r0 & 1) * SLOT_PITCH, part_cur = (r0 & 1) * PART_BUF;
+        auto march = [&](auto edgec) __attribute__((always_inline)) {
+            for (int i = r0; i < r1; ++i) {
+                uint4 nxt = make_uint4(0, 0, 0, 0);
+                if (wv < 3) nxt = fetch_lr(i + 2);  // wave-uniform skip for the five waves that load nothing
+                const unsigned char* ring_prev = ring + (ring_cur ^ SLOT_PITCH);
+                unsigned char* part_prev = part + (part_cur ^ PART_BUF);
+                // steady state: every row of G(i) is inside the image and rows i-1, i-2 belong to this segment.
+                // kBranchFree: one big basic block per step lets hipcc overlap the two phases, but it then hoists
+                // every ds_read and overshoots the 256-VGPR budget (spills to scratch: 2.0 ms vs 1.5 ms measured);
+                // kept off until the block is hand-scheduled with sched_group_barrier.
+                if (kBranchFree && i >= r0 + 2 && i <= h - 2) {
+                    phase2(ring_prev, part_prev);                      // G(i-1) -> partial tiles of row i-1
+                    __builtin_amdgcn_sched_barrier(0);                 // keep the two phases' live ranges apart (VGPR cap)
+                    phase1(i, s_i, s_i1, ring + ring_cur, BoolC<false>{}, edgec);
+                    __builtin_amdgcn_sched_barrier(0);
+                    reduce_store(i - 2, part + part_cur);              // partial buffer of parity (i-2)&1 == i&1
+                } else {
+                    phase2(ring_prev, part_prev);                      // (row r0-1 is never reduced: harmless)
+                    phase1(i, s_i, s_i1, ring + ring_cur, BoolC<true>{}, edgec);
+                    if (i - 2 >= r0) reduce_store(i - 2, part + part_cur);
+                }
+                if (wv < 3 && lr_loader) *reinterpret_cast<uint4*>(lrr + s_im1 + lr_st) = nxt;  // row i+2 -> slot of row i-1
+                __syncthreads();
+                const int t = s_im1; s_im1 = s_i; s_i = s_i1; s_i1 = t;
+                ring_cur ^= SLOT_PITCH;
+                part_cur ^= PART_BUF;
+            }
+        };
+        if (edge_strip) march(BoolC<true>{}); else march(BoolC<false>{});
+        // after the loop *_cur has the parity of r1: row r1-1 lives in the other buffers
+        phase2(ring + (ring_cur ^ SLOT_PITCH), part + (part_cur ^ PART_BUF));
+        if (r1 - 2 >= r0) reduce_store(r1 - 2, part + part_cur);
+        __syncthreads();
+        reduce_store(r1 - 1, part + (part_cur ^ PART_BUF));
     } else {
         // deconv only: groups G(r0-1) .. G(r1-1) cover HR rows 4r0-2 .. 4r1+1; a wave skips rows outside
         // [4r0, 4r1): they belong to the neighbouring segment, or do not exist at the image border.
         for (int i = r0 - 1; i < r1; ++i) {
             const uint4 nxt = fetch_lr(i + 2);
-            const int r_hr = 4 * i + 2 + (wv >> 1);
-            if (r_hr >= 4 * r0 && r_hr < 4 * r1) phase1(i);
+            const int r_hr = 4 * i + 2 + py;
+            if (r_hr >= 4 * r0 && r_hr < 4 * r1) phase1(i, lr_slot(i), lr_slot(i + 1), ring, BoolC<true>{}, BoolC<true>{});
             __syncthreads();
-            stash_lr(i + 2, nxt);
+            if (lr_loader) *reinterpret_cast<uint4*>(lrr + lr_slot(i + 2) + lr_st) = nxt;
             __syncthreads();
         }
     }
@@ -464,26 +532,25 @@ size_t vsr_sr_utd_blob_bytes(void) { return BLOB_BYTES; }
 int vsr_sr_utd_strip_width(void) { return TX; }
 
 int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int deconv_only,
-                   vsr_stream_t stream) {
+                   int slopes_le_one, vsr_stream_t stream) {
     VSR_REQUIRE(in && blob && out, "sr_utd: null pointer");
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_utd: bad shape");
     VSR_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0, "sr_utd: pointers must be 16-byte aligned");
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
     VSR_REQUIRE(segs <= 65535, "sr_utd: too many row segments");
+    typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
+    static const kern_t kerns[4] = {k_utd<0, false>, k_utd<0, true>, k_utd<1, false>, k_utd<1, true>};
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_utd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_utd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS) != hipSuccess)
-            return vsr::fail(VSR_E_LAUNCH, "sr_utd: cannot reserve %d bytes of LDS", UTD_LDS);
+        for (kern_t k : kerns)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS) != hipSuccess)
+                return vsr::fail(VSR_E_LAUNCH, "sr_utd: cannot reserve %d bytes of LDS", UTD_LDS);
         attr_done = true;
     }
-    if (deconv_only)
-        hipLaunchKernelGGL(k_utd<1>, dim3(strips, segs, N), dim3(512), UTD_LDS, vsr::S(stream), (const _Float16*)in,
-                           (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
-    else
-        hipLaunchKernelGGL(k_utd<0>, dim3(strips, segs, N), dim3(512), UTD_LDS, vsr::S(stream), (const _Float16*)in,
-                           (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
+    const kern_t k = kerns[(deconv_only ? 2 : 0) + (slopes_le_one ? 1 : 0)];
+    hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(512), UTD_LDS, vsr::S(stream), (const _Float16*)in,
+                       (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
     return vsr::launched("sr_utd");
 }
 

@@ -166,6 +166,7 @@ class SRProjectionModule(nn.Module):
                                         b.downBlocks[j + 2][0].weight, b.downBlocks[j + 2][0].bias, P["dn_a"][j + 2])
         P["utd_out"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0)
         P["cv_w_pk"] = f(self.conv_out[0].weight.permute(2, 3, 1, 0))  # [dy][dx][ci][3]
+        P["slopes_le_one"] = all(a <= 1.0 for a in P["up_a"] + P["dn_a"] + P["dt_a"] + [P["out_a"]])
         self._pack, self._pack_key = P, key
         self._const.clear()
         self._const_nhwc.clear()
@@ -343,7 +344,8 @@ class SRProjectionModule(nn.Module):
         out = torch.empty((N, 4 * h, 4 * w, _NF) if deconv_only else (N, h, w, _NF), dtype=torch.float16, device=a.device)
         tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else "sr_utd_f16")
         L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
-                                        self._rows_per_segment(N, h, w), int(deconv_only), L.stream()), "sr_utd_f16")
+                                        self._rows_per_segment(N, h, w), int(deconv_only), int(self._pack["slopes_le_one"]),
+                                        L.stream()), "sr_utd_f16")
         L.TIMER.stop(tok)
         return out
 
@@ -445,13 +447,15 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a)
     fpar[0:32] = up_b.detach().float()
     fpar[96] = float(up_a)
     if dn_w is not None:
-        # ---- down fragments [w 8][kx 8][mt 2][lane 64][j 8]: A[co][k = (g, j)] with the ring's channel order
+        # ---- down fragments [w 8][lo/hi 2][kx 8][lane 64][j 8]: wave w owns kernel rows w&3 (lo) and (w&3)+4 (hi) for
+        #      out-channel half w>>2; A[co][k = (g, j)] with the ring's channel order
         W = torch.arange(8, device=dev).view(8, 1, 1, 1, 1)
-        KX = torch.arange(8, device=dev).view(1, 8, 1, 1, 1)
-        MT = torch.arange(2, device=dev).view(1, 1, 2, 1, 1)
-        co = 16 * MT + col_l.view(1, 1, 1, 64, 1)
+        HL = torch.arange(2, device=dev).view(1, 2, 1, 1, 1)
+        KX = torch.arange(8, device=dev).view(1, 1, 8, 1, 1)
+        co = 16 * (W >> 2) + col_l.view(1, 1, 1, 64, 1)
         ci = perm[g].view(1, 1, 1, 64, 8)
-        co, ci, ky, kx = torch.broadcast_tensors(co, ci, W, KX)
+        ky = (W & 3) + 4 * HL
+        co, ci, ky, kx = torch.broadcast_tensors(co, ci, ky, KX)
         dn_frag = dn_w.detach().float()[co, ci, ky, kx].to(torch.float16).contiguous()
         blob[off_dn:off_dt] = dn_frag.view(torch.uint8).reshape(-1)
         # ---- 1x1 fragments [mt 2][lane 64][j 8]
