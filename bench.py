@@ -101,7 +101,7 @@ def main():
 
     h, w = args.lr_h, args.lr_w
     model = fill_module_(VSR().eval(), seed=0).to(dev)
-    model.model.precision = args.precision
+    model.precision = model.model.precision = args.precision
     n_frames = args.steps + args.warmup + 2
     clip = torch.from_numpy(synthetic_clip(rank, n_frames, h, w)).to(dev)  # resident in HBM before timing
     hf = torch.zeros((3, 4 * h, 4 * w, 3), dtype=torch.float32, device=dev)

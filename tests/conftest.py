@@ -50,7 +50,7 @@ def gpu_vsr(cpu_vsr):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     m = copy.deepcopy(cpu_vsr).cuda().eval()
-    m.model.precision = "fp32"  # the exact path: strict parity bars
+    m.precision = m.model.precision = "fp32"  # the exact configuration: strict parity bars
     return m
 
 
@@ -62,5 +62,5 @@ def gpu_vsr_f16(cpu_vsr):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     m = copy.deepcopy(cpu_vsr).cuda().eval()
-    m.model.precision = "fp16"
+    m.precision = m.model.precision = "fp16"
     return m

@@ -95,3 +95,20 @@ def test_chunk_channel_order_is_a_permutation():
     p = _chunk_channel_order("cpu")
     assert sorted(p.reshape(-1).tolist()) == list(range(32))
     assert p[1].tolist() == [4, 5, 6, 7, 20, 21, 22, 23]
+
+
+def test_batchnorm_folding_preserves_the_hourglass(cpu_vsr):
+    """Execution copies fold eval-mode BatchNorm into the preceding conv: same function, 155 fewer layers."""
+    import torch.nn as nn
+    from video_super_resolution_amd.trunks import ExecCopy
+    netg = cpu_vsr.DepthModule.model.netG
+    folded = ExecCopy(netg, fold_bn=True).get(torch.float32)
+    assert folded is not netg
+    assert sum(isinstance(m, nn.BatchNorm2d) for m in netg.modules()) == 155
+    assert sum(isinstance(m, nn.BatchNorm2d) for m in folded.modules()) == 0
+    x = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (1, 3, 32, 48)).astype(np.float32))
+    with torch.no_grad():
+        a, b = netg(x), folded(x)
+    assert (a - b).abs().max() <= 1e-5 * a.abs().max()
+    # the master keeps its parameters and keys
+    assert len(netg.state_dict()) == len(cpu_vsr.DepthModule.model.netG.state_dict())

@@ -10,7 +10,7 @@ def log(*a):
     print(f"[{time.time()-T0:7.2f}s]", *a, flush=True)
 T0 = time.time()
 torch.set_grad_enabled(False)
-m = fill_module_(VSR().eval(), 0).cuda(); m.model.precision = sys.argv[3] if len(sys.argv) > 3 else 'fp16'; log('model ready', m.model.precision)
+m = fill_module_(VSR().eval(), 0).cuda(); m.precision = m.model.precision = sys.argv[3] if len(sys.argv) > 3 else 'fp16'; log('model ready', m.model.precision)
 d = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (3, h, w, 3)).astype(np.float32)).cuda()
 def timed(name, fn, n=2):
     for i in range(n):
@@ -24,5 +24,5 @@ _lib.TIMER.enabled = True
 timed("sr(x8)", lambda: m.model(x8), n=2)
 print(_lib.TIMER.summary(), flush=True)
 _lib.TIMER.enabled = False
-timed("vsr.forward", lambda: m(d, None, None, None, train=False), n=1)
+timed("vsr.forward", lambda: m(d, None, None, None, train=False), n=3)
 log("max mem GB", torch.cuda.max_memory_allocated() / 2**30)

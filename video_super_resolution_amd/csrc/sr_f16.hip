@@ -349,51 +349,73 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
     }
 }
 
-// ---- 1x1 conv over up to three NHWC fp16 inputs (+ fp32 NHWC constant map) + bias + PReLU -> NHWC fp16
+// ---- 1x1 conv over up to three NHWC fp16 inputs (+ fp32 NHWC constant map) + bias + PReLU -> NHWC fp16, on MFMA.
+//      HBM-bound (64 B in per input + 64 B out per pixel).  One wave = 16 consecutive pixels per trip:
+//      B operand = the pixels themselves (lane (px, g) loads the 16-byte chunk g of pixel px: a wave reads 1 KiB
+//      contiguous), A operand = the 32x32 weight slice converted to fp16 once per wave, M = out-channels.
 __global__ void __launch_bounds__(256)
 k_conv1x1_h(const _Float16* __restrict__ in0, const float* __restrict__ w0, int ld0, const _Float16* __restrict__ in1,
             const float* __restrict__ w1, int ld1, const _Float16* __restrict__ in2, const float* __restrict__ w2, int ld2,
             const float* __restrict__ bias, const float* __restrict__ cmap, float slope, _Float16* __restrict__ out,
-            size_t P) {
-    const int n = blockIdx.y;
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
-    float acc[NF];
-#pragma unroll
-    for (int k = 0; k < NF; ++k) acc[k] = bias[k];
-    if (cmap) {
-#pragma unroll
-        for (int k4 = 0; k4 < NF / 4; ++k4) {
-            const f4 c = *reinterpret_cast<const f4*>(cmap + p * NF + 4 * k4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[4 * k4 + e] += c[e];
-        }
-    }
+            size_t P, size_t total_px) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, g = lane >> 4;
     const _Float16* ins[3] = {in0, in1, in2};
     const float* ws[3] = {w0, w1, w2};
     const int lds_[3] = {ld0, ld1, ld2};
+    h8 A[3][2];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        if (!ins[t]) continue;
-        const _Float16* ip = ins[t] + ((size_t)n * P + p) * NF;
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int c8 = 0; c8 < 4; ++c8) {
-            const h8 v = *reinterpret_cast<const h8*>(ip + 8 * c8);
+        for (int mt = 0; mt < 2; ++mt) {
+            h8 a;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = (float)v[e];
+            for (int e = 0; e < 8; ++e) a[e] = (_Float16)0.0f;
+            if (ins[t]) {
+                const float* wr = ws[t] + (size_t)(16 * mt + l15) * lds_[t] + 8 * g;
 #pragma unroll
-                for (int k = 0; k < NF; ++k) acc[k] += ws[t][k * lds_[t] + 8 * c8 + e] * a;
+                for (int e = 0; e < 8; ++e) a[e] = (_Float16)wr[e];
+            }
+            A[t][mt] = a;
+        }
+    f4 bz[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[mt][r] = bias[16 * mt + 4 * g + r];
+    const h2 a2 = {(_Float16)slope, (_Float16)slope};
+    const bool use_max = slope <= 1.0f;
+    const size_t ntiles = (total_px + 15) / 16;
+    const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    for (size_t tile = wave0; tile < ntiles; tile += nwaves) {
+        const size_t px = tile * 16 + l15;            // global pixel index over all images
+        const size_t pc = px < total_px ? px : total_px - 1;
+        f4 acc[2] = {bz[0], bz[1]};
+        if (cmap) {
+            const size_t pp = pc % P;                 // position inside the image (the map is shared by the images)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f4 c = *reinterpret_cast<const f4*>(cmap + pp * NF + 16 * mt + 4 * g);
+                acc[mt] += c;
             }
         }
-    }
-    _Float16* op = out + ((size_t)n * P + p) * NF;
 #pragma unroll
-    for (int c8 = 0; c8 < 4; ++c8) {
-        h8 o;
+        for (int t = 0; t < 3; ++t) {
+            if (!ins[t]) continue;
+            const h8 bfrag = *reinterpret_cast<const h8*>(ins[t] + pc * NF + 8 * g);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (_Float16)prelu(acc[8 * c8 + e], slope);
-        *reinterpret_cast<h8*>(op + 8 * c8) = o;
+            for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma16(A[t][mt], bfrag, acc[mt]);
+        }
+        if (px < total_px) {
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const h2 p0 = prelu_h2(__builtin_convertvector(f2v{acc[mt][0], acc[mt][1]}, h2), a2, use_max);
+                const h2 p1 = prelu_h2(__builtin_convertvector(f2v{acc[mt][2], acc[mt][3]}, h2), a2, use_max);
+                *reinterpret_cast<h4*>(out + px * NF + 16 * mt + 4 * g) = h4{p0[0], p0[1], p1[0], p1[1]};
+            }
+        }
     }
 }
 
@@ -560,9 +582,12 @@ int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* i
     VSR_REQUIRE(in0 && w0 && bias && out, "sr_conv1x1_f16: null pointer");
     VSR_REQUIRE((in1 == nullptr) == (w1 == nullptr) && (in2 == nullptr) == (w2 == nullptr), "sr_conv1x1_f16: input/weight mismatch");
     VSR_REQUIRE(N > 0 && P > 0 && N <= 65535, "sr_conv1x1_f16: bad shape");
-    hipLaunchKernelGGL(k_conv1x1_h, dim3(vsr::cdiv(P, 256), N), dim3(256), 0, vsr::S(stream), (const _Float16*)in0, w0,
-                       ldw0, (const _Float16*)in1, w1, ldw1, (const _Float16*)in2, w2, ldw2, bias, cmap_nhwc, slope,
-                       (_Float16*)out, (size_t)P);
+    const size_t total = (size_t)N * P;
+    const size_t tiles = (total + 15) / 16;
+    const unsigned grid = (unsigned)(tiles / 4 + 1 < 2048 ? tiles / 4 + 1 : 2048);  // 4 waves per block, grid-stride
+    hipLaunchKernelGGL(k_conv1x1_h, dim3(grid), dim3(256), 0, vsr::S(stream), (const _Float16*)in0, w0, ldw0,
+                       (const _Float16*)in1, w1, ldw1, (const _Float16*)in2, w2, ldw2, bias, cmap_nhwc, slope,
+                       (_Float16*)out, (size_t)P, total);
     return vsr::launched("sr_conv1x1_f16");
 }
 

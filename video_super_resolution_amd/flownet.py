@@ -85,7 +85,7 @@ class FlowNetC(_Decoder):
         a2b2 = self.conv2(self.conv1(s))
         a3b3 = self.conv3(a2b2)
         a2, a3, b3 = a2b2[:B], a3b3[:B], a3b3[B:]
-        corr = F.leaky_relu(self.corr(a3, b3), 0.1)
+        corr = F.leaky_relu(self.corr(a3, b3), 0.1).to(a3.dtype)  # the cost volume kernel works in float32
         c3 = self.conv3_1(torch.cat((self.conv_redir(a3), corr), 1))
         c4 = self.conv4_1(self.conv4(c3))
         c5 = self.conv5_1(self.conv5(c4))
@@ -218,22 +218,27 @@ class FlowNet2(nn.Module):
         self.flownetfusion = FlowNetFusion()
 
     def forward(self, inputs):
+        # Normalisation, flows and the warp/norm kernels stay float32 (as in the reference); only the convolution
+        # trunks follow the module's parameter dtype (float32, or float16 on the throughput configuration).
+        dt = self.flownetfusion.predict_flow0.weight.dtype
+        inputs = inputs.float()
         mean = inputs.contiguous().view(inputs.shape[:2] + (-1,)).mean(dim=-1).view(inputs.shape[:2] + (1, 1, 1))
         x = (inputs - mean) / self.rgb_max
         x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1).contiguous()
-        up_bil = lambda t: F.interpolate(t, scale_factor=4, mode="bilinear")
-        up_nn = lambda t: F.interpolate(t, scale_factor=4, mode="nearest")
+        xt = x.to(dt)
+        up_bil = lambda t: F.interpolate(t.float(), scale_factor=4, mode="bilinear")
+        up_nn = lambda t: F.interpolate(t.float(), scale_factor=4, mode="nearest")
 
-        flow_c = up_bil(self.flownetc(x) * self.div_flow)
+        flow_c = up_bil(self.flownetc(xt) * self.div_flow)
         concat1 = ops.warp_concat(x, flow_c, self.div_flow)          # models.py:86-91 in one kernel
-        flow_s1 = up_bil(self.flownets_1(concat1) * self.div_flow)
+        flow_s1 = up_bil(self.flownets_1(concat1.to(dt)) * self.div_flow)
         concat2 = ops.warp_concat(x, flow_s1, self.div_flow)         # :98-103
-        flow_s2 = up_nn(self.flownets_2(concat2) * self.div_flow)
+        flow_s2 = up_nn(self.flownets_2(concat2.to(dt)) * self.div_flow)
         n_s2, d_s2 = ops.warp_norms(x, flow_s2)                      # :108-112
-        flow_sd = up_nn(self.flownets_d(x) / self.div_flow)          # :115-116 (divided)
+        flow_sd = up_nn(self.flownets_d(xt) / self.div_flow)         # :115-116 (divided)
         n_sd, d_sd = ops.warp_norms(x, flow_sd)                      # :117-121
         concat3 = torch.cat((x[:, :3], flow_sd, flow_s2, n_sd, n_s2, d_sd, d_s2), dim=1)
-        return self.flownetfusion(concat3)
+        return self.flownetfusion(concat3.to(dt)).float()
 
 
 class FlowProjectionModule(nn.Module):
@@ -245,8 +250,7 @@ class FlowProjectionModule(nn.Module):
         self.image_size = image_size
         self.render_size = render_size
 
-    @torch.no_grad()
-    def flow(self, input1, input2):
+    def _crop_pair(self, input1, input2):
         h, w = input1.shape[:2]
         th, tw = (h // 64) * 64, (w // 64) * 64
         if th == 0 or tw == 0:
@@ -254,8 +258,19 @@ class FlowProjectionModule(nn.Module):
         self.image_size, self.render_size = (h, w), [th, tw]
         y0, x0 = (h - th) // 2, (w - tw) // 2  # StaticCenterCrop, utils/tools.py:8-14
         images = torch.stack([input1[y0:y0 + th, x0:x0 + tw], input2[y0:y0 + th, x0:x0 + tw]])  # [2,h',w',3]
-        images = images.permute(3, 0, 1, 2).unsqueeze(0)  # [1,3,2,h',w']
-        return self.net(images)[0]  # [2,h',w']
+        return images.permute(3, 0, 1, 2)  # [3,2,h',w']
+
+    @torch.no_grad()
+    def flow(self, input1, input2, net=None):
+        return (net or self.net)(self._crop_pair(input1, input2).unsqueeze(0))[0]  # [2,h',w']
+
+    @torch.no_grad()
+    def forward_pairs(self, pairs, net=None):
+        """Several frame pairs as ONE FlowNet2 batch (independent samples: same arithmetic per pair, fewer and
+        better filled launches) -> list of colour pictures.  `net`: an execution copy of self.net (e.g. fp16)."""
+        batch = torch.stack([self._crop_pair(a, b) for a, b in pairs])  # [B,3,2,h',w']
+        flows = (net or self.net)(batch)
+        return [ops.flow2img(f) for f in flows]  # the colour coding normalises by a per-picture maximum
 
     @torch.no_grad()
     def forward(self, input1, input2):

@@ -67,9 +67,11 @@ class VOSProjectionModule(nn.Module):
         self.register_buffer("meanval", torch.tensor(MEANVAL, dtype=torch.float32), persistent=False)
 
     @torch.no_grad()
-    def forward(self, input1, input2):
-        """[h,w,3] x2 -> [h,w] in {0,1}: sigma(logit_a)+sigma(logit_b) > 0.7 (VOSProjectionModule.py:22-25)."""
+    def forward(self, input1, input2, net=None):
+        """[h,w,3] x2 -> [h,w] in {0,1}: sigma(logit_a)+sigma(logit_b) > 0.7 (VOSProjectionModule.py:22-25).
+        `net`: optional execution copy of self.net (e.g. float16)."""
+        net = net or self.net
         imgs = torch.stack([input1, input2]) - self.meanval  # [2,h,w,3]
-        logits = self.net(imgs.permute(0, 3, 1, 2).contiguous())  # [2,1,h,w]
+        logits = net(imgs.permute(0, 3, 1, 2).contiguous().to(net.fuse.weight.dtype)).float()  # [2,1,h,w]
         s = torch.sigmoid(logits[0, 0]) + torch.sigmoid(logits[1, 0])
         return (s > 0.7).to(torch.float32)

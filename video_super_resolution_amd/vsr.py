@@ -32,6 +32,7 @@ import torch.nn.functional as F
 from .depth import DepthProjectionModule
 from .flownet import FlowProjectionModule
 from .sr import SRProjectionModule
+from .trunks import ExecCopy
 from .vos import VOSProjectionModule
 
 
@@ -48,6 +49,12 @@ class VSR(nn.Module):
         self.DepthModule = DepthProjectionModule().eval()
         self.VOSModule = VOSProjectionModule().eval()
         self.loss_fn: Optional[Callable] = None
+        # "fp16": the headline configuration -- SR stack on the MFMA path, guidance trunks executed from float16
+        #         copies with BatchNorm folded; "fp32": every stage in float32 (the parity configuration).
+        self.precision = "fp16"
+        self._flow_exec = ExecCopy(self.FlowModule.net, fold_bn=False)
+        self._depth_exec = ExecCopy(self.DepthModule.model.netG, fold_bn=True)
+        self._vos_exec = ExecCopy(self.VOSModule.net, fold_bn=False)
 
     def train(self, mode: bool = True):
         # main.py:178 calls model.train(), which would flip the frozen guidance networks (HG BatchNorm!)
@@ -59,18 +66,27 @@ class VSR(nn.Module):
         return self
 
     # ------------------------------------------------------------------------------------------
+    def _trunk_dtype(self):
+        if self.precision not in ("fp16", "fp32"):
+            raise ValueError(f"precision must be 'fp16' or 'fp32', got {self.precision!r}")
+        return torch.float16 if self.precision == "fp16" else torch.float32
+
     @torch.no_grad()
     def _guidance(self, trip, depth_cache):
         """trip: three [h,w,3] frames -> (flow pictures [2,3,h,w], depth planes [2,3,h,w])."""
         h, w = trip[0].shape[:2]
-        pics = torch.stack([self.FlowModule(trip[0], trip[1]), self.FlowModule(trip[1], trip[2])])  # [2,h',w',3]
+        dt = self._trunk_dtype()
+        # both frame pairs as one FlowNet2 batch of two
+        pics = torch.stack(self.FlowModule.forward_pairs([(trip[0], trip[1]), (trip[1], trip[2])], self._flow_exec.get(dt)))
         pics = F.interpolate(pics.permute(0, 3, 1, 2), (h, w))  # nearest back to h x w (:35,:52)
-        z = []
-        for f in trip:
-            key = f.data_ptr()
-            if key not in depth_cache:
-                depth_cache[key] = (f, self.DepthModule.predict(f))  # keep f alive so the pointer stays unique
-            z.append(depth_cache[key][1])
+        # depth trunk once per distinct frame, all new frames as one batch
+        new = [f for f in trip if f.data_ptr() not in depth_cache]
+        if new:
+            netg = self._depth_exec.get(dt)
+            z = netg(torch.stack(new).permute(0, 3, 1, 2).to(dt)).float()  # [k,1,h,w]
+            for i, f in enumerate(new):
+                depth_cache[f.data_ptr()] = (f, z[i:i + 1])  # keep f alive so the pointer stays unique
+        z = [depth_cache[f.data_ptr()][1] for f in trip]
         depth = torch.stack([maskprocess(self.DepthModule.combine(z[0], z[1])),
                              maskprocess(self.DepthModule.combine(z[1], z[2]))])
         return pics, depth
@@ -96,13 +112,14 @@ class VSR(nn.Module):
             else:
                 est = F.interpolate(estimated_image.detach().to(torch.float32).permute(0, 3, 1, 2), (h, w))  # :37
                 est_hw3 = est[0].permute(1, 2, 0).contiguous()
+            self.model.precision = self.precision
             out1 = self.model(torch.cat((frames, pics, depth, est), 0))  # [1,3,4h,4w]
 
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
             mid = F.interpolate(out1, (h, w))[0]  # nearest: HR pixel (4i,4j)
             mid_hw3 = mid.permute(1, 2, 0).contiguous()
             pics2, depth2 = self._guidance((est_hw3, mid_hw3, f2), depth_cache)
-            mask = self.VOSModule(est_hw3, mid_hw3)  # [h,w] in {0,1}
+            mask = self.VOSModule(est_hw3, mid_hw3, self._vos_exec.get(self._trunk_dtype()))  # [h,w] in {0,1}
             masked = torch.where(maskprocess(mask) != 0, torch.zeros_like(mid), mid).unsqueeze(0)  # :58-60
 
             # ---- pass 2 SR (:62-64)
