@@ -162,6 +162,25 @@ int vsr_sr_tail_fc_f16(const void* hr_nhwc, const float* w_out_packed, const flo
                        const float* w1, const float* b1, const float* w2, const float* b2, int nplanes, int hidden,
                        float* out, float* prefc_or_null, int h, int w, int out_nhwc, vsr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Guidance trunks (FlowNet2 models.py:73-128 and networks/FlowNet{C,S,SD,Fusion}.py, depth hourglass pytorch_DIW_scratch.py:34-837, OSVOS
+ * vgg_osvos.py:47-62): one generic NHWC fp16 convolution on MFMA replaces the cuDNN convolutions the reference
+ * calls through torch.nn.Conv2d / ConvTranspose2d.
+ * ------------------------------------------------------------------------------------------ */
+
+/* out[n, oy*oy_mul+oy_off, ox*ox_mul+ox_off, out_coff + co] = act( bias[co] + sum_{ky,kx,ci}
+ *        in[n, oy*stride - pad_y + ky, ox*stride - pad_x + kx, in_coff + ci] * W[co, ci, ky, kx] )      (zero outside)
+ * in  [N,H,W,in_ld] fp16, channel slice [in_coff, in_coff+cin), cin a multiple of 32 (zero padded);
+ * out [N,outH,outW,out_ld] fp16, channel slice [out_coff, out_coff+cout): concatenations are written in place;
+ * (oy_mul, oy_off, ox_mul, ox_off) = (1,0,1,0) for a convolution; a k4 s2 p1 transposed convolution is four launches
+ *   with 2x2 taps, stride 1, (2, py, 2, px) and per-phase weights.
+ * w_packed: fp16 [kh*kw][cin/32][cout_pad][32] (cout_pad = cout rounded up to 16, 32 or a multiple of 64);
+ * bias: fp32 [cout_pad] or NULL.  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  fp32 accumulation. */
+int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
+                        int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
+                        int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
+                        int ox_mul, int ox_off, int act, float slope, vsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,76 @@
+"""The generic NHWC fp16 MFMA convolution (csrc/conv_igemm.hip) against torch.nn.functional on the same fp16-rounded
+operands (fp32 accumulate on both sides): bar 2e-3 of the output range (fp16 output rounding is 4.9e-4)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from video_super_resolution_amd import igemm  # noqa: E402
+
+CASES = [  # (N, Cin, H, W, Cout, k, stride, pad, act)
+    (1, 3, 20, 28, 128, 7, 1, 3, igemm.ACT_RELU),      # hourglass stem
+    (2, 128, 17, 23, 32, 1, 1, 0, igemm.ACT_RELU),     # inception 1x1
+    (1, 32, 19, 21, 32, 7, 1, 3, igemm.ACT_RELU),      # inception 7x7
+    (1, 64, 9, 11, 64, 11, 1, 5, igemm.ACT_RELU),      # inception 11x11
+    (2, 12, 32, 40, 64, 7, 2, 3, igemm.ACT_LEAKY),     # FlowNetS conv1
+    (1, 473, 8, 16, 256, 3, 1, 1, igemm.ACT_LEAKY),    # FlowNetC conv3_1 (odd channel count)
+    (1, 1026, 4, 6, 2, 3, 1, 1, igemm.ACT_NONE),       # predict_flow (2 outputs)
+    (3, 64, 6, 5, 1, 3, 1, 1, igemm.ACT_NONE),         # single output channel
+    (1, 256, 33, 47, 512, 3, 2, 1, igemm.ACT_LEAKY),   # stride 2
+    (1, 96, 130, 3, 48, 3, 1, 1, igemm.ACT_RELU),      # narrow, more pixels than one tile
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_matches_torch(case):
+    N, cin, H, W, cout, k, s, p, act = case
+    rs = np.random.RandomState(cin * 7 + cout)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.conv2d(x.float(), w, b, stride=s, padding=p)
+    if act == igemm.ACT_RELU:
+        ref = F.relu(ref)
+    elif act == igemm.ACT_LEAKY:
+        ref = F.leaky_relu(ref, 0.1)
+    conv = igemm.HConv(w, b, stride=s, pad=p, act=act)
+    out = conv(igemm.to_nhwc_half(x))
+    got = igemm.to_nchw_float(out, cout)
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+    if out.shape[3] > cout:  # padding channels stay zero so the tensor can feed the next layer
+        assert float(out[..., cout:].abs().max()) == 0.0
+
+
+def test_conv_writes_into_channel_slices():
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(rs.randn(1, 64, 10, 12).astype(np.float32)).cuda().half()
+    xs = igemm.to_nhwc_half(x)
+    dst = torch.zeros((1, 10, 12, 96), dtype=torch.float16, device="cuda")
+    convs = []
+    for off, cout in ((0, 32), (32, 16), (48, 48)):
+        w = torch.from_numpy((rs.randn(cout, 64, 3, 3) / 24).astype(np.float32)).cuda().half().float()
+        c = igemm.HConv(w, None, stride=1, pad=1)
+        c(xs, out=dst, out_coff=off)
+        convs.append((off, cout, w))
+    for off, cout, w in convs:
+        ref = F.conv2d(x.float(), w, None, padding=1)
+        got = dst[..., off:off + cout].permute(0, 3, 1, 2).float()
+        assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 7, 9, 32), (2, 1026, 4, 5, 256), (1, 386, 16, 30, 64)])
+def test_transposed_conv_k4s2(shape):
+    N, cin, H, W, cout = shape
+    rs = np.random.RandomState(cin)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cin, cout, 4, 4) / np.sqrt(cin * 4)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.leaky_relu(F.conv_transpose2d(x.float(), w, b, stride=2, padding=1), 0.1)
+    dc = igemm.HDeconv4s2(w, b, act=igemm.ACT_LEAKY)
+    got = igemm.to_nchw_float(dc(igemm.to_nhwc_half(x)), cout)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()

@@ -1,0 +1,196 @@
+// conv_igemm.hip -- generic NHWC fp16 convolution on MFMA (implicit GEMM, no im2col buffer) for the guidance trunks
+// (FlowNet2, depth hourglass, OSVOS: reference models.py / networks/*.py, pytorch_DIW_scratch.py, vgg_osvos.py).
+//
+// GEMM view: rows = out-channels (A operand = weights), columns = output pixels (B operand = input pixels gathered
+// per tap), K = taps x input channels walked as (tap, 32-channel chunk) steps.  With the out-channels on the MFMA
+// rows each lane ends up with 4 consecutive channels of one pixel -> 8-byte NHWC stores.
+//   workgroup: 128 output pixels x BN out-channels (BN = 64 / 32 / 16), 4 waves, wave w owns pixels [32w, 32w+32)
+//   LDS: double-buffered weight tile [BN][32] and pixel tile [128][32] (64-byte rows, chunk index XOR row bits 1-2:
+//        conflict-free ds_read_b128 for the 16x16x32 operand pattern, same scheme as the LR ring of k_utd)
+//   one barrier per K step: global loads of step s+1 are in flight while step s is multiplied
+// Epilogue: + bias (fp32), none / ReLU / LeakyReLU, fp16 store into a channel slice [out_coff, out_coff+Cout) of a
+// tensor with out_ld channels (concatenations are written in place), with an output pixel stride/offset so the four
+// phases of a k4 s2 transposed convolution are four ordinary 2x2-tap launches.
+#include "vsr_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128;  // output pixels per workgroup
+
+struct ConvP {
+    const _Float16* in;
+    const _Float16* wpk;   // [tap][cin/32][cout_pad][32]
+    const float* bias;     // [cout_pad] or null
+    _Float16* out;
+    int in_ld, in_coff, out_ld, out_coff;
+    int N, H, W, cin, Ho, Wo, cout, cout_pad;
+    int kh, kw, stride, pad_y, pad_x;
+    int outH, outW, oy_mul, oy_off, ox_mul, ox_off;
+    int act;
+    float slope;
+};
+
+__device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
+
+template <int BN>
+__global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
+    constexpr int MT = BN / 16;                 // out-channel tiles per wave
+    constexpr int A_BYTES = BN * 64;            // weight tile
+    constexpr int B_BYTES = BM * 64;            // pixel tile
+    constexpr int A_PIECES = A_BYTES / 16;      // 16-byte pieces (<= 256)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+    auto As = [&](int b) __attribute__((always_inline)) { return smem + b * (A_BYTES + B_BYTES); };
+    auto Bs = [&](int b) __attribute__((always_inline)) { return smem + b * (A_BYTES + B_BYTES) + A_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int co0 = blockIdx.y * BN;
+    const int nchunk = p.cin >> 5;
+    const int nk = p.kh * p.kw * nchunk;
+
+    // ---- the two pixel pieces this thread stages per K step: piece q = tid + 256 r -> row q>>2, chunk q&3
+    int pn[2], piy0[2], pix0[2];
+    bool pok[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = (tid + 256 * r) >> 2;
+        const long long m = m0 + row;
+        pok[r] = m < M;
+        const long long mm = pok[r] ? m : 0;
+        const int n = (int)(mm / ((long long)p.Ho * p.Wo));
+        const int rem = (int)(mm - (long long)n * p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        pn[r] = n;
+        piy0[r] = oy * p.stride - p.pad_y;
+        pix0[r] = ox * p.stride - p.pad_x;
+    }
+    const int bchunk = tid & 3;
+    const int brow[2] = {tid >> 2, (tid + 256) >> 2};
+
+    uint4 ra = make_uint4(0, 0, 0, 0), rb[2];
+    auto gload = [&](int ks) __attribute__((always_inline)) {
+        const int tap = ks / nchunk, ch = ks - tap * nchunk;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        if (tid < A_PIECES) {
+            // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0 .. co0+BN-1 are contiguous
+            const _Float16* src = p.wpk + ((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8;
+            ra = *reinterpret_cast<const uint4*>(src);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int iy = piy0[r] + ky, ix = pix0[r] + kx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (pok[r] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                v = *reinterpret_cast<const uint4*>(p.in + (((size_t)pn[r] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff +
+                                                   ch * 32 + bchunk * 8);
+            rb[r] = v;
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        if (tid < A_PIECES) *reinterpret_cast<uint4*>(As(buf) + sw_off(tid >> 2, tid & 3)) = ra;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) *reinterpret_cast<uint4*>(Bs(buf) + sw_off(brow[r], bchunk)) = rb[r];
+    };
+
+    f4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) gload(ks + 1);
+        h8 bf[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const h8*>(Bs(buf) + sw_off(32 * wv + 16 * nt + l15, g));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const h8 af = *reinterpret_cast<const h8*>(As(buf) + sw_off(16 * mt + l15, g));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (ks + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: this lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const long long m = m0 + 32 * wv + 16 * nt + l15;
+        if (m >= M) continue;
+        const int n = (int)(m / ((long long)p.Ho * p.Wo));
+        const int rem = (int)(m - (long long)n * p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
+                        p.out_coff;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c = co0 + 16 * mt + 4 * g;
+            if (c >= p.cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[mt][nt][r] + (p.bias ? p.bias[c + r] : 0.0f);
+                if (p.act == 1) t = fmaxf(t, 0.0f);
+                else if (p.act == 2) t = t >= 0.0f ? t : t * p.slope;
+                v[r] = t;
+            }
+            if (c + 4 <= p.cout && ((p.out_coff + c) & 3) == 0 && (p.out_ld & 3) == 0) {
+                *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < p.cout) dst[c + r] = (_Float16)v[r];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
+                        int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
+                        int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
+                        int ox_mul, int ox_off, int act, float slope, vsr_stream_t stream) {
+    VSR_REQUIRE(in && w_packed && out, "conv2d: null pointer");
+    VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0, "conv2d: bad shape");
+    VSR_REQUIRE(cin > 0 && (cin & 31) == 0, "conv2d: input channels %d must be padded to a multiple of 32", cin);
+    VSR_REQUIRE((in_ld & 7) == 0 && (in_coff & 7) == 0 && in_coff + cin <= in_ld, "conv2d: input slice [%d,+%d) of %d channels", in_coff, cin, in_ld);
+    VSR_REQUIRE(out_coff >= 0 && out_coff + cout <= out_ld, "conv2d: output slice [%d,+%d) of %d channels", out_coff, cout, out_ld);
+    VSR_REQUIRE(cout_pad >= cout && (cout_pad & 15) == 0, "conv2d: cout_pad %d", cout_pad);
+    VSR_REQUIRE((Ho - 1) * oy_mul + oy_off < outH && (Wo - 1) * ox_mul + ox_off < outW && oy_off >= 0 && ox_off >= 0,
+                "conv2d: output window exceeds the destination tensor");
+    VSR_REQUIRE(act >= 0 && act <= 2, "conv2d: activation %d", act);
+    ConvP p;
+    p.in = (const _Float16*)in; p.wpk = (const _Float16*)w_packed; p.bias = bias; p.out = (_Float16*)out;
+    p.in_ld = in_ld; p.in_coff = in_coff; p.out_ld = out_ld; p.out_coff = out_coff;
+    p.N = N; p.H = H; p.W = W; p.cin = cin; p.Ho = Ho; p.Wo = Wo; p.cout = cout; p.cout_pad = cout_pad;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.outH = outH; p.outW = outW; p.oy_mul = oy_mul; p.oy_off = oy_off; p.ox_mul = ox_mul; p.ox_off = ox_off;
+    p.act = act; p.slope = slope;
+    const long long M = (long long)N * Ho * Wo;
+    const unsigned gx = vsr::cdiv(M, BM);
+    // tile width: the widest of 64/32/16 that the padded channel count fills (cout_pad is a multiple of it)
+    if ((cout_pad & 63) == 0) {
+        hipLaunchKernelGGL(k_conv_igemm<64>, dim3(gx, cout_pad / 64), dim3(256), 0, vsr::S(stream), p);
+    } else if ((cout_pad & 31) == 0) {
+        hipLaunchKernelGGL(k_conv_igemm<32>, dim3(gx, cout_pad / 32), dim3(256), 0, vsr::S(stream), p);
+    } else {
+        hipLaunchKernelGGL(k_conv_igemm<16>, dim3(gx, cout_pad / 16), dim3(256), 0, vsr::S(stream), p);
+    }
+    return vsr::launched("conv2d_nhwc_f16");
+}
+
+}  // extern "C"

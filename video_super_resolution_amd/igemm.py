@@ -1,0 +1,113 @@
+"""NHWC fp16 convolution layers on the hand-written MFMA implicit-GEMM kernel (csrc/conv_igemm.hip).
+
+Activations are `[N,H,W,Cp]` float16 tensors whose channel count Cp is padded with zeros to a multiple of 32; a
+layer reads a channel slice and writes a channel slice, so `torch.cat` along channels becomes "write into the
+destination buffer".  Weights are packed once from the master `nn.Conv2d` / `nn.ConvTranspose2d` parameters.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def _cout_pad(c: int) -> int:
+    if c <= 16:
+        return 16
+    if c <= 32:
+        return 32
+    return (c + 63) // 64 * 64
+
+
+def to_nhwc_half(x_nchw: torch.Tensor, cp: int = None) -> torch.Tensor:
+    """[N,C,H,W] any float -> [N,H,W,pad32(C)] float16, zero padded."""
+    N, C, H, W = x_nchw.shape
+    cp = cp or pad32(C)
+    out = torch.zeros((N, H, W, cp), dtype=torch.float16, device=x_nchw.device)
+    out[..., :C] = x_nchw.permute(0, 2, 3, 1)
+    return out
+
+
+def to_nchw_float(x_nhwc: torch.Tensor, c: int) -> torch.Tensor:
+    return x_nhwc[..., :c].permute(0, 3, 1, 2).float()
+
+
+class HConv:
+    """One convolution (+bias +activation) launch.  `weight` [Cout,Cin,kh,kw] float; input slice width = pad32(Cin)
+    unless `cin_layout` gives the positions of the Cin real channels inside a wider padded slice."""
+
+    def __init__(self, weight, bias, stride=1, pad=0, act=ACT_NONE, slope=0.1, cin_layout=None, cin_pad=None):
+        weight = weight.detach().float()
+        cout, cin, kh, kw = weight.shape
+        dev = weight.device
+        self.cout, self.kh, self.kw, self.stride = cout, kh, kw, stride
+        self.pad_y = self.pad_x = pad
+        self.act, self.slope = act, slope
+        self.cin_pad = cin_pad or pad32(cin if cin_layout is None else int(max(cin_layout)) + 1)
+        self.cout_pad = _cout_pad(cout)
+        wfull = torch.zeros((self.cout_pad, self.cin_pad, kh, kw), dtype=torch.float32, device=dev)
+        if cin_layout is None:
+            wfull[:cout, :cin] = weight
+        else:
+            wfull[:cout, torch.as_tensor(cin_layout, device=dev)] = weight
+        # [co][ci][ky][kx] -> [tap][chunk][co][32]
+        wp = wfull.view(self.cout_pad, self.cin_pad // 32, 32, kh * kw).permute(3, 1, 0, 2).contiguous()
+        self.w = wp.to(torch.float16)
+        self.b = None
+        if bias is not None:
+            self.b = torch.zeros(self.cout_pad, dtype=torch.float32, device=dev)
+            self.b[:cout] = bias.detach().float()
+        self.oy = (1, 0)
+        self.ox = (1, 0)
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad_y - self.kh) // self.stride + 1, (W + 2 * self.pad_x - self.kw) // self.stride + 1
+
+    def __call__(self, x, out=None, out_coff=0, in_coff=0, out_hw=None):
+        N, H, W, in_ld = x.shape
+        Ho, Wo = out_hw or self.out_hw(H, W)
+        if out is None:
+            out = torch.zeros((N, Ho * self.oy[0], Wo * self.ox[0], pad32(out_coff + self.cout)), dtype=torch.float16,
+                              device=x.device) if pad32(out_coff + self.cout) != out_coff + self.cout else \
+                torch.empty((N, Ho * self.oy[0], Wo * self.ox[0], out_coff + self.cout), dtype=torch.float16, device=x.device)
+        L.check(L.load().vsr_conv2d_nhwc_f16(
+            L.dptr(x, torch.float16), in_ld, in_coff, L.dptr(self.w, torch.float16), L.optr(self.b), L.dptr(out, torch.float16),
+            out.shape[3], out_coff, N, H, W, self.cin_pad, Ho, Wo, self.cout, self.cout_pad, self.kh, self.kw, self.stride,
+            self.pad_y, self.pad_x, out.shape[1], out.shape[2], self.oy[0], self.oy[1], self.ox[0], self.ox[1], self.act,
+            L.cf(self.slope), L.stream()), "conv2d_nhwc_f16")
+        return out
+
+
+class HDeconv4s2:
+    """ConvTranspose2d(k=4, s=2, p=1) (+bias +activation) as four 2x2-tap phase convolutions.
+    weight [Cin,Cout,4,4].  Output row oy = 2y+py gathers input rows y+a+base(py), a in {0,1}:
+    py=0: base -1, kernel rows (3,1); py=1: base 0, kernel rows (2,0); same along x."""
+
+    def __init__(self, weight, bias, act=ACT_NONE, slope=0.1, cin_pad=None):
+        w = weight.detach().float()  # [Cin,Cout,4,4]
+        self.cout = w.shape[1]
+        self.phases = []
+        kmap = {0: (3, 1), 1: (2, 0)}
+        for py in (0, 1):
+            for px in (0, 1):
+                wk = w[:, :, list(kmap[py]), :][:, :, :, list(kmap[px])]  # [Cin,Cout,2,2]
+                c = HConv(wk.permute(1, 0, 2, 3), bias, stride=1, pad=0, act=act, slope=slope, cin_pad=cin_pad)
+                c.pad_y, c.pad_x = (1 if py == 0 else 0), (1 if px == 0 else 0)
+                c.oy, c.ox = (2, py), (2, px)
+                self.phases.append(c)
+
+    def __call__(self, x, out=None, out_coff=0, in_coff=0):
+        N, H, W, _ = x.shape
+        if out is None:
+            cp = pad32(out_coff + self.cout)
+            out = torch.zeros((N, 2 * H, 2 * W, cp), dtype=torch.float16, device=x.device)
+        for c in self.phases:
+            c(x, out=out, out_coff=out_coff, in_coff=in_coff, out_hw=(H, W))
+        return out

@@ -1,0 +1,399 @@
+"""Executors of the guidance trunks on the hand-written MFMA convolution (igemm.HConv): the fp16 configuration.
+
+Each executor is built from the float32 master module (whose parameters keep the reference's state_dict keys),
+packs every convolution once (eval-mode BatchNorm folded in), and evaluates the same graph as the master's
+`forward` on NHWC float16 tensors.  Channel concatenations are never materialised by a copy: producers write into
+channel slices of the destination buffer.
+
+  HourglassExec  <- depth.build_hourglass()            (reference pytorch_DIW_scratch.py:34-837)
+  FlowNet2Exec   <- flownet.FlowNet2                   (reference models.py:73-128, networks/FlowNet*.py)
+  OSVOSExec      <- vos.OSVOS                          (reference vgg_osvos.py:47-62)
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .depth import HOURGLASS
+from .igemm import ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HDeconv4s2, pad32, to_nhwc_half
+
+
+def _fold(conv: nn.Conv2d, bn):
+    """(weight, bias) of conv followed by eval-mode BatchNorm (or conv alone when bn is None)."""
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if bn is not None:
+        scale = torch.rsqrt(bn.running_var.float() + bn.eps)
+        if bn.affine:
+            scale = scale * bn.weight.detach().float()
+        shift = -bn.running_mean.float() * scale
+        if bn.affine:
+            shift = shift + bn.bias.detach().float()
+        w = w * scale.view(-1, 1, 1, 1)
+        b = b * scale + shift
+    return w, b
+
+
+def _nchw(x):  # NHWC tensor -> NCHW view (channels_last memory) for stock pooling / resize ops
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ hourglass
+class _Inception:
+    """cat(1x1 | 1x1->k1 | 1x1->k2 | 1x1->k3), every conv + BN + ReLU.  One fused launch evaluates all four 1x1s into
+    a work buffer laid out [mid1 | mid2 | mid3 | o0 | o1 | o2 | o3]; the three kxk convs read their mid slice and write
+    their o slice; the block's result is the channel slice [M, M+Ctot) of that buffer."""
+
+    def __init__(self, mod):  # mod: ChannelConcat of 4 Sequentials
+        b0 = mod[0]
+        w0, bb0 = _fold(b0[0], b0[1])
+        ws, bs, self.kconvs = [], [], []
+        mids, outs = [], []
+        for j in (1, 2, 3):
+            br = mod[j]
+            w1, b1 = _fold(br[0], br[1])
+            ws.append(w1)
+            bs.append(b1)
+            mids.append(w1.shape[0])
+            wk, bk = _fold(br[3], br[4])
+            outs.append(wk.shape[0])
+            self.kconvs.append((wk, bk, br[3].kernel_size[0]))
+        self.M = sum(mids)
+        self.o0 = w0.shape[0]
+        self.ctot = self.o0 + sum(outs)
+        self.width = pad32(self.M + self.ctot)
+        self.first = HConv(torch.cat(ws + [w0], 0), torch.cat(bs + [bb0], 0), act=ACT_RELU)
+        packed = []
+        moff, ooff = 0, self.M + self.o0
+        for (wk, bk, k), mid, o in zip(self.kconvs, mids, outs):
+            packed.append((HConv(wk, bk, pad=(k - 1) // 2, act=ACT_RELU), moff, ooff))
+            moff += mid
+            ooff += o
+        self.kconvs = packed
+        self.cin = w0.shape[1]
+
+    def __call__(self, x, in_coff):
+        N, H, W, _ = x.shape
+        buf = torch.empty((N, H, W, self.width), dtype=torch.float16, device=x.device)
+        if self.width != self.M + self.ctot:
+            buf[..., self.M + self.ctot:] = 0
+        self.first(x, out=buf, out_coff=0, in_coff=in_coff)
+        for conv, moff, ooff in self.kconvs:
+            conv(buf, out=buf, out_coff=ooff, in_coff=moff)
+        return buf, self.M, self.ctot
+
+
+class HourglassExec:
+    def __init__(self, netg: nn.Sequential):
+        self.prog = self._build(HOURGLASS, netg)
+
+    def _build(self, node, mod):
+        if isinstance(node, str):
+            return node
+        tag = node[0]
+        if tag == "S":
+            items, children = [], list(mod)
+            i = 0
+            while i < len(node[1]):
+                ch = node[1][i]
+                if isinstance(ch, tuple) and ch[0] == "conv":
+                    # conv [+ bn] [+ relu] fused into one launch
+                    bn = children[i + 1] if i + 1 < len(children) and isinstance(children[i + 1], nn.BatchNorm2d) else None
+                    j = i + (2 if bn is not None else 1)
+                    relu = j < len(children) and isinstance(children[j], nn.ReLU)
+                    w, b = _fold(children[i], bn)
+                    items.append(("conv", HConv(w, b, pad=ch[4], act=ACT_RELU if relu else ACT_NONE), ch[2]))
+                    i = j + (1 if relu else 0)
+                    continue
+                items.append(self._build(ch, children[i]))
+                i += 1
+            return ("S", items)
+        if tag == "M":
+            return ("M", [self._build(c, m) for c, m in zip(node[1], mod)])
+        if tag == "I":
+            return ("I", _Inception(mod))
+        raise ValueError(node)
+
+    def _run(self, node, x, coff, c):
+        """x: NHWC buffer whose live channels are [coff, coff+c) -> (buffer, coff, c)."""
+        if node == "max" or node == "avg":
+            v = _nchw(x[..., coff:coff + c])
+            y = F.max_pool2d(v, 2, 2) if node == "max" else F.avg_pool2d(v, 2, 2)
+            return _nhwc(y), 0, c
+        if node == "up":
+            return _nhwc(F.interpolate(_nchw(x[..., coff:coff + c]), scale_factor=2, mode="nearest")), 0, c
+        tag = node[0]
+        if tag == "conv":
+            out = node[1](x, in_coff=coff)
+            return out, 0, node[2]
+        if tag == "I":
+            buf, m, ctot = node[1](x, coff)
+            return buf, m, ctot
+        if tag == "S":
+            for ch in node[1]:
+                if ch == "+":
+                    (a, ca, na), (b, cb, nb) = x  # list from the preceding fan-out
+                    av, bv = _nchw(a[..., ca:ca + na]), _nchw(b[..., cb:cb + nb])
+                    x, coff, c = _nhwc(F.interpolate(av, bv.shape[-2:]) + bv), 0, nb
+                elif isinstance(ch, tuple) and ch[0] == "M":
+                    x = [self._run(sub, x, coff, c) for sub in ch[1]]
+                else:
+                    x, coff, c = self._run(ch, x, coff, c)
+            return x, coff, c
+        raise ValueError(node)
+
+    @torch.no_grad()
+    def __call__(self, frames_nhwc3: torch.Tensor) -> torch.Tensor:
+        """[k,h,w,3] float frames -> [k,1,h,w] float depth predictions."""
+        k, h, w, _ = frames_nhwc3.shape
+        x = torch.zeros((k, h, w, 32), dtype=torch.float16, device=frames_nhwc3.device)
+        x[..., :3] = frames_nhwc3
+        out, coff, c = self._run(self.prog, x, 0, 32)
+        return out[..., coff:coff + 1].permute(0, 3, 1, 2).float()
+
+
+# ------------------------------------------------------------------------------------------------ FlowNet2
+def _cv(seq, stride=1, act=ACT_LEAKY, cin_pad=None):
+    conv = seq[0] if isinstance(seq, nn.Sequential) else seq
+    k = conv.kernel_size[0]
+    return HConv(conv.weight, conv.bias, stride=conv.stride[0], pad=(k - 1) // 2, act=act, slope=0.1, cin_pad=cin_pad)
+
+
+class _Refine:
+    """Coarse-to-fine decoder shared by FlowNetC/S (predict on the concat) and SD (inter_conv before predict)."""
+
+    def __init__(self, net, with_inter: bool):
+        self.with_inter = with_inter
+        self.pred6 = _cv(net.predict_flow6, act=ACT_NONE)
+        self.levels = []
+        for lvl, cin_cat in ((5, 1026), (4, 770), (3, 386), (2, 194)):
+            dec = getattr(net, f"deconv{lvl}")[0]
+            up = getattr(net, f"upsampled_flow{lvl + 1}_to_{lvl}")
+            item = dict(deconv=HDeconv4s2(dec.weight, dec.bias, act=ACT_LEAKY),
+                        upflow=HDeconv4s2(up.weight, up.bias, act=ACT_NONE),
+                        cat=pad32(cin_cat), dec_c=dec.weight.shape[1])
+            if with_inter:
+                item["inter"] = _cv(getattr(net, f"inter_conv{lvl}"), act=ACT_NONE, cin_pad=pad32(cin_cat))
+                item["pred"] = _cv(getattr(net, f"predict_flow{lvl}"), act=ACT_NONE)
+            else:
+                item["pred"] = _cv(getattr(net, f"predict_flow{lvl}"), act=ACT_NONE, cin_pad=pad32(cin_cat))
+            self.levels.append(item)
+
+    def alloc_cat(self, idx, N, H, W, dev):
+        """Concat buffer of decoder level idx (0 -> level 5 ...) at its resolution; the encoder writes slice 0."""
+        return torch.zeros((N, H, W, self.levels[idx]["cat"]), dtype=torch.float16, device=dev)
+
+    def __call__(self, c6, cats, enc_c):
+        """c6: coarsest features; cats[i]: concat buffer of level 5-i already holding the encoder features in
+        [0, enc_c[i]).  Returns flow2 [N,H/4,W/4,32] (2 live channels)."""
+        flow = self.pred6(c6)
+        src = c6
+        for i, lv in enumerate(self.levels):
+            cat = cats[i]
+            lv["deconv"](src, out=cat, out_coff=enc_c[i])
+            lv["upflow"](flow, out=cat, out_coff=enc_c[i] + lv["dec_c"])
+            flow = lv["pred"](lv["inter"](cat)) if self.with_inter else lv["pred"](cat)
+            src = cat
+        return flow
+
+
+class _FlowNetSExec:
+    def __init__(self, net, cin):
+        self.conv1 = _cv(net.conv1, cin_pad=pad32(cin))
+        self.names = ["conv2", "conv3", "conv3_1", "conv4", "conv4_1", "conv5", "conv5_1", "conv6", "conv6_1"]
+        self.convs = {n: _cv(getattr(net, n)) for n in self.names}
+        self.refine = _Refine(net, with_inter=False)
+
+    def __call__(self, x):
+        N, H, W, _ = x.shape
+        dev = x.device
+        c1 = self.conv1(x)
+        h2, w2 = H // 4, W // 4
+        cats = [self.refine.alloc_cat(i, N, H >> (5 - i), W >> (5 - i), dev) for i in range(4)]  # levels 5,4,3,2
+        # encoder features land directly in their concat buffers: conv2 -> cat2, conv3_1 -> cat3, conv4_1 -> cat4, conv5_1 -> cat5
+        self.convs["conv2"](c1, out=cats[3], out_coff=0)
+        # (a conv reads the leading channel slice of a wider buffer in place: in_ld = buffer width, cin = its own)
+        self.convs["conv3_1"](self.convs["conv3"](cats[3]), out=cats[2], out_coff=0)
+        self.convs["conv4_1"](self.convs["conv4"](cats[2]), out=cats[1], out_coff=0)
+        self.convs["conv5_1"](self.convs["conv5"](cats[1]), out=cats[0], out_coff=0)
+        c6 = self.convs["conv6_1"](self.convs["conv6"](cats[0]))
+        return self.refine(c6, cats, [512, 512, 256, 128])
+
+
+class _FlowNetCExec:
+    def __init__(self, net):
+        self.conv1 = _cv(net.conv1, cin_pad=32)
+        self.conv2, self.conv3 = _cv(net.conv2), _cv(net.conv3)
+        self.redir = _cv(net.conv_redir)
+        self.conv3_1 = _cv(net.conv3_1, cin_pad=pad32(473))
+        self.names = ["conv4", "conv4_1", "conv5", "conv5_1", "conv6", "conv6_1"]
+        self.convs = {n: _cv(getattr(net, n)) for n in self.names}
+        self.refine = _Refine(net, with_inter=False)
+
+    def __call__(self, x6):
+        """x6: [B,H,W,32] with the two normalised frames in channels 0-2 and 3-5."""
+        B, H, W, _ = x6.shape
+        dev = x6.device
+        both = torch.zeros((2 * B, H, W, 32), dtype=torch.float16, device=dev)
+        both[:B, ..., :3] = x6[..., 0:3]
+        both[B:, ..., :3] = x6[..., 3:6]
+        c2 = self.conv2(self.conv1(both))           # [2B,H/4,W/4,128]
+        c3 = self.conv3(c2)                         # [2B,H/8,W/8,256]
+        a3, b3 = c3[:B], c3[B:]
+        corr = ops.correlation(a3.permute(0, 3, 1, 2).float().contiguous(), b3.permute(0, 3, 1, 2).float().contiguous(),
+                               20, 1, 20, 1, 2)     # fp32 NCHW cost volume kernel
+        h8, w8 = H // 8, W // 8
+        cat31 = torch.zeros((B, h8, w8, pad32(473)), dtype=torch.float16, device=dev)
+        self.redir(a3.contiguous(), out=cat31, out_coff=0)
+        cat31[..., 32:473] = F.leaky_relu(corr, 0.1).permute(0, 2, 3, 1)
+        cats = [self.refine.alloc_cat(i, B, H >> (5 - i), W >> (5 - i), dev) for i in range(4)]
+        cats[3][..., :128] = c2[:B]                 # out_conv2a
+        self.conv3_1(cat31, out=cats[2], out_coff=0)
+        self.convs["conv4_1"](self.convs["conv4"](cats[2]), out=cats[1], out_coff=0)
+        self.convs["conv5_1"](self.convs["conv5"](cats[1]), out=cats[0], out_coff=0)
+        c6 = self.convs["conv6_1"](self.convs["conv6"](cats[0]))
+        return self.refine(c6, cats, [512, 512, 256, 128])
+
+
+class _FlowNetSDExec:
+    def __init__(self, net):
+        self.conv0 = _cv(net.conv0, cin_pad=32)
+        self.names = ["conv1", "conv1_1", "conv2", "conv2_1", "conv3", "conv3_1", "conv4", "conv4_1", "conv5", "conv5_1",
+                      "conv6", "conv6_1"]
+        self.convs = {n: _cv(getattr(net, n)) for n in self.names}
+        self.refine = _Refine(net, with_inter=True)
+
+    def __call__(self, x6):
+        N, H, W, _ = x6.shape
+        dev = x6.device
+        c = self.convs
+        c0 = self.conv0(x6)
+        c1 = c["conv1_1"](c["conv1"](c0))
+        cats = [self.refine.alloc_cat(i, N, H >> (5 - i), W >> (5 - i), dev) for i in range(4)]
+        c["conv2_1"](c["conv2"](c1), out=cats[3], out_coff=0)
+        c["conv3_1"](c["conv3"](cats[3]), out=cats[2], out_coff=0)
+        c["conv4_1"](c["conv4"](cats[2]), out=cats[1], out_coff=0)
+        c["conv5_1"](c["conv5"](cats[1]), out=cats[0], out_coff=0)
+        c6 = c["conv6_1"](c["conv6"](cats[0]))
+        return self.refine(c6, cats, [512, 512, 256, 128])
+
+
+class _FusionExec:
+    def __init__(self, net):
+        self.conv0 = _cv(net.conv0, cin_pad=32)
+        self.conv1, self.conv1_1 = _cv(net.conv1), _cv(net.conv1_1)
+        self.conv2, self.conv2_1 = _cv(net.conv2), _cv(net.conv2_1)
+        self.pred2 = _cv(net.predict_flow2, act=ACT_NONE)
+        self.deconv1 = HDeconv4s2(net.deconv1[0].weight, net.deconv1[0].bias, act=ACT_LEAKY)
+        self.up21 = HDeconv4s2(net.upsampled_flow2_to_1.weight, net.upsampled_flow2_to_1.bias)
+        self.inter1 = _cv(net.inter_conv1, act=ACT_NONE, cin_pad=pad32(162))
+        self.pred1 = _cv(net.predict_flow1, act=ACT_NONE)
+        self.deconv0 = HDeconv4s2(net.deconv0[0].weight, net.deconv0[0].bias, act=ACT_LEAKY, cin_pad=pad32(162))
+        self.up10 = HDeconv4s2(net.upsampled_flow1_to_0.weight, net.upsampled_flow1_to_0.bias)
+        self.inter0 = _cv(net.inter_conv0, act=ACT_NONE, cin_pad=pad32(82))
+        self.pred0 = _cv(net.predict_flow0, act=ACT_NONE)
+
+    def __call__(self, x11):
+        N, H, W, _ = x11.shape
+        dev = x11.device
+        cat0 = torch.zeros((N, H, W, pad32(82)), dtype=torch.float16, device=dev)
+        cat1 = torch.zeros((N, H // 2, W // 2, pad32(162)), dtype=torch.float16, device=dev)
+        self.conv0(x11, out=cat0, out_coff=0)                                             # 64
+        self.conv1_1(self.conv1(cat0), out=cat1, out_coff=0)                              # 128
+        c2 = self.conv2_1(self.conv2(cat1))
+        flow2 = self.pred2(c2)
+        self.deconv1(c2, out=cat1, out_coff=128)                                          # 32
+        self.up21(flow2, out=cat1, out_coff=160)                                          # 2
+        flow1 = self.pred1(self.inter1(cat1))
+        self.deconv0(cat1, out=cat0, out_coff=64)                                         # 16
+        self.up10(flow1, out=cat0, out_coff=80)                                           # 2
+        return self.pred0(self.inter0(cat0))
+
+
+class FlowNet2Exec:
+    def __init__(self, net):
+        self.div_flow = net.div_flow
+        self.c = _FlowNetCExec(net.flownetc)
+        self.s1 = _FlowNetSExec(net.flownets_1, 12)
+        self.s2 = _FlowNetSExec(net.flownets_2, 12)
+        self.sd = _FlowNetSDExec(net.flownets_d)
+        self.fusion = _FusionExec(net.flownetfusion)
+
+    @staticmethod
+    def _flow_nchw(t):  # [B,h,w,>=2] half -> [B,2,h,w] float
+        return t[..., :2].permute(0, 3, 1, 2).float()
+
+    @torch.no_grad()
+    def __call__(self, inputs):
+        """inputs [B,3,2,H,W] (0..255) -> flow [B,2,H,W] float32; mirrors flownet.FlowNet2.forward."""
+        inputs = inputs.float()
+        mean = inputs.contiguous().view(inputs.shape[:2] + (-1,)).mean(dim=-1).view(inputs.shape[:2] + (1, 1, 1))
+        x = (inputs - mean) / 255.0
+        x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1).contiguous()  # [B,6,H,W] float32
+        x6 = to_nhwc_half(x)
+        up_bil = lambda t: F.interpolate(self._flow_nchw(t), scale_factor=4, mode="bilinear")
+        up_nn = lambda t: F.interpolate(self._flow_nchw(t), scale_factor=4, mode="nearest")
+        flow_c = up_bil(self.c(x6)) * self.div_flow
+        concat1 = ops.warp_concat(x, flow_c, self.div_flow)
+        flow_s1 = up_bil(self.s1(to_nhwc_half(concat1))) * self.div_flow
+        concat2 = ops.warp_concat(x, flow_s1, self.div_flow)
+        flow_s2 = up_nn(self.s2(to_nhwc_half(concat2))) * self.div_flow
+        n_s2, d_s2 = ops.warp_norms(x, flow_s2)
+        flow_sd = up_nn(self.sd(x6)) / self.div_flow
+        n_sd, d_sd = ops.warp_norms(x, flow_sd)
+        concat3 = torch.cat((x[:, :3], flow_sd, flow_s2, n_sd, n_s2, d_sd, d_s2), dim=1)
+        return self._flow_nchw(self.fusion(to_nhwc_half(concat3)))
+
+
+# ------------------------------------------------------------------------------------------------ OSVOS
+class OSVOSExec:
+    def __init__(self, net):
+        self.stages = []
+        for si, stage in enumerate(net.stages):
+            items = []
+            for m in stage:
+                if isinstance(m, nn.MaxPool2d):
+                    items.append("M")
+                elif isinstance(m, nn.Conv2d):
+                    items.append(HConv(m.weight, m.bias, pad=1, act=ACT_RELU, cin_pad=32 if m.in_channels == 3 else None))
+            self.stages.append(items)
+        self.side = [HConv(m.weight, m.bias, pad=1, act=ACT_NONE) for m in net.side_prep]
+        self.up_w = [m.weight.detach().half() for m in net.upscale]
+        self.up_s = [m.stride[0] for m in net.upscale]
+        self.fuse_w, self.fuse_b = net.fuse.weight.detach().half(), net.fuse.bias.detach().half()
+
+    @torch.no_grad()
+    def __call__(self, x_nchw):
+        """[2,3,h,w] mean-subtracted frames -> fused logit [2,1,h,w] float32."""
+        hh, ww = x_nchw.shape[-2:]
+        x = to_nhwc_half(x_nchw)
+        sides = []
+        for si, items in enumerate(self.stages):
+            for it in items:
+                x = _nhwc(F.max_pool2d(_nchw(x), 2, 2, ceil_mode=True)) if it == "M" else it(x)
+            if si > 0:
+                s = self.side[si - 1](x)  # [2,h',w',32] (16 live)
+                up = F.conv_transpose2d(s[..., :16].permute(0, 3, 1, 2), self.up_w[si - 1], None, stride=self.up_s[si - 1])
+                dh, dw = up.shape[2] - hh, up.shape[3] - ww
+                sides.append(up[:, :, dh // 2: up.shape[2] - (dh - dh // 2), dw // 2: up.shape[3] - (dw - dw // 2)])
+        return F.conv2d(torch.cat(sides, 1), self.fuse_w, self.fuse_b).float()
+
+
+class TrunkExecCache:
+    """Version-checked cache of an executor built from a master module."""
+
+    def __init__(self, master: nn.Module, factory):
+        self.master, self.factory = master, factory
+        self._exec, self._key = None, None
+
+    def get(self):
+        key = tuple((t.data_ptr(), t._version) for t in list(self.master.parameters()) + list(self.master.buffers()))
+        if self._exec is None or key != self._key:
+            self._exec, self._key = self.factory(self.master), key
+        return self._exec

@@ -72,6 +72,6 @@ class VOSProjectionModule(nn.Module):
         `net`: optional execution copy of self.net (e.g. float16)."""
         net = net or self.net
         imgs = torch.stack([input1, input2]) - self.meanval  # [2,h,w,3]
-        logits = net(imgs.permute(0, 3, 1, 2).contiguous().to(net.fuse.weight.dtype)).float()  # [2,1,h,w]
+        logits = net(imgs.permute(0, 3, 1, 2).contiguous()).float()  # [2,1,h,w]
         s = torch.sigmoid(logits[0, 0]) + torch.sigmoid(logits[1, 0])
         return (s > 0.7).to(torch.float32)

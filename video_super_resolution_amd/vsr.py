@@ -32,7 +32,7 @@ import torch.nn.functional as F
 from .depth import DepthProjectionModule
 from .flownet import FlowProjectionModule
 from .sr import SRProjectionModule
-from .trunks import ExecCopy
+from .trunk_exec import FlowNet2Exec, HourglassExec, OSVOSExec, TrunkExecCache
 from .vos import VOSProjectionModule
 
 
@@ -49,12 +49,13 @@ class VSR(nn.Module):
         self.DepthModule = DepthProjectionModule().eval()
         self.VOSModule = VOSProjectionModule().eval()
         self.loss_fn: Optional[Callable] = None
-        # "fp16": the headline configuration -- SR stack on the MFMA path, guidance trunks executed from float16
-        #         copies with BatchNorm folded; "fp32": every stage in float32 (the parity configuration).
+        # "fp16": the headline configuration -- SR stack on the MFMA path, guidance trunks on the hand-written NHWC fp16
+        #         MFMA convolution (trunk_exec.py: BatchNorm folded, concatenations written in place, frames batched);
+        # "fp32": SR stack in exact float32 kernels, trunks on stock float32 convolutions (the parity configuration).
         self.precision = "fp16"
-        self._flow_exec = ExecCopy(self.FlowModule.net, fold_bn=False)
-        self._depth_exec = ExecCopy(self.DepthModule.model.netG, fold_bn=True)
-        self._vos_exec = ExecCopy(self.VOSModule.net, fold_bn=False)
+        self._flow_exec = TrunkExecCache(self.FlowModule.net, FlowNet2Exec)
+        self._depth_exec = TrunkExecCache(self.DepthModule.model.netG, HourglassExec)
+        self._vos_exec = TrunkExecCache(self.VOSModule.net, OSVOSExec)
 
     def train(self, mode: bool = True):
         # main.py:178 calls model.train(), which would flip the frozen guidance networks (HG BatchNorm!)
@@ -66,24 +67,27 @@ class VSR(nn.Module):
         return self
 
     # ------------------------------------------------------------------------------------------
-    def _trunk_dtype(self):
+    def _fast(self) -> bool:
         if self.precision not in ("fp16", "fp32"):
             raise ValueError(f"precision must be 'fp16' or 'fp32', got {self.precision!r}")
-        return torch.float16 if self.precision == "fp16" else torch.float32
+        return self.precision == "fp16"
 
     @torch.no_grad()
     def _guidance(self, trip, depth_cache):
         """trip: three [h,w,3] frames -> (flow pictures [2,3,h,w], depth planes [2,3,h,w])."""
         h, w = trip[0].shape[:2]
-        dt = self._trunk_dtype()
+        fast = self._fast()
         # both frame pairs as one FlowNet2 batch of two
-        pics = torch.stack(self.FlowModule.forward_pairs([(trip[0], trip[1]), (trip[1], trip[2])], self._flow_exec.get(dt)))
+        pics = torch.stack(self.FlowModule.forward_pairs([(trip[0], trip[1]), (trip[1], trip[2])],
+                                                         self._flow_exec.get() if fast else None))
         pics = F.interpolate(pics.permute(0, 3, 1, 2), (h, w))  # nearest back to h x w (:35,:52)
         # depth trunk once per distinct frame, all new frames as one batch
         new = [f for f in trip if f.data_ptr() not in depth_cache]
         if new:
-            netg = self._depth_exec.get(dt)
-            z = netg(torch.stack(new).permute(0, 3, 1, 2).to(dt)).float()  # [k,1,h,w]
+            if fast:
+                z = self._depth_exec.get()(torch.stack(new))  # [k,1,h,w] float32
+            else:
+                z = self.DepthModule.model(torch.stack(new).permute(0, 3, 1, 2))
             for i, f in enumerate(new):
                 depth_cache[f.data_ptr()] = (f, z[i:i + 1])  # keep f alive so the pointer stays unique
         z = [depth_cache[f.data_ptr()][1] for f in trip]
@@ -119,7 +123,7 @@ class VSR(nn.Module):
             mid = F.interpolate(out1, (h, w))[0]  # nearest: HR pixel (4i,4j)
             mid_hw3 = mid.permute(1, 2, 0).contiguous()
             pics2, depth2 = self._guidance((est_hw3, mid_hw3, f2), depth_cache)
-            mask = self.VOSModule(est_hw3, mid_hw3, self._vos_exec.get(self._trunk_dtype()))  # [h,w] in {0,1}
+            mask = self.VOSModule(est_hw3, mid_hw3, self._vos_exec.get() if self._fast() else None)  # [h,w] in {0,1}
             masked = torch.where(maskprocess(mask) != 0, torch.zeros_like(mid), mid).unsqueeze(0)  # :58-60
 
             # ---- pass 2 SR (:62-64)
