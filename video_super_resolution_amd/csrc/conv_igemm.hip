@@ -5,7 +5,8 @@
 // per tap), K = taps x input channels walked as (tap, 32-channel chunk) steps.  With the out-channels on the MFMA
 // rows each lane ends up with 4 consecutive channels of one pixel -> 8-byte NHWC stores.
 //   workgroup: 128 output pixels x BN out-channels (BN = 64 / 32 / 16), 4 waves, wave w owns pixels [32w, 32w+32)
-//   LDS: double-buffered weight tile [BN][32] and pixel tile [128][32] (64-byte rows, chunk index XOR row bits 1-2:
+//   K step = two (tap, chunk) pairs (64 K elements) per barrier; LDS: double-buffered, per pair a weight tile [BN][32]
+//        and a pixel tile [128][32] (64-byte rows, chunk index XOR row bits 1-2:
 //        conflict-free ds_read_b128 for the 16x16x32 operand pattern, same scheme as the LR ring of k_utd)
 //   one barrier per K step: global loads of step s+1 are in flight while step s is multiplied
 // Epilogue: + bias (fp32), none / ReLU / LeakyReLU, fp16 store into a channel slice [out_coff, out_coff+Cout) of a
@@ -39,12 +40,13 @@ __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((
 template <int BN>
 __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     constexpr int MT = BN / 16;                 // out-channel tiles per wave
-    constexpr int A_BYTES = BN * 64;            // weight tile
-    constexpr int B_BYTES = BM * 64;            // pixel tile
-    constexpr int A_PIECES = A_BYTES / 16;      // 16-byte pieces (<= 256)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
-    auto As = [&](int b) __attribute__((always_inline)) { return smem + b * (A_BYTES + B_BYTES); };
-    auto Bs = [&](int b) __attribute__((always_inline)) { return smem + b * (A_BYTES + B_BYTES) + A_BYTES; };
+    constexpr int A_HALF = BN * 64;             // weight tile of one (tap, chunk)
+    constexpr int B_HALF = BM * 64;             // pixel tile of one (tap, chunk)
+    constexpr int STAGE = 2 * (A_HALF + B_HALF);  // one K step = two (tap, chunk) pairs = 64 K elements
+    constexpr int A_PIECES = A_HALF / 16;       // 16-byte pieces per half (<= 256)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    auto As = [&](int b, int hf) __attribute__((always_inline)) { return smem + b * STAGE + hf * (A_HALF + B_HALF); };
+    auto Bs = [&](int b, int hf) __attribute__((always_inline)) { return smem + b * STAGE + hf * (A_HALF + B_HALF) + A_HALF; };
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -52,9 +54,10 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     const long long m0 = (long long)blockIdx.x * BM;
     const int co0 = blockIdx.y * BN;
     const int nchunk = p.cin >> 5;
-    const int nk = p.kh * p.kw * nchunk;
+    const int npair = p.kh * p.kw * nchunk;     // (tap, chunk) pairs
+    const int nk = (npair + 1) >> 1;            // K steps of two pairs (the odd tail pair is zero-filled)
 
-    // ---- the two pixel pieces this thread stages per K step: piece q = tid + 256 r -> row q>>2, chunk q&3
+    // ---- the two pixel pieces this thread stages per pair: piece q = tid + 256 r -> row q>>2, chunk q&3
     int pn[2], piy0[2], pix0[2];
     bool pok[2];
 #pragma unroll
@@ -73,29 +76,36 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     const int bchunk = tid & 3;
     const int brow[2] = {tid >> 2, (tid + 256) >> 2};
 
-    uint4 ra = make_uint4(0, 0, 0, 0), rb[2];
+    uint4 ra[2], rb[2][2];
     auto gload = [&](int ks) __attribute__((always_inline)) {
-        const int tap = ks / nchunk, ch = ks - tap * nchunk;
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        if (tid < A_PIECES) {
-            // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0 .. co0+BN-1 are contiguous
-            const _Float16* src = p.wpk + ((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8;
-            ra = *reinterpret_cast<const uint4*>(src);
-        }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int iy = piy0[r] + ky, ix = pix0[r] + kx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (pok[r] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = *reinterpret_cast<const uint4*>(p.in + (((size_t)pn[r] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff +
-                                                   ch * 32 + bchunk * 8);
-            rb[r] = v;
+        for (int hf = 0; hf < 2; ++hf) {
+            const int pr = 2 * ks + hf;
+            const bool live = pr < npair;
+            const int prc = live ? pr : 0;
+            const int tap = prc / nchunk, ch = prc - tap * nchunk;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            ra[hf] = make_uint4(0, 0, 0, 0);
+            if (live && tid < A_PIECES)  // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0.. contiguous
+                ra[hf] = *reinterpret_cast<const uint4*>(p.wpk + ((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int iy = piy0[r] + ky, ix = pix0[r] + kx;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (live && pok[r] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                    v = *reinterpret_cast<const uint4*>(p.in + (((size_t)pn[r] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff +
+                                                       ch * 32 + bchunk * 8);
+                rb[hf][r] = v;
+            }
         }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
-        if (tid < A_PIECES) *reinterpret_cast<uint4*>(As(buf) + sw_off(tid >> 2, tid & 3)) = ra;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) *reinterpret_cast<uint4*>(Bs(buf) + sw_off(brow[r], bchunk)) = rb[r];
+        for (int hf = 0; hf < 2; ++hf) {
+            if (tid < A_PIECES) *reinterpret_cast<uint4*>(As(buf, hf) + sw_off(tid >> 2, tid & 3)) = ra[hf];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) *reinterpret_cast<uint4*>(Bs(buf, hf) + sw_off(brow[r], bchunk)) = rb[hf][r];
+        }
     };
 
     f4 acc[MT][2];
@@ -110,14 +120,18 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nk) gload(ks + 1);
-        h8 bf[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const h8*>(Bs(buf) + sw_off(32 * wv + 16 * nt + l15, g));
+        for (int hf = 0; hf < 2; ++hf) {
+            h8 bf[2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const h8 af = *reinterpret_cast<const h8*>(As(buf) + sw_off(16 * mt + l15, g));
+            for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const h8*>(Bs(buf, hf) + sw_off(32 * wv + 16 * nt + l15, g));
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) {
+                const h8 af = *reinterpret_cast<const h8*>(As(buf, hf) + sw_off(16 * mt + l15, g));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+            }
         }
         if (ks + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
