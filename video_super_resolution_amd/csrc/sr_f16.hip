@@ -419,48 +419,103 @@ k_conv1x1_h(const _Float16* __restrict__ in0, const float* __restrict__ w0, int 
     }
 }
 
-// ---- head with NHWC fp16 output (same arithmetic as sr_f32.hip:k_head, fp32 math)
+// ---- head on MFMA: sub_mean -> conv_in 3x3 (3->128) + PReLU -> feat_in 1x1 (128->32) + PReLU -> NHWC fp16
+//      (SRProjectionModule.py:135,137-138).  One wave = 16 pixels per trip.  First product: M = 128 mid channels
+//      (8 tiles), K = 27 taps padded to 32, B = the mean-shifted 3x3x3 neighbourhood gathered by the lanes (zero
+//      padding applies after the mean shift).  Its accumulator tiles are PReLU'd, packed and used in place as the B
+//      operand of the 1x1 (K = 128 in four steps; weight K order permuted to the accumulator's channel order).
 __global__ void __launch_bounds__(256)
 k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const float* __restrict__ sub_bias,
          const float* __restrict__ w_in, const float* __restrict__ b_in, float slope_in, int nmid,
          const float* __restrict__ w_feat, const float* __restrict__ b_feat, float slope_feat, _Float16* __restrict__ out,
-         int h, int w) {
-    const int n = blockIdx.y;
-    const size_t hw = (size_t)h * w;
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= hw) return;
-    const int y = (int)(p / w), xx = (int)(p % w);
-    float v[27];
+         int N, int h, int w) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, g = lane >> 4;
+    const size_t hw = (size_t)h * w, total = (size_t)N * hw;
+    // A1[mt]: conv_in weights, row = mid channel 16 mt + l15, k = 8 g + j -> (c, dy, dx) = (k / 9, (k % 9) / 3, k % 3)
+    h8 A1[8], A2[4][2];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int mt = 0; mt < 8; ++mt) {
+        h8 a;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int yy = y + dy - 1, xc = xx + dx - 1;
-                float t = 0.0f;
-                if (yy >= 0 && yy < h && xc >= 0 && xc < w)
-                    t = x[((size_t)n * 3 + c) * hw + (size_t)yy * w + xc] * sub_scale[c] + sub_bias[c];
-                v[c * 9 + dy * 3 + dx] = t;
-            }
-    float acc[NF];
-#pragma unroll
-    for (int k = 0; k < NF; ++k) acc[k] = b_feat[k];
-    for (int j = 0; j < nmid; ++j) {
-        float f = b_in[j];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) f += w_in[j * 27 + k] * v[k];
-        f = prelu(f, slope_in);
-#pragma unroll
-        for (int k = 0; k < NF; ++k) acc[k] += w_feat[k * nmid + j] * f;
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * g + j;
+            a[j] = k < 27 ? (_Float16)w_in[(16 * mt + l15) * 27 + k] : (_Float16)0.0f;
+        }
+        A1[mt] = a;
     }
-    _Float16* op = out + ((size_t)n * hw + p) * NF;
+    // A2[s][mt2]: feat_in weights, row = out channel 16 mt2 + l15, k step s covers mids 32 s + {4g+j | 16+4g+j-4}
 #pragma unroll
-    for (int c8 = 0; c8 < 4; ++c8) {
-        h8 o;
+    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (_Float16)prelu(acc[8 * c8 + e], slope_feat);
-        *reinterpret_cast<h8*>(op + 8 * c8) = o;
+        for (int mt2 = 0; mt2 < 2; ++mt2) {
+            h8 a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int mid = 32 * s4 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+                a[j] = (_Float16)w_feat[(16 * mt2 + l15) * nmid + mid];
+            }
+            A2[s4][mt2] = a;
+        }
+    const h2 a1 = {(_Float16)slope_in, (_Float16)slope_in}, a2 = {(_Float16)slope_feat, (_Float16)slope_feat};
+    const bool max1 = slope_in <= 1.0f, max2 = slope_feat <= 1.0f;
+    // this lane's 8 taps of the 27 (k = 8g + j): channel and offsets are lane constants
+    int tc[8], tdy[8], tdx[8];
+    float ts[8], tb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j, kk = k < 27 ? k : 0;
+        tc[j] = kk / 9;
+        tdy[j] = (kk % 9) / 3 - 1;
+        tdx[j] = kk % 3 - 1;
+        ts[j] = k < 27 ? sub_scale[tc[j]] : 0.0f;
+        tb[j] = k < 27 ? sub_bias[tc[j]] : 0.0f;
+    }
+    const size_t ntiles = (total + 15) / 16;
+    const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    for (size_t tile = wave0; tile < ntiles; tile += nwaves) {
+        const size_t px = tile * 16 + l15;
+        const size_t pc = px < total ? px : total - 1;
+        const int n = (int)(pc / hw);
+        const int rem = (int)(pc - (size_t)n * hw);
+        const int y = rem / w, xx = rem - y * w;
+        h8 bfrag;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int yy = y + tdy[j], xc = xx + tdx[j];
+            float t = 0.0f;
+            if (yy >= 0 && yy < h && xc >= 0 && xc < w) t = x[((size_t)n * 3 + tc[j]) * hw + (size_t)yy * w + xc] * ts[j] + tb[j];
+            bfrag[j] = (_Float16)t;
+        }
+        f4 acc1[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            f4 bz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bz[r] = b_in[16 * mt + 4 * g + r];
+            acc1[mt] = mfma16(A1[mt], bfrag, bz);
+        }
+        f4 acc2[2];
+#pragma unroll
+        for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc2[mt2][r] = b_feat[16 * mt2 + 4 * g + r];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const h8 mid = act_pack(acc1[2 * s4], acc1[2 * s4 + 1], a1, max1);
+#pragma unroll
+            for (int mt2 = 0; mt2 < 2; ++mt2) acc2[mt2] = mfma16(A2[s4][mt2], mid, acc2[mt2]);
+        }
+        if (px < total) {
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int mt2 = 0; mt2 < 2; ++mt2) {
+                const h2 p0 = prelu_h2(__builtin_convertvector(f2v{acc2[mt2][0], acc2[mt2][1]}, h2), a2, max2);
+                const h2 p1 = prelu_h2(__builtin_convertvector(f2v{acc2[mt2][2], acc2[mt2][3]}, h2), a2, max2);
+                *reinterpret_cast<h4*>(out + px * NF + 16 * mt2 + 4 * g) = h4{p0[0], p0[1], p1[0], p1[1]};
+            }
+        }
     }
 }
 
@@ -595,9 +650,12 @@ int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bi
                     float slope_in, int nmid, const float* w_feat, const float* b_feat, float slope_feat, void* out_nhwc,
                     int N, int h, int w, vsr_stream_t stream) {
     VSR_REQUIRE(x && sub_scale3 && sub_bias3 && w_in && b_in && w_feat && b_feat && out_nhwc, "sr_head_f16: null pointer");
-    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && nmid > 0 && N <= 65535, "sr_head_f16: bad shape");
-    hipLaunchKernelGGL(k_head_h, dim3(vsr::cdiv((long long)h * w, 256), N), dim3(256), 0, vsr::S(stream), x, sub_scale3,
-                       sub_bias3, w_in, b_in, slope_in, nmid, w_feat, b_feat, slope_feat, (_Float16*)out_nhwc, h, w);
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0, "sr_head_f16: bad shape");
+    if (nmid != 128) return vsr::fail(VSR_E_UNSUPPORTED, "sr_head_f16: %d mid channels (the reference has 4 x 32)", nmid);
+    const size_t tiles = ((size_t)N * h * w + 15) / 16;
+    const unsigned grid = (unsigned)(tiles / 4 + 1 < 2048 ? tiles / 4 + 1 : 2048);  // 4 waves per block, grid-stride
+    hipLaunchKernelGGL(k_head_h, dim3(grid), dim3(256), 0, vsr::S(stream), x, sub_scale3, sub_bias3, w_in, b_in, slope_in,
+                       nmid, w_feat, b_feat, slope_feat, (_Float16*)out_nhwc, N, h, w);
     return vsr::launched("sr_head_f16");
 }
 
