@@ -175,11 +175,14 @@ int vsr_sr_tail_fc_f16(const void* hr_nhwc, const float* w_out_packed, const flo
  * (oy_mul, oy_off, ox_mul, ox_off) = (1,0,1,0) for a convolution; a k4 s2 p1 transposed convolution is four launches
  *   with 2x2 taps, stride 1, (2, py, 2, px) and per-phase weights.
  * w_packed: fp16 [kh*kw][cin/32][cout_pad][32] (cout_pad = cout rounded up to 16, 32 or a multiple of 64);
- * bias: fp32 [cout_pad] or NULL.  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  fp32 accumulation. */
+ * bias: fp32 [cout_pad] or NULL.  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  fp32 accumulation.
+ * splitk_ws: optional fp32 scratch (splitk_ws_bytes); when the launch cannot fill the chip and K is long, K is split
+ * over grid.z, partial tiles go to the scratch and a second kernel sums them in a fixed order (deterministic). */
 int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
                         int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
                         int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
-                        int ox_mul, int ox_off, int act, float slope, vsr_stream_t stream);
+                        int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
+                        vsr_stream_t stream);
 
 #ifdef __cplusplus
 }

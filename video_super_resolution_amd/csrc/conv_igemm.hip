@@ -33,6 +33,8 @@ struct ConvP {
     int outH, outW, oy_mul, oy_off, ox_mul, ox_off;
     int act;
     float slope;
+    float* ws;      // split-K partial sums [splits][M][cout_pad] fp32, or null
+    int splits;
 };
 
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
@@ -55,7 +57,12 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     const int co0 = blockIdx.y * BN;
     const int nchunk = p.cin >> 5;
     const int npair = p.kh * p.kw * nchunk;     // (tap, chunk) pairs
-    const int nk = (npair + 1) >> 1;            // K steps of two pairs (the odd tail pair is zero-filled)
+    const int nk_all = (npair + 1) >> 1;        // K steps of two pairs (the odd tail pair is zero-filled)
+    // split-K (small pixel counts with long K, e.g. the 1/32 and 1/64-resolution FlowNet layers): blockIdx.z owns a
+    // contiguous range of K steps and writes an fp32 partial tile; k_splitk_finish sums them in a fixed order
+    const int ks_per = (nk_all + p.splits - 1) / p.splits;
+    const int ks0 = blockIdx.z * ks_per;
+    const int nk = min(nk_all, ks0 + ks_per);
 
     // ---- the two pixel pieces this thread stages per pair: piece q = tid + 256 r -> row q>>2, chunk q&3
     int pn[2], piy0[2], pix0[2];
@@ -114,10 +121,12 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    gload(0);
-    lstore(0);
+    if (ks0 < nk) {
+        gload(ks0);
+        lstore(ks0 & 1);
+    }
     __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
+    for (int ks = ks0; ks < nk; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nk) gload(ks + 1);
 #pragma unroll
@@ -142,6 +151,12 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     for (int nt = 0; nt < 2; ++nt) {
         const long long m = m0 + 32 * wv + 16 * nt + l15;
         if (m >= M) continue;
+        if (p.splits > 1) {
+            float* wsp = p.ws + ((size_t)blockIdx.z * M + m) * p.cout_pad + co0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4*>(wsp + 16 * mt + 4 * g) = acc[mt][nt];
+            continue;
+        }
         const int n = (int)(m / ((long long)p.Ho * p.Wo));
         const int rem = (int)(m - (long long)n * p.Ho * p.Wo);
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -170,6 +185,32 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     }
 }
 
+// sums the split-K partials in a fixed order, + bias, activation, fp16 store (4 channels per thread)
+__global__ void __launch_bounds__(256) k_splitk_finish(const ConvP p) {
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const int c4n = p.cout_pad >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * c4n) return;
+    const long long m = idx / c4n;
+    const int c = (int)(idx - m * c4n) * 4;
+    if (c >= p.cout) return;
+    f4 s = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int z = 0; z < p.splits; ++z) s += *reinterpret_cast<const f4*>(p.ws + ((size_t)z * M + m) * p.cout_pad + c);
+    const int n = (int)(m / ((long long)p.Ho * p.Wo));
+    const int rem = (int)(m - (long long)n * p.Ho * p.Wo);
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
+                    p.out_coff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (c + r >= p.cout) break;
+        float t = s[r] + (p.bias ? p.bias[c + r] : 0.0f);
+        if (p.act == 1) t = fmaxf(t, 0.0f);
+        else if (p.act == 2) t = t >= 0.0f ? t : t * p.slope;
+        dst[c + r] = (_Float16)t;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -177,7 +218,8 @@ extern "C" {
 int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
                         int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
                         int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
-                        int ox_mul, int ox_off, int act, float slope, vsr_stream_t stream) {
+                        int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
+                        vsr_stream_t stream) {
     VSR_REQUIRE(in && w_packed && out, "conv2d: null pointer");
     VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0, "conv2d: bad shape");
     VSR_REQUIRE(cin > 0 && (cin & 31) == 0, "conv2d: input channels %d must be padded to a multiple of 32", cin);
@@ -196,13 +238,28 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
     p.act = act; p.slope = slope;
     const long long M = (long long)N * Ho * Wo;
     const unsigned gx = vsr::cdiv(M, BM);
-    // tile width: the widest of 64/32/16 that the padded channel count fills (cout_pad is a multiple of it)
-    if ((cout_pad & 63) == 0) {
-        hipLaunchKernelGGL(k_conv_igemm<64>, dim3(gx, cout_pad / 64), dim3(256), 0, vsr::S(stream), p);
-    } else if ((cout_pad & 31) == 0) {
-        hipLaunchKernelGGL(k_conv_igemm<32>, dim3(gx, cout_pad / 32), dim3(256), 0, vsr::S(stream), p);
-    } else {
-        hipLaunchKernelGGL(k_conv_igemm<16>, dim3(gx, cout_pad / 16), dim3(256), 0, vsr::S(stream), p);
+    const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);  // widest tile the padded count fills
+    const unsigned gy = cout_pad / bn;
+    // split-K when the launch cannot fill the chip and K is long
+    const int nk_all = (kh * kw * (cin >> 5) + 1) >> 1;
+    int splits = 1;
+    if (splitk_ws && (long long)gx * gy < 128 && nk_all >= 8) {
+        splits = (int)(256 / ((long long)gx * gy));
+        if (splits > nk_all / 4) splits = nk_all / 4;
+        if (splits > 32) splits = 32;
+        while (splits > 1 && (size_t)splits * M * cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
+        if (splits < 1) splits = 1;
+    }
+    p.ws = splits > 1 ? (float*)splitk_ws : nullptr;
+    p.splits = splits;
+    const dim3 grid(gx, gy, splits);
+    if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, vsr::S(stream), p);
+    else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, vsr::S(stream), p);
+    else hipLaunchKernelGGL(k_conv_igemm<16>, grid, dim3(256), 0, vsr::S(stream), p);
+    if (splits > 1) {
+        int rc = vsr::launched("conv2d_nhwc_f16");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_splitk_finish, dim3(vsr::cdiv(M * (cout_pad >> 2), 256)), dim3(256), 0, vsr::S(stream), p);
     }
     return vsr::launched("conv2d_nhwc_f16");
 }

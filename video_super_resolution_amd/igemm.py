@@ -11,7 +11,19 @@ import torch.nn as nn
 
 from . import _lib as L
 
+import ctypes
+
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+_WS_BYTES = 64 << 20
+_ws = {}
+
+
+def _splitk_ws(device) -> torch.Tensor:
+    """One fp32 scratch buffer per device for split-K partial tiles (kernels are stream-ordered, so it is reused)."""
+    key = (device.type, device.index)
+    if key not in _ws:
+        _ws[key] = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
+    return _ws[key]
 
 
 def pad32(c: int) -> int:
@@ -81,7 +93,7 @@ class HConv:
             L.dptr(x, torch.float16), in_ld, in_coff, L.dptr(self.w, torch.float16), L.optr(self.b), L.dptr(out, torch.float16),
             out.shape[3], out_coff, N, H, W, self.cin_pad, Ho, Wo, self.cout, self.cout_pad, self.kh, self.kw, self.stride,
             self.pad_y, self.pad_x, out.shape[1], out.shape[2], self.oy[0], self.oy[1], self.ox[0], self.ox[1], self.act,
-            L.cf(self.slope), L.stream()), "conv2d_nhwc_f16")
+            L.cf(self.slope), L.dptr(_splitk_ws(x.device)), ctypes.c_size_t(_WS_BYTES), L.stream()), "conv2d_nhwc_f16")
         return out
 
 
