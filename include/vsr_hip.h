@@ -154,6 +154,19 @@ int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bi
                     float slope_in, int nmid, const float* w_feat, const float* b_feat, float slope_feat, void* out_nhwc,
                     int N, int h, int w, vsr_stream_t stream);
 
+/* Fused tail: hid [N,h,w,32] fp16 -> `out` DeconvBlock -> conv_out 3x3 + bilinear x4 skip of sub_mean(x) + add_mean
+ * -> pre-fusion planes prefc [N,3,4h,4w] fp32 (SRProjectionModule.py:118-123,136,142-143); the x4 feature map stays in
+ * LDS (ring of 12 HR rows).  blob: a deconv-only vsr_sr_utd blob of the `out` block; conv_out_frags: 9 MFMA
+ * A-fragments [tap][lane 64][8] fp16 with channel c in row 4c (sr.py:pack_conv_out_frags); tail_params: fp32
+ * b_out[3] sub_scale[3] sub_bias[3] add_scale[3] add_bias[3]; x [N,3,h,w] fp32. */
+int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,
+                    const float* x, float* prefc, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                    vsr_stream_t stream);
+
+/* The fusion MLP (vsr_sr_fc_fuse_f32) specialised and unrolled for the reference's 8 planes x 32 hidden units. */
+int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,
+                         int nplanes, int hidden, float* out, int P, int out_nhwc, vsr_stream_t stream);
+
 /* conv_out 3x3 + bilinear skip + add_mean + fusion MLP in one pass over the HR map of all planes
  * (SRProjectionModule.py:136,142-143,146).  hr_nhwc [8,4h,4w,32] fp16; w_out_packed = conv_out weight [3,32,3,3]
  * permuted to [dy][dx][ci][3]; out [3,4h,4w] (or [4h,4w,3] if out_nhwc); prefc_or_null: optional [8,3,4h,4w] tap. */

@@ -600,6 +600,212 @@ k_tail_fc_h(const _Float16* __restrict__ hr, const float* __restrict__ w_pk, con
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused tail:  hid -> `out` DeconvBlock (ConvTranspose k8 s4 p2 + PReLU) -> conv_out 3x3 (32->3) + bilinear x4 skip of
+// sub_mean(x) + add_mean  ->  pre-fusion planes [N,3,4h,4w] fp32 (SRProjectionModule.py:136,142-143), the x4 feature map
+// staying in LDS.  Same march as k_utd, with a ring of THREE groups of four HR rows: while P1(i) writes group G(i),
+// P3(i) reads the complete groups G(i-2), G(i-1) and emits HR rows 4i-5 .. 4i-2 (3x3 needs one row above and below).
+//   P3: wave w -> output row 4i-5+(w>>1), column half w&1 of the strip's own 124 HR columns, 4 tiles of 16 pixels:
+//       M = 16 rows of which rows 0, 4, 8 carry the 3 output channels (so lane groups g = 0,1,2 each finish one
+//       channel), N = 16 pixels, K = 9 taps x 32 ch, B straight from the ring.
+template <bool ALLMAX>
+__global__ void __launch_bounds__(512, 2)
+k_tail(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, const unsigned char* __restrict__ acv,
+       const float* __restrict__ tpar, const float* __restrict__ x, float* __restrict__ prefc, int h, int w, int rows_per_seg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RING3 = 3 * SLOT_PITCH;
+    unsigned char* const ring = smem;
+    unsigned char* const lrr = smem + RING3;
+    float* const bias_s = reinterpret_cast<float*>(smem + RING3 + LR_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int x0 = blockIdx.x * TX;
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_seg;
+    const int r1 = min(h, r0 + rows_per_seg);
+    if (r0 >= r1) return;
+    const int H = 4 * h, W = 4 * w;
+
+    h8 Aup[2][4][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                Aup[c][t][mt] = *reinterpret_cast<const h8*>(blob + BLOB_UP + ((((wv * 2 + c) * 4 + t) * 2 + mt) * 64 + lane) * 16);
+    h8 Acv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) Acv[t] = *reinterpret_cast<const h8*>(acv + (t * 64 + lane) * 16);
+    const float* fpar = reinterpret_cast<const float*>(blob + BLOB_F32);
+    if (tid < 32) bias_s[tid] = fpar[tid];
+    auto bias_up = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f4*>(bias_s + 16 * mt + 4 * g); };
+    const float a_up = fpar[96];
+    const h2 a_up2 = {(_Float16)a_up, (_Float16)a_up};
+    const bool up_max = ALLMAX || a_up <= 1.0f;
+    // tail parameters of this lane's output channel (lane group g < 3 finishes channel g)
+    const int ch = g < 3 ? g : 0;
+    const float b_out = tpar[ch], sub_s = tpar[3 + ch], sub_b = tpar[6 + ch], add_s = tpar[9 + ch], add_b = tpar[12 + ch];
+
+    int ring_lo[2], lr_b[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = 16 * nt + l15;
+        ring_lo[nt] = j * (4 * COL_PITCH) + ((g ^ ((j >> 1) & 3)) << 4);
+        lr_b[0][nt] = lr_off(j + 1, g);
+        lr_b[1][nt] = lr_off(j, g);
+    }
+    const int py = wv >> 1, pxb = (wv & 1) * 2;
+    const _Float16* in_n = in + (size_t)n * h * w * NF;
+    const bool lr_loader = tid < LR_COLS * 4;
+    const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 1 + lr_px;
+    const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
+    const int lr_st = lr_off(lr_px, lr_ch);
+    auto fetch_lr = [&](int r) __attribute__((always_inline)) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (lr_col_ok && r >= 0 && r < h) v = *reinterpret_cast<const uint4*>(in_n + ((size_t)r * w + lr_col) * NF + lr_ch * 8);
+        return v;
+    };
+    auto lr_slot = [&](int r) __attribute__((always_inline)) { return ((r + 1) % 3) * LR_SLOT; };
+    auto ring_slot = [&](int gi) __attribute__((always_inline)) { return ring + ((gi + 3) % 3) * SLOT_PITCH; };
+
+    // ---- P1(i): group G(i) = HR rows 4i+2 .. 4i+5 of PReLU(deconv), zeros outside the image
+    auto phase1 = [&](int i) __attribute__((always_inline)) {
+        const int r_hr = 4 * i + 2 + py;
+        unsigned char* const rowbase = ring_slot(i) + py * ROW_PITCH;
+        if (r_hr >= 0 && r_hr < H) {
+            h8 Bf[4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int dy = t >> 1, dx = t & 1;
+                const unsigned char* base = lrr + lr_slot(i + 1 - dy);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) Bf[t][nt] = *reinterpret_cast<const h8*>(base + lr_b[dx][nt]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int px = pxb + c;
+                f4 acc[2][2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = bias_up(mt);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(Aup[c][t][mt], Bf[t][nt], acc[mt][nt]);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    h8 hb = act_pack(acc[0][nt], acc[1][nt], a_up2, up_max);
+                    const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
+                    const bool col_ok = (c_hr >= 0) && (c_hr < W);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hb[e] = col_ok ? hb[e] : (_Float16)0.0f;
+                    *reinterpret_cast<h8*>(rowbase + ring_lo[nt] + px * COL_PITCH) = hb;
+                }
+            }
+        } else {
+            h8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<h8*>(rowbase + ring_lo[nt] + (pxb + c) * COL_PITCH) = z;
+        }
+    };
+
+    // ---- P3(i): HR output row R = 4i-5+(w>>1) from groups G(i-2), G(i-1)
+    auto phase3 = [&](int i) __attribute__((always_inline)) {
+        const int R = 4 * i - 5 + (wv >> 1);
+        if (R < 4 * r0 || R >= 4 * r1) return;  // wave-uniform: row of another segment / outside the image
+        const int half = wv & 1;
+        f4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ra = R + dy - 1;                       // HR row of this tap, in [4i-6, 4i-1]
+            const int gi = (ra >= 4 * i - 2) ? i - 1 : i - 2;  // its group; row inside the group = ra - (4 gi + 2)
+            const unsigned char* rowbase = ring_slot(gi) + (ra - (4 * gi + 2)) * ROW_PITCH;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int cc = 2 + 62 * half + 16 * t + l15 + dx - 1;  // ring column of the tap, <= 127
+                    const h8 b = *reinterpret_cast<const h8*>(rowbase + ring_off(cc, g));
+                    acc[t] = mfma16(Acv[dy * 3 + dx], b, acc[t]);
+                }
+        }
+        // lane group g < 3 holds channel g in accumulator row 4g (register 0)
+        int y0, y1;
+        float ly;
+        bil4(R, h, y0, y1, ly);
+        const float* xp = x + ((size_t)n * 3 + ch) * (size_t)h * w;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oc = 62 * half + 16 * t + l15;  // column inside the strip's 124 own HR columns
+            const int c = 4 * x0 + oc;
+            if (g < 3 && oc < 62 * (half + 1) && c < W) {
+                int x0i, x1i;
+                float lx;
+                bil4(c, w, x0i, x1i, lx);
+                const float v00 = xp[(size_t)y0 * w + x0i] * sub_s + sub_b, v01 = xp[(size_t)y0 * w + x1i] * sub_s + sub_b;
+                const float v10 = xp[(size_t)y1 * w + x0i] * sub_s + sub_b, v11 = xp[(size_t)y1 * w + x1i] * sub_s + sub_b;
+                const float skip = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+                prefc[(((size_t)n * 3 + ch) * H + R) * W + c] = (skip + acc[t][0] + b_out) * add_s + add_b;
+            }
+        }
+    };
+
+    if (lr_loader) {
+        *reinterpret_cast<uint4*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
+        *reinterpret_cast<uint4*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
+        *reinterpret_cast<uint4*>(lrr + lr_slot(r0 + 1) + lr_st) = fetch_lr(r0 + 1);
+    }
+    __syncthreads();
+    phase1(r0 - 1);
+    __syncthreads();
+    for (int i = r0; i <= r1 + 1; ++i) {
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        const bool produce = i <= r1 - 1;
+        if (produce && wv < 3) nxt = fetch_lr(i + 2);
+        if (produce) phase1(i);          // writes ring slot i%3 (last read by phase3(i-1) as G(i-3))
+        if (i >= r0 + 1) phase3(i);      // reads G(i-2), G(i-1)
+        if (produce && wv < 3 && lr_loader) *reinterpret_cast<uint4*>(lrr + lr_slot(i + 2) + lr_st) = nxt;
+        __syncthreads();
+    }
+}
+
+// ---- fusion MLP over the 8 pre-fusion planes (SRProjectionModule.py:126-131,146), fully unrolled
+template <int NPL, int HID>
+__global__ void __launch_bounds__(256)
+k_fc_planes(const float* __restrict__ prefc, const float* __restrict__ w1, const float* __restrict__ b1,
+            const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, size_t P, int nhwc) {
+    const int c = blockIdx.y;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    float v[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = prefc[((size_t)i * 3 + c) * P + p];
+    float o = b2[0];
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+        float hs = b1[j];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) hs += w1[j * NPL + i] * v[i];
+        o += w2[j] * fmaxf(hs, 0.0f);
+    }
+    o = fmaxf(o, 0.0f);
+    if (nhwc) out[p * 3 + c] = o; else out[(size_t)c * P + p] = o;
+}
+
 }  // namespace
 
 extern "C" {
@@ -657,6 +863,42 @@ int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bi
     hipLaunchKernelGGL(k_head_h, dim3(grid), dim3(256), 0, vsr::S(stream), x, sub_scale3, sub_bias3, w_in, b_in, slope_in,
                        nmid, w_feat, b_feat, slope_feat, (_Float16*)out_nhwc, N, h, w);
     return vsr::launched("sr_head_f16");
+}
+
+int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,
+                    const float* x, float* prefc, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                    vsr_stream_t stream) {
+    VSR_REQUIRE(hid_nhwc && blob && conv_out_frags && tail_params && x && prefc, "sr_tail_f16: null pointer");
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_tail_f16: bad shape");
+    constexpr int LDS = 3 * SLOT_PITCH + LR_BYTES + 256;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
+    VSR_REQUIRE(segs <= 65535, "sr_tail_f16: too many row segments");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return vsr::fail(VSR_E_LAUNCH, "sr_tail_f16: cannot reserve %d bytes of LDS", LDS);
+        attr_done = true;
+    }
+    if (slopes_le_one)
+        hipLaunchKernelGGL(k_tail<true>, dim3(strips, segs, N), dim3(512), LDS, vsr::S(stream), (const _Float16*)hid_nhwc,
+                           (const unsigned char*)blob, (const unsigned char*)conv_out_frags, tail_params, x, prefc, h, w, rows_per_seg);
+    else
+        hipLaunchKernelGGL(k_tail<false>, dim3(strips, segs, N), dim3(512), LDS, vsr::S(stream), (const _Float16*)hid_nhwc,
+                           (const unsigned char*)blob, (const unsigned char*)conv_out_frags, tail_params, x, prefc, h, w, rows_per_seg);
+    return vsr::launched("sr_tail_f16");
+}
+
+int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,
+                         int nplanes, int hidden, float* out, int P, int out_nhwc, vsr_stream_t stream) {
+    VSR_REQUIRE(prefc && w1 && b1 && w2 && b2 && out, "sr_fc_planes: null pointer");
+    VSR_REQUIRE(P > 0, "sr_fc_planes: bad shape");
+    if (nplanes != 8 || hidden != 32)
+        return vsr::fail(VSR_E_UNSUPPORTED, "sr_fc_planes: %d planes / %d hidden units (the reference fuses 8 through 32)", nplanes, hidden);
+    hipLaunchKernelGGL((k_fc_planes<8, 32>), dim3(vsr::cdiv(P, 256), 3), dim3(256), 0, vsr::S(stream), prefc, w1, b1, w2, b2, out,
+                       (size_t)P, out_nhwc);
+    return vsr::launched("sr_fc_planes");
 }
 
 int vsr_sr_tail_fc_f16(const void* hr_nhwc, const float* w_out_packed, const float* b_out, const float* x,

@@ -166,6 +166,8 @@ class SRProjectionModule(nn.Module):
                                         b.downBlocks[j + 2][0].weight, b.downBlocks[j + 2][0].bias, P["dn_a"][j + 2])
         P["utd_out"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0)
         P["cv_w_pk"] = f(self.conv_out[0].weight.permute(2, 3, 1, 0))  # [dy][dx][ci][3]
+        P["cv_frags"] = pack_conv_out_frags(self.conv_out[0].weight)
+        P["tail_par"] = torch.cat((P["cv_b"], P["sub_s"], P["sub_b"], P["add_s"], P["add_b"])).contiguous()
         P["slopes_le_one"] = all(a <= 1.0 for a in P["up_a"] + P["dn_a"] + P["dt_a"] + [P["out_a"]])
         self._pack, self._pack_key = P, key
         self._const.clear()
@@ -382,13 +384,15 @@ class SRProjectionModule(nn.Module):
                 if step == self.num_steps - 1:
                     for k, v in live.items():
                         taps[f"lr{k}"] = nchw(v)
-        hr = self._utd(hid, P["utd_out"], N, h, w, deconv_only=True)
-        prefc = torch.empty((N, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev) if taps is not None else None
+        prefc = torch.empty((N, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev)
+        tok = L.TIMER.start("sr_tail_f16")
+        L.check(lib.vsr_sr_tail_f16(L.dptr(hid, torch.float16), L.dptr(P["utd_out"], torch.uint8), L.dptr(P["cv_frags"], torch.float16),
+                                    L.dptr(P["tail_par"]), L.dptr(x), L.dptr(prefc), N, h, w, self._rows_per_segment(N, h, w),
+                                    int(P["slopes_le_one"]), L.stream()), "sr_tail_f16")
+        L.TIMER.stop(tok)
         out = torch.empty((1, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev)
-        L.check(lib.vsr_sr_tail_fc_f16(L.dptr(hr, torch.float16), L.dptr(P["cv_w_pk"]), L.dptr(P["cv_b"]), L.dptr(x),
-                                       L.dptr(P["sub_s"]), L.dptr(P["sub_b"]), L.dptr(P["add_s"]), L.dptr(P["add_b"]),
-                                       L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]), L.dptr(P["fc_w2"]), L.dptr(P["fc_b2"]), N,
-                                       P["fc_w1"].shape[0], L.dptr(out), L.optr(prefc), h, w, 0, L.stream()), "sr_tail_fc_f16")
+        L.check(lib.vsr_sr_fc_planes_f32(L.dptr(prefc), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]), L.dptr(P["fc_w2"]), L.dptr(P["fc_b2"]),
+                                         N, P["fc_w1"].shape[0], L.dptr(out), 16 * h * w, 0, L.stream()), "sr_fc_planes")
         if taps is not None:
             taps[f"prefc{self.num_steps - 1}"] = prefc
         return out
@@ -471,3 +475,20 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a)
         fpar[98] = float(dn_a)
     blob[off_f:off_f + 512] = fpar.view(torch.uint8)
     return blob
+
+
+def pack_conv_out_frags(weight) -> torch.Tensor:
+    """conv_out weight [3,32,3,3] -> the 9 MFMA A-fragments of csrc/sr_f16.hip:k_tail, [tap][lane 64][8] fp16:
+    accumulator row m = lane & 15 carries output channel c iff m == 4c; k index (g, j) follows the ring's channel order."""
+    dev = weight.device
+    w = weight.detach().float()
+    lane = torch.arange(64, device=dev)
+    m, g = lane & 15, lane >> 4
+    perm = _chunk_channel_order(dev)  # [4,8]
+    frags = torch.zeros((9, 64, 8), dtype=torch.float32, device=dev)
+    for c in range(3):
+        sel = m == 4 * c
+        ci = perm[g[sel]]  # [n_sel, 8]
+        for t in range(9):
+            frags[t, sel] = w[c, ci, t // 3, t % 3]
+    return frags.to(torch.float16).contiguous()
