@@ -19,8 +19,9 @@ _ws = {}
 
 
 def _splitk_ws(device) -> torch.Tensor:
-    """One fp32 scratch buffer per device for split-K partial tiles (kernels are stream-ordered, so it is reused)."""
-    key = (device.type, device.index)
+    """One fp32 scratch buffer per (device, stream) for split-K partial tiles: launches on one stream are ordered, so
+    the buffer is reused; trunks running concurrently on different streams must not share it."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _ws:
         _ws[key] = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
     return _ws[key]

@@ -131,28 +131,28 @@ class SRProjectionModule(nn.Module):
         P = {}
         P["sub_s"], P["sub_b"] = self._diag(self.sub_mean)
         P["add_s"], P["add_b"] = self._diag(self.add_mean)
-        P["w_in"], P["b_in"], P["a_in"] = f(self.conv_in[0].weight), f(self.conv_in[0].bias), float(self.conv_in[1].weight)
+        P["w_in"], P["b_in"], P["a_in"] = f(self.conv_in[0].weight), f(self.conv_in[0].bias), float(self.conv_in[1].weight.detach())
         P["w_feat"] = f(self.feat_in[0].weight.reshape(_NF, -1))
-        P["b_feat"], P["a_feat"] = f(self.feat_in[0].bias), float(self.feat_in[1].weight)
+        P["b_feat"], P["a_feat"] = f(self.feat_in[0].bias), float(self.feat_in[1].weight.detach())
         wci = f(b.compress_in[0].weight.reshape(_NF, 2 * _NF))
-        P["ci_w"], P["ci_b"], P["ci_a"] = wci, f(b.compress_in[0].bias), float(b.compress_in[1].weight)
+        P["ci_w"], P["ci_b"], P["ci_a"] = wci, f(b.compress_in[0].bias), float(b.compress_in[1].weight.detach())
         # ConvTranspose2d weight [in,out,ky,kx] and Conv2d weight [out,in,ky,kx] -> [ky][kx][in][out]
         P["up_w"] = [f(m[0].weight.permute(2, 3, 0, 1)) for m in b.upBlocks]
         P["up_b"] = [f(m[0].bias) for m in b.upBlocks]
-        P["up_a"] = [float(m[1].weight) for m in b.upBlocks]
+        P["up_a"] = [float(m[1].weight.detach()) for m in b.upBlocks]
         P["dn_w"] = [f(m[0].weight.permute(2, 3, 1, 0)) for m in b.downBlocks]
         P["dn_b"] = [f(m[0].bias) for m in b.downBlocks]
-        P["dn_a"] = [float(m[1].weight) for m in b.downBlocks]
+        P["dn_a"] = [float(m[1].weight.detach()) for m in b.downBlocks]
         P["ut_w"] = [f(m[0].weight.reshape(_NF, -1)) for m in b.uptranBlocks]
         P["ut_b"] = [f(m[0].bias) for m in b.uptranBlocks]
-        P["ut_a"] = [float(m[1].weight) for m in b.uptranBlocks]
+        P["ut_a"] = [float(m[1].weight.detach()) for m in b.uptranBlocks]
         P["dt_w"] = [f(m[0].weight.reshape(_NF, -1)) for m in b.downtranBlocks]
         P["dt_b"] = [f(m[0].bias) for m in b.downtranBlocks]
-        P["dt_a"] = [float(m[1].weight) for m in b.downtranBlocks]
+        P["dt_a"] = [float(m[1].weight.detach()) for m in b.downtranBlocks]
         P["co_w"] = f(b.compress_out[0].weight.reshape(_NF, -1))
-        P["co_b"], P["co_a"] = f(b.compress_out[0].bias), float(b.compress_out[1].weight)
+        P["co_b"], P["co_a"] = f(b.compress_out[0].bias), float(b.compress_out[1].weight.detach())
         P["out_w"] = f(self.out[0].weight.permute(2, 3, 0, 1))
-        P["out_b"], P["out_a"] = f(self.out[0].bias), float(self.out[1].weight)
+        P["out_b"], P["out_a"] = f(self.out[0].bias), float(self.out[1].weight.detach())
         P["cv_w"], P["cv_b"] = f(self.conv_out[0].weight), f(self.conv_out[0].bias)
         P["fc_w1"], P["fc_b1"] = f(self.fc[0].weight), f(self.fc[0].bias)
         P["fc_w2"], P["fc_b2"] = f(self.fc[2].weight.reshape(-1)), f(self.fc[2].bias)

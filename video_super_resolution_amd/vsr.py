@@ -72,28 +72,58 @@ class VSR(nn.Module):
             raise ValueError(f"precision must be 'fp16' or 'fp32', got {self.precision!r}")
         return self.precision == "fp16"
 
+    def _side_streams(self, dev):
+        key = (dev.type, dev.index)
+        if getattr(self, "_streams_key", None) != key:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            self._streams_key = key
+        return self._streams
+
     @torch.no_grad()
-    def _guidance(self, trip, depth_cache):
-        """trip: three [h,w,3] frames -> (flow pictures [2,3,h,w], depth planes [2,3,h,w])."""
+    def _guidance(self, trip, depth_cache, extra_depth=(), with_vos=None):
+        """trip: three [h,w,3] frames -> (flow pictures [2,3,h,w], depth planes [2,3,h,w][, VOS mask]).
+
+        The flow, depth and segmentation trunks are independent of each other and individually too small to fill 256
+        CUs in their low-resolution layers, so in the fp16 configuration they run concurrently on separate HIP streams
+        (joined before the 8-plane assembly).  `extra_depth`: frames whose depth is wanted later (batched now)."""
         h, w = trip[0].shape[:2]
         fast = self._fast()
-        # both frame pairs as one FlowNet2 batch of two
+        main = torch.cuda.current_stream()
+        s_depth, s_vos = self._side_streams(trip[0].device) if fast else (main, main)
+        if fast:
+            s_depth.wait_stream(main)
+            s_vos.wait_stream(main)
+
+        # depth trunk once per distinct frame, all new frames as one batch
+        new = []
+        for f in list(trip) + list(extra_depth):
+            if f.data_ptr() not in depth_cache and all(f.data_ptr() != g.data_ptr() for g in new):
+                new.append(f)
+        if new:
+            with torch.cuda.stream(s_depth):
+                if fast:
+                    z = self._depth_exec.get()(torch.stack(new))  # [k,1,h,w] float32
+                else:
+                    z = self.DepthModule.model(torch.stack(new).permute(0, 3, 1, 2))
+                z.record_stream(main)
+            for i, f in enumerate(new):
+                depth_cache[f.data_ptr()] = (f, z[i:i + 1])  # keep f alive so the pointer stays unique
+        mask = None
+        if with_vos is not None:
+            with torch.cuda.stream(s_vos):
+                mask = self.VOSModule(with_vos[0], with_vos[1], self._vos_exec.get() if fast else None)  # [h,w] in {0,1}
+                mask.record_stream(main)
+        # both frame pairs as one FlowNet2 batch of two (on the main stream)
         pics = torch.stack(self.FlowModule.forward_pairs([(trip[0], trip[1]), (trip[1], trip[2])],
                                                          self._flow_exec.get() if fast else None))
         pics = F.interpolate(pics.permute(0, 3, 1, 2), (h, w))  # nearest back to h x w (:35,:52)
-        # depth trunk once per distinct frame, all new frames as one batch
-        new = [f for f in trip if f.data_ptr() not in depth_cache]
-        if new:
-            if fast:
-                z = self._depth_exec.get()(torch.stack(new))  # [k,1,h,w] float32
-            else:
-                z = self.DepthModule.model(torch.stack(new).permute(0, 3, 1, 2))
-            for i, f in enumerate(new):
-                depth_cache[f.data_ptr()] = (f, z[i:i + 1])  # keep f alive so the pointer stays unique
+        if fast:
+            main.wait_stream(s_depth)
+            main.wait_stream(s_vos)
         z = [depth_cache[f.data_ptr()][1] for f in trip]
         depth = torch.stack([maskprocess(self.DepthModule.combine(z[0], z[1])),
                              maskprocess(self.DepthModule.combine(z[1], z[2]))])
-        return pics, depth
+        return pics, depth, mask
 
     def forward(self, data, target, high_frames, estimated_image, train=True):
         if data.dim() != 4 or data.shape[0] != 3 or data.shape[3] != 3:
@@ -109,21 +139,21 @@ class VSR(nn.Module):
             frames = d.permute(0, 3, 1, 2)  # [3,3,h,w]
 
             # ---- pass 1 (:26-41)
-            pics, depth = self._guidance((f0, f1, f2), depth_cache)
             if estimated_image is None:
                 est = frames[0:1]
                 est_hw3 = f0
             else:
                 est = F.interpolate(estimated_image.detach().to(torch.float32).permute(0, 3, 1, 2), (h, w))  # :37
                 est_hw3 = est[0].permute(1, 2, 0).contiguous()
+            # (the estimate's depth is only used in pass 2 but is already known: batched with the three frames)
+            pics, depth, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,))
             self.model.precision = self.precision
             out1 = self.model(torch.cat((frames, pics, depth, est), 0))  # [1,3,4h,4w]
 
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
             mid = F.interpolate(out1, (h, w))[0]  # nearest: HR pixel (4i,4j)
             mid_hw3 = mid.permute(1, 2, 0).contiguous()
-            pics2, depth2 = self._guidance((est_hw3, mid_hw3, f2), depth_cache)
-            mask = self.VOSModule(est_hw3, mid_hw3, self._vos_exec.get() if self._fast() else None)  # [h,w] in {0,1}
+            pics2, depth2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3))
             masked = torch.where(maskprocess(mask) != 0, torch.zeros_like(mid), mid).unsqueeze(0)  # :58-60
 
             # ---- pass 2 SR (:62-64)
