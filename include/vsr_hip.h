@@ -197,6 +197,10 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
                         int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
                         vsr_stream_t stream);
 
+/* Tuning hook for benchmarks: 0 heuristic choice between the gather kernel and the LDS-patch kernel (cout <= 16,
+ * stride 1), 1 never the patch kernel, 2 whenever legal.  Returns the previous mode. */
+int vsr_conv2d_tuning(int patch_mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,10 @@ CASES = [  # (N, Cin, H, W, Cout, k, stride, pad, act)
     (3, 64, 6, 5, 1, 3, 1, 1, igemm.ACT_NONE),         # single output channel
     (1, 256, 33, 47, 512, 3, 2, 1, igemm.ACT_LEAKY),   # stride 2
     (1, 96, 130, 3, 48, 3, 1, 1, igemm.ACT_RELU),      # narrow, more pixels than one tile
+    (2, 64, 37, 61, 1, 3, 1, 1, igemm.ACT_NONE),       # hourglass final conv: LDS-patch path (cout <= 16, stride 1)
+    (1, 64, 20, 50, 16, 11, 1, 5, igemm.ACT_RELU),     # 16-wide 11x11 inception branch: patch path
+    (1, 194, 33, 47, 2, 3, 1, 1, igemm.ACT_NONE),      # predict_flow2: patch path over 7 channel chunks
+    (1, 32, 9, 40, 16, 7, 1, 3, igemm.ACT_RELU),       # patch path, ragged tile edges
 ]
 
 

@@ -202,20 +202,26 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) Bf[t][nt] = *reinterpret_cast<const h8*>(base + lr_b[dx][nt]);
             }
+            // both column phases' deconv MFMAs are issued before either epilogue: the second phase's 16 MFMAs cover
+            // the MFMA->VALU latency and the PReLU/convert VALU work of the first
+            f4 acc2c[2][2][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int px = pxb + c;
-                f4 acc[2][2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = bias_up(mt);
+                    for (int nt = 0; nt < 2; ++nt) acc2c[c][mt][nt] = bias_up(mt);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(Aup[c][t][mt], Bf[t][nt], acc[mt][nt]);
+                        for (int nt = 0; nt < 2; ++nt) acc2c[c][mt][nt] = mfma16(Aup[c][t][mt], Bf[t][nt], acc2c[c][mt][nt]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int px = pxb + c;
+                f4 (&acc)[2][2] = acc2c[c];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const h8 hb = act_pack(acc[0][nt], acc[1][nt], a_up2, up_max);
