@@ -156,8 +156,16 @@ def main():
             peak = FP16_MFMA_PEAK_TFLOPS if name.startswith("sr_utd_f16") else FP32_PEAK_TFLOPS
             flop = 8 * h * w * per_px
             achieved = flop / (ms * 1e-3) / 1e12
+            # HBM bytes per launch of this kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+            # separate passes, gfx950 correction applied; profiles/r01_k_utd_pmc.json) -- same launch geometry only
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_k_utd_pmc.json")
+            if name == "sr_utd_f16" and (h, w) == (540, 960) and os.path.exists(pmc):
+                with open(pmc) as f:
+                    traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"]
             roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
-                        frac=round(achieved / peak, 4), traffic=None, launches_timed=launches, avg_ms=round(ms, 4))
+                        frac=round(achieved / peak, 4), traffic=traffic, launches_timed=launches, avg_ms=round(ms, 4),
+                        algorithmic_flop_per_launch=flop)
         line = dict(metric="HR frames/sec, 1080p->4K x4 VSR (LR 540x960 -> 2160x3840), VSR.forward end-to-end",
                     value=round(fps, 4), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="weak",
