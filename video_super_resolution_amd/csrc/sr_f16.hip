@@ -272,6 +272,15 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
                 acc[nt] = mfma16(Adn[1][kx], b, acc[nt]);
                 nc[nt] = mfma16(Adn[0][kx], b, nc[nt]);
             }
+        // scheduling: keep 8 ring reads (32 VGPRs) in flight ahead of the MFMAs instead of hipcc's 2-4 -- this phase is
+        // far below the register peak of P1, and the LDS latency of every read was exposed between MFMA pairs
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         carry[0] = nc[0];
         carry[1] = nc[1];
 #pragma unroll
