@@ -187,34 +187,45 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Few-output-channel convolutions (cout <= 16, stride 1): the hourglass's final 64->1 conv and 16-wide inception
-// branches, FlowNet's predict_flow / flow up-sampling layers, OSVOS's side branches.  With so few output channels the
-// tap-by-tap gather of k_conv_igemm re-reads every input pixel kh*kw times from L2 for almost no MFMA work; here a
-// workgroup stages the 2-D input patch of an 8 x 32 output tile in LDS once per 32-channel chunk and walks the taps
-// from LDS.  M = 16 out-channels (one MFMA tile), N = pixels (wave w: tile rows 2w, 2w+1), K = taps x channels.
+// Stride-1 convolutions with a spatial kernel (the hourglass's 3x3..11x11 inception branches and final conv, FlowNet's
+// 3x3 layers and predict_flow, OSVOS's VGG stages): the tap-by-tap gather of k_conv_igemm re-reads every input pixel
+// kh*kw times from L2, which bounds these layers by L2 bandwidth; here a workgroup stages the 2-D input patch of an
+// 8 x 32 output tile in LDS once per 32-channel chunk and walks the taps from LDS.
+// M = 16*MT out-channels, N = pixels (wave w: tile rows 2w, 2w+1), K = taps x channels.
 constexpr int PT_H = 8, PT_W = 32;
 
+// MT = out-channel tiles (16 each) per workgroup; blockIdx.z walks blocks of 16*MT out-channels.
+// Weights are not staged: each tap's A fragments are read straight from global memory (the packed slab of one
+// (tap, chunk) is [cout_pad][32] fp16, so a wave's 16 rows x 64 B are one contiguous 1 KiB read, L2-resident and
+// shared by every workgroup), prefetched one tap ahead of the MFMAs that use them.
+template <int MT>
 __global__ void __launch_bounds__(256) k_conv_patch(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     const int PH = PT_H + p.kh - 1, PW = PT_W + p.kw - 1;  // patch
     const int ntap = p.kh * p.kw;
-    const int patch_bytes = PH * PW * 64;
-    const int wt_bytes = ntap * 16 * 64;                   // [tap][16 co][32 ci] of one chunk
     unsigned char* const patch = psm;                      // [PH][PW] pixels of 64 B (chunk XOR pixel-column bits 1-2)
-    unsigned char* const wts = psm + patch_bytes;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int tiles_x = (p.Wo + PT_W - 1) / PT_W;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int n = blockIdx.y;
+    const int co0 = blockIdx.z * 16 * MT;
     const int oy0 = ty * PT_H, ox0 = tx * PT_W;
     const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
     const int nchunk = p.cin >> 5;
 
-    f4 acc[4];
+    f4 acc[MT][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
     // this lane's four pixels: rows 2 wv + (t >> 1), columns 16 (t & 1) + l15 of the tile
+    int poff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) poff[t] = (2 * wv + (t >> 1)) * PW + 16 * (t & 1) + l15;
+    auto wfrag = [&](int tap, int ch, int mt) __attribute__((always_inline)) {
+        return *reinterpret_cast<const h8*>(p.wpk + ((size_t)(tap * nchunk + ch) * p.cout_pad + co0 + 16 * mt + l15) * 32 + 8 * g);
+    };
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();
         for (int q = tid; q < PH * PW * 4; q += 256) {
@@ -226,46 +237,54 @@ __global__ void __launch_bounds__(256) k_conv_patch(const ConvP p) {
                 v = *reinterpret_cast<const uint4*>(p.in + (((size_t)n * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + ch * 32 + c4 * 8);
             *reinterpret_cast<uint4*>(patch + pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4)) = v;
         }
-        for (int q = tid; q < ntap * 64; q += 256) {
-            const int tap = q >> 6, r = q & 63;  // r: 16 rows x 4 pieces
-            *reinterpret_cast<uint4*>(wts + tap * 1024 + sw_off(r >> 2, r & 3)) =
-                *reinterpret_cast<const uint4*>(p.wpk + ((size_t)(tap * nchunk + ch) * p.cout_pad) * 32 + r * 8);
-        }
+        h8 af[MT], afn[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = wfrag(0, ch, mt);
         __syncthreads();
+        int tap = 0;
         for (int ky = 0; ky < p.kh; ++ky)
-            for (int kx = 0; kx < p.kw; ++kx) {
-                const h8 af = *reinterpret_cast<const h8*>(wts + (ky * p.kw + kx) * 1024 + sw_off(l15, g));
+            for (int kx = 0; kx < p.kw; ++kx, ++tap) {
+                const int tn = tap + 1 < ntap ? tap + 1 : tap;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) afn[mt] = wfrag(tn, ch, mt);  // next tap's weights in flight
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int py = 2 * wv + (t >> 1) + ky, px = 16 * (t & 1) + l15 + kx;
-                    const h8 bf = *reinterpret_cast<const h8*>(patch + (py * PW + px) * 64 + ((g ^ ((px >> 1) & 3)) << 4));
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[t], 0, 0, 0);
+                    const int pix = poff[t] + ky * PW + kx;
+                    const int px = 16 * (t & 1) + l15 + kx;
+                    const h8 bf = *reinterpret_cast<const h8*>(patch + pix * 64 + ((g ^ ((px >> 1) & 3)) << 4));
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf, acc[mt][t], 0, 0, 0);
                 }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[mt] = afn[mt];
             }
     }
-    // lane holds channels 4g .. 4g+3 of its four pixels
-    const int c = 4 * g;
-    if (c >= p.cout) return;
+    // lane holds channels co0 + 16 mt + 4g .. +3 of its four pixels
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int oy = oy0 + 2 * wv + (t >> 1), ox = ox0 + 16 * (t & 1) + l15;
         if (oy >= p.Ho || ox >= p.Wo) continue;
         _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
                         p.out_coff;
-        float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float tt = acc[t][r] + (p.bias ? p.bias[c + r] : 0.0f);
-            if (p.act == 1) tt = fmaxf(tt, 0.0f);
-            else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
-            v[r] = tt;
-        }
-        if (c + 4 <= p.cout && ((p.out_coff + c) & 3) == 0 && (p.out_ld & 3) == 0) {
-            *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        } else {
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c = co0 + 16 * mt + 4 * g;
+            if (c >= p.cout) continue;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (c + r < p.cout) dst[c + r] = (_Float16)v[r];
+            for (int r = 0; r < 4; ++r) {
+                float tt = acc[mt][t][r] + (p.bias ? p.bias[c + r] : 0.0f);
+                if (p.act == 1) tt = fmaxf(tt, 0.0f);
+                else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
+                v[r] = tt;
+            }
+            if (c + 4 <= p.cout && ((p.out_coff + c) & 3) == 0 && (p.out_ld & 3) == 0) {
+                *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < p.cout) dst[c + r] = (_Float16)v[r];
+            }
         }
     }
 }
@@ -330,17 +349,21 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
     p.outH = outH; p.outW = outW; p.oy_mul = oy_mul; p.oy_off = oy_off; p.ox_mul = ox_mul; p.ox_off = ox_off;
     p.act = act; p.slope = slope;
     const long long M = (long long)N * Ho * Wo;
-    // few output channels at stride 1 with enough pixels: the 2-D LDS patch kernel (reads the input once)
-    const int patch_lds = (PT_H + kh - 1) * (PT_W + kw - 1) * 64 + kh * kw * 1024;
-    // measured on MI355X (tools/conv_microbench.py): 1.2-2x faster than the gather kernel on maps of >= 8k pixels,
-    // slower on the tiny 1/32-resolution maps with many channel chunks (split-K gather wins there)
-    const bool patch_legal = cout_pad == 16 && stride == 1 && Ho >= 4 && Wo >= 16 && patch_lds <= 64 * 1024 && N <= 65535;
-    const bool patch_pays = (long long)Ho * Wo >= 8192 && (cin >> 5) <= 8;
+    // stride-1 layers with a real spatial kernel and enough pixels: the 2-D LDS patch kernel (stages the input once per
+    // 32-channel chunk instead of gathering it kh*kw times from L2).  Measured on MI355X (tools/conv_microbench.py).
+    const int patch_lds = (PT_H + kh - 1) * (PT_W + kw - 1) * 64;
+    const bool patch_legal = stride == 1 && Ho >= 4 && Wo >= 16 && patch_lds <= 64 * 1024 && N <= 65535 && (cout_pad & 15) == 0;
+    const bool patch_pays = (long long)Ho * Wo >= 8192 && kh * kw >= 9 && ((cout_pad == 16 && (cin >> 5) <= 8) || cout_pad >= 32);
     if (patch_legal && g_patch_mode != 1 && (patch_pays || g_patch_mode == 2)) {
         p.ws = nullptr;
         p.splits = 1;
         const unsigned tiles = vsr::cdiv(Ho, PT_H) * vsr::cdiv(Wo, PT_W);
-        hipLaunchKernelGGL(k_conv_patch, dim3(tiles, N), dim3(256), patch_lds, vsr::S(stream), p);
+        if ((cout_pad & 63) == 0)
+            hipLaunchKernelGGL(k_conv_patch<4>, dim3(tiles, N, cout_pad / 64), dim3(256), patch_lds, vsr::S(stream), p);
+        else if ((cout_pad & 31) == 0)
+            hipLaunchKernelGGL(k_conv_patch<2>, dim3(tiles, N, cout_pad / 32), dim3(256), patch_lds, vsr::S(stream), p);
+        else
+            hipLaunchKernelGGL(k_conv_patch<1>, dim3(tiles, N, cout_pad / 16), dim3(256), patch_lds, vsr::S(stream), p);
         return vsr::launched("conv2d_nhwc_f16/patch");
     }
     const unsigned gx = vsr::cdiv(M, BM);
