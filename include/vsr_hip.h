@@ -144,6 +144,13 @@ int vsr_sr_utd_strip_width(void); /* LR columns one workgroup marches down (31) 
 int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int deconv_only,
                    int slopes_le_one, vsr_stream_t stream);
 
+/* The same fused stage with specialised wave roles (4 producer waves: deconv + 1x1 into the LDS ring; 4 consumer
+ * waves: stride-4 conv out of it).  Measured 7 % slower than vsr_sr_utd_f16 on MI355X (the producer chain is the long
+ * pole); kept, tested, as the starting point for unequal role splits.  blob_v2: fragment order of sr.py:pack_utd_blob(...,
+ * layout=2): up [producer 4][phase 4][tap 4][tile 2], conv [consumer 4][lo/hi 2][kx 8][tile 2], then as v1. */
+int vsr_sr_utd2_f16(const void* in, const void* blob_v2, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                    vsr_stream_t stream);
+
 /* vsr_sr_conv1x1_f32 for NHWC fp16 tensors [N,P,32]; weights/bias fp32, cmap_nhwc fp32 [P,32] or NULL. */
 int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* in1, const float* w1, int ldw1,
                        const void* in2, const float* w2, int ldw2, const float* bias, const float* cmap_nhwc, float slope,

@@ -26,7 +26,10 @@ def _stage_reference(m, j, a_nchw):
 
 @pytest.mark.parametrize("shape", [(2, 5, 7), (1, 9, 40), (3, 20, 70), (1, 2, 2), (1, 33, 31), (8, 12, 32)])
 @pytest.mark.parametrize("chain", [0, 3])
-def test_fused_up_tran_down_stage(gpu_vsr_f16, shape, chain):
+@pytest.mark.parametrize("kernel", ["roles", "uniform"])
+def test_fused_up_tran_down_stage(gpu_vsr_f16, shape, chain, kernel):
+    """Both builds of the fused stage: k_utd (every wave runs both phases; the one the forward runs) and k_utd2
+    (producer/consumer wave roles; kept as a measured alternative)."""
     m = gpu_vsr_f16.model
     N, h, w = shape
     P = m._packed()
@@ -34,7 +37,8 @@ def test_fused_up_tran_down_stage(gpu_vsr_f16, shape, chain):
     a = torch.from_numpy((rs.randn(N, h, w, 32) * 20).astype(np.float16)).cuda()
     with torch.no_grad():
         ref, _ = _stage_reference(m, chain, a.float().permute(0, 3, 1, 2))
-        got = m._utd(a, P["utd"][chain], N, h, w).float().permute(0, 3, 1, 2)
+        got = m._utd2(a, P["utd2"][chain], N, h, w) if kernel == "roles" else m._utd(a, P["utd"][chain], N, h, w)
+        got = got.float().permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()
     assert err <= 3e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
 
@@ -46,14 +50,18 @@ def test_stage_row_segments_agree(gpu_vsr_f16):
     P = m._packed()
     N, h, w = 2, 37, 45
     a = torch.from_numpy((np.random.RandomState(5).randn(N, h, w, 32) * 10).astype(np.float16)).cuda()
-    outs = []
-    for rps in (h, 16, 5, 1):
-        out = torch.empty((N, h, w, 32), dtype=torch.float16, device="cuda")
-        L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(P["utd"][0], torch.uint8), L.dptr(out, torch.float16),
-                                        N, h, w, rps, 0, 1, L.stream()))
-        outs.append(out)
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0])
+    for fn, blob in ((L.load().vsr_sr_utd2_f16, P["utd2"][0]), (None, P["utd"][0])):
+        outs = []
+        for rps in (h, 16, 5, 1):
+            out = torch.empty((N, h, w, 32), dtype=torch.float16, device="cuda")
+            if fn is None:
+                L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16),
+                                                N, h, w, rps, 0, 1, L.stream()))
+            else:
+                L.check(fn(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), N, h, w, rps, 1, L.stream()))
+            outs.append(out)
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 7), (1, 9, 40), (1, 17, 64)])

@@ -10,13 +10,20 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 m = fill_module_(SRProjectionModule().eval(), 0, "model.").cuda()
 P = m._packed()
 a = (torch.randn(N, h, w, 32, device="cuda") * 20).half()
-for _ in range(2):
-    m._utd(a, P["utd"][0], N, h, w)
+variants = {"k_utd2 (roles)": lambda: m._utd2(a, P["utd2"][0], N, h, w), "k_utd (uniform)": lambda: m._utd(a, P["utd"][0], N, h, w)}
+if len(sys.argv) > 4:
+    variants = {k: v for k, v in variants.items() if sys.argv[4] in k}
+for fn in variants.values():
+    for _ in range(2): fn()
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(reps):
-    m._utd(a, P["utd"][0], N, h, w)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / reps
-print(f"utd {N}x{h}x{w}: {ms:.3f} ms  -> {N*h*w*294912/ms/1e9:.1f} TFLOP/s")
+res = {k: [] for k in variants}
+for r in range(4):  # interleaved rounds on one device
+    for k, fn in variants.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): fn()
+        e1.record(); torch.cuda.synchronize()
+        res[k].append(e0.elapsed_time(e1) / reps)
+for k, v in res.items():
+    ms = sorted(v)[len(v) // 2]
+    print(f"{k:18s} {N}x{h}x{w}: {ms:.3f} ms  -> {N*h*w*294912/ms/1e9:.1f} TFLOP/s")

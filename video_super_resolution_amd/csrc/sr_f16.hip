@@ -617,6 +617,216 @@ k_tail_fc_h(const _Float16* __restrict__ hr, const float* __restrict__ w_pk, con
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_utd2: the same fused stage with SPECIALISED wave roles.  In k_utd every wave runs P2 then P1 and both waves of
+// a SIMD stall in step on their own MFMA->VALU->MFMA chains (PMC: MFMA pipe busy 45 %, 38 % of wave time parked).
+// Here waves 0-3 are PRODUCERS (deconv + 1x1 -> ring; the VALU-heavy role) and waves 4-7 are CONSUMERS (stride-4
+// conv from the ring; almost pure MFMA + ds_read).  Waves w and w+4 share a SIMD, so every SIMD always has one
+// MFMA-dense and one VALU-dense instruction stream to interleave.  One workgroup barrier per LR row, as before:
+// in interval t the producers build group G(t) in ring slot t&1 while the consumers turn G(t-1) (slot (t-1)&1) into
+// the partial tiles of output row t-1 and sum/store row t-2.
+//   producer p: HR row 4t+2+p of the group, all four column phases (32 deconv weight fragments resident, 80 MFMA/row)
+//   consumer q: ring row q, kernel rows q and q+4, both out-channel halves (32 conv weight fragments, 64 MFMA/row)
+// Blob layout "v2": up [p 4][phase 4][tap 4][mt 2], dn [q 4][lo/hi 2][kx 8][mt 2], then as v1.
+template <bool ALLMAX>
+__global__ void __launch_bounds__(512, 2)
+k_utd2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _Float16* __restrict__ out, int h, int w,
+       int rows_per_seg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem;
+    unsigned char* const part = smem + RING_BYTES;
+    unsigned char* const lrr = smem + RING_BYTES + PART_BYTES;
+    float* const bias_s = reinterpret_cast<float*>(smem + RING_BYTES + PART_BYTES + LR_BYTES);
+    const unsigned char* const adt_base = smem + RING_BYTES + PART_BYTES + LR_BYTES + 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int x0 = blockIdx.x * TX;
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_seg;
+    const int r1 = min(h, r0 + rows_per_seg);
+    if (r0 >= r1) return;  // uniform per workgroup
+
+    const float* fpar = reinterpret_cast<const float*>(blob + BLOB_F32);
+    if (tid < 64) bias_s[tid] = fpar[tid];
+    if (tid >= 64 && tid < 192) *reinterpret_cast<uint4*>(smem + RING_BYTES + PART_BYTES + LR_BYTES + 256 + (tid - 64) * 16) =
+        *reinterpret_cast<const uint4*>(blob + BLOB_DT + (tid - 64) * 16);
+    const float a_up = fpar[96], a_dt = fpar[97], a_dn = fpar[98];
+    int ring_lo[2], ring_hi[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = 16 * nt + l15;
+        ring_lo[nt] = j * (4 * COL_PITCH) + ((g ^ ((j >> 1) & 3)) << 4);
+        ring_hi[nt] = j * (4 * COL_PITCH) + ((g ^ (((j + 1) >> 1) & 3)) << 4);
+    }
+    const int t_first = r0 - 1, t_last = r1 + 1;  // intervals; every wave executes one barrier per interval
+
+    if (wv < 4) {
+        // ===================================================== producers
+        const int py = wv;
+        h8 Aup[4][4][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    Aup[c][t][mt] = *reinterpret_cast<const h8*>(blob + BLOB_UP + ((((py * 4 + c) * 4 + t) * 2 + mt) * 64 + lane) * 16);
+        const h2 a_up2 = {(_Float16)a_up, (_Float16)a_up}, a_dt2 = {(_Float16)a_dt, (_Float16)a_dt};
+        const bool up_max = ALLMAX || a_up <= 1.0f, dt_max = ALLMAX || a_dt <= 1.0f;
+        const bool edge_strip = (x0 == 0) || (4 * (x0 + 32) - 2 >= 4 * w);
+        int lr_b[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            lr_b[0][nt] = lr_off(16 * nt + l15 + 1, g);
+            lr_b[1][nt] = lr_off(16 * nt + l15, g);
+        }
+        const unsigned char* const adt_s = adt_base + lane * 16;
+        const _Float16* in_n = in + (size_t)n * h * w * NF;
+        const bool lr_loader = tid < LR_COLS * 4;
+        const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 1 + lr_px;
+        const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
+        const int lr_st = lr_off(lr_px, lr_ch);
+        auto fetch_lr = [&](int r) __attribute__((always_inline)) -> uint4 {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (lr_col_ok && r >= 0 && r < h) v = *reinterpret_cast<const uint4*>(in_n + ((size_t)r * w + lr_col) * NF + lr_ch * 8);
+            return v;
+        };
+        auto lr_slot = [&](int r) __attribute__((always_inline)) { return ((r + 1) % 3) * LR_SLOT; };
+        if (lr_loader) {
+            *reinterpret_cast<uint4*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
+            *reinterpret_cast<uint4*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
+        }
+        __syncthreads();  // (A) LR rows r0-1, r0 + biases + 1x1 fragments visible
+        for (int t = t_first; t <= t_last; ++t) {
+            if (t <= r1 - 1) {
+                uint4 nxt = make_uint4(0, 0, 0, 0);
+                if (wv < 3) nxt = fetch_lr(t + 2);
+                const int r_hr = 4 * t + 2 + py;
+                unsigned char* const rowbase = ring + (t & 1) * SLOT_PITCH + py * ROW_PITCH;
+                if (r_hr >= 0 && r_hr < 4 * h) {
+                    h8 Bf[4][2];
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) {
+                        const int dy = tp >> 1, dx = tp & 1;
+                        const unsigned char* base = lrr + lr_slot(t + 1 - dy);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) Bf[tp][nt] = *reinterpret_cast<const h8*>(base + lr_b[dx][nt]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f4 acc[2][2];
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = *reinterpret_cast<const f4*>(bias_s + 16 * mt + 4 * g);
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(Aup[c][tp][mt], Bf[tp][nt], acc[mt][nt]);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const h8 hb = act_pack(acc[0][nt], acc[1][nt], a_up2, up_max);
+                            f4 a2[2] = {*reinterpret_cast<const f4*>(bias_s + 32 + 4 * g), *reinterpret_cast<const f4*>(bias_s + 48 + 4 * g)};
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt) a2[mt] = mfma16(*reinterpret_cast<const h8*>(adt_s + mt * 1024), hb, a2[mt]);
+                            h8 ob = act_pack(a2[0], a2[1], a_dt2, dt_max);
+                            if (edge_strip) {
+                                const int c_hr = 4 * (x0 + 16 * nt + l15) + c - 2;
+                                const bool col_ok = (c_hr >= 0) && (c_hr < 4 * w);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) ob[e] = col_ok ? ob[e] : (_Float16)0.0f;
+                            }
+                            *reinterpret_cast<h8*>(rowbase + ring_lo[nt] + c * COL_PITCH) = ob;
+                        }
+                    }
+                } else {
+                    h8 z;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<h8*>(rowbase + ring_lo[nt] + c * COL_PITCH) = z;
+                }
+                if (wv < 3 && lr_loader) *reinterpret_cast<uint4*>(lrr + lr_slot(t + 2) + lr_st) = nxt;  // slot of LR row t-1
+            }
+            __syncthreads();
+        }
+    } else {
+        // ===================================================== consumers
+        const int q = wv - 4;
+        h8 Adn[2][8][2];  // [lo: kernel row q | hi: kernel row q+4][kx][out-channel tile]
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    Adn[hl][kx][mt] = *reinterpret_cast<const h8*>(blob + BLOB_DN + ((((q * 2 + hl) * 8 + kx) * 2 + mt) * 64 + lane) * 16);
+        const int ctid = tid - 256;                 // 0..255 among the consumer threads
+        const int rj = ctid >> 3, rc4 = ctid & 7;   // reduce role: output pixel, group of 4 channels
+        const f4 bdn = *reinterpret_cast<const f4*>(fpar + 64 + 4 * rc4);
+        const bool red_ok = (rj < TX) && (x0 + rj < w);
+        f4 carry[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) carry[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();  // (A)
+        for (int t = t_first; t <= t_last; ++t) {
+            if (t >= r0 && t <= r1) {
+                // group G(t-1) in ring slot (t-1)&1: finishes output row t-1, starts row t
+                const unsigned char* const rowbase = ring + ((t - 1) & 1) * SLOT_PITCH + q * ROW_PITCH;
+                f4 acc[2][2], nc[2][2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc[mt][nt] = carry[mt][nt];
+                        nc[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+#pragma unroll
+                for (int kx = 0; kx < 8; ++kx)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const h8 b = *reinterpret_cast<const h8*>(rowbase + (kx < 4 ? ring_lo[nt] : ring_hi[nt]) + kx * COL_PITCH);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            acc[mt][nt] = mfma16(Adn[1][kx][mt], b, acc[mt][nt]);
+                            nc[mt][nt] = mfma16(Adn[0][kx][mt], b, nc[mt][nt]);
+                        }
+                    }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        carry[mt][nt] = nc[mt][nt];
+                        *reinterpret_cast<f4*>(part + ((t - 1) & 1) * PART_BUF + q * PART_W_PITCH + (16 * nt + l15) * PART_PX_PITCH +
+                                               (16 * mt + 4 * g) * 4) = acc[mt][nt];
+                    }
+            }
+            if (t - 2 >= r0 && t - 2 <= r1 - 1) {
+                // output row t-2: its 4 partial tiles were completed in the previous interval
+                const unsigned char* pb = part + ((t - 2) & 1) * PART_BUF + rj * PART_PX_PITCH + rc4 * 16;
+                f4 s4 = bdn;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s4 += *reinterpret_cast<const f4*>(pb + k * PART_W_PITCH);
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 o = {(_Float16)prelu(s4[0], a_dn), (_Float16)prelu(s4[1], a_dn), (_Float16)prelu(s4[2], a_dn),
+                              (_Float16)prelu(s4[3], a_dn)};
+                if (red_ok) *reinterpret_cast<h4*>(out + (((size_t)n * h + (t - 2)) * w + x0 + rj) * NF + 4 * rc4) = o;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
 // Fused tail:  hid -> `out` DeconvBlock (ConvTranspose k8 s4 p2 + PReLU) -> conv_out 3x3 (32->3) + bilinear x4 skip of
 // sub_mean(x) + add_mean  ->  pre-fusion planes [N,3,4h,4w] fp32 (SRProjectionModule.py:136,142-143), the x4 feature map
 // staying in LDS.  Same march as k_utd, with a ring of THREE groups of four HR rows: while P1(i) writes group G(i),
@@ -878,6 +1088,30 @@ int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bi
     hipLaunchKernelGGL(k_head_h, dim3(grid), dim3(256), 0, vsr::S(stream), x, sub_scale3, sub_bias3, w_in, b_in, slope_in,
                        nmid, w_feat, b_feat, slope_feat, (_Float16*)out_nhwc, N, h, w);
     return vsr::launched("sr_head_f16");
+}
+
+int vsr_sr_utd2_f16(const void* in, const void* blob_v2, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                    vsr_stream_t stream) {
+    VSR_REQUIRE(in && blob_v2 && out, "sr_utd2: null pointer");
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_utd2: bad shape");
+    VSR_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob_v2) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0, "sr_utd2: pointers must be 16-byte aligned");
+    const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
+    VSR_REQUIRE(segs <= 65535, "sr_utd2: too many row segments");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_utd2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_utd2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS) != hipSuccess)
+            return vsr::fail(VSR_E_LAUNCH, "sr_utd2: cannot reserve %d bytes of LDS", UTD_LDS);
+        attr_done = true;
+    }
+    if (slopes_le_one)
+        hipLaunchKernelGGL(k_utd2<true>, dim3(strips, segs, N), dim3(512), UTD_LDS, vsr::S(stream), (const _Float16*)in,
+                           (const unsigned char*)blob_v2, (_Float16*)out, h, w, rows_per_seg);
+    else
+        hipLaunchKernelGGL(k_utd2<false>, dim3(strips, segs, N), dim3(512), UTD_LDS, vsr::S(stream), (const _Float16*)in,
+                           (const unsigned char*)blob_v2, (_Float16*)out, h, w, rows_per_seg);
+    return vsr::launched("sr_utd2");
 }
 
 int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,

@@ -159,11 +159,12 @@ class SRProjectionModule(nn.Module):
         P["zero_b"] = torch.zeros(_NF, dtype=torch.float32, device=wci.device)
         # ---- MFMA path: one packed blob per live chain  lr[j] -> hr[j+1] -> lr[j+3]  and one for the tail deconv
         G = b.num_groups
-        P["utd"] = {}
+        P["utd"], P["utd2"] = {}, {}
         for j in range(0, G - 2, 3):
-            P["utd"][j] = pack_utd_blob(b.upBlocks[j + 1][0].weight, b.upBlocks[j + 1][0].bias, P["up_a"][j + 1],
-                                        P["dt_w"][j + 1], _NF * (j + 2), P["dt_b"][j + 1], P["dt_a"][j + 1],
-                                        b.downBlocks[j + 2][0].weight, b.downBlocks[j + 2][0].bias, P["dn_a"][j + 2])
+            args = (b.upBlocks[j + 1][0].weight, b.upBlocks[j + 1][0].bias, P["up_a"][j + 1], P["dt_w"][j + 1], _NF * (j + 2),
+                    P["dt_b"][j + 1], P["dt_a"][j + 1], b.downBlocks[j + 2][0].weight, b.downBlocks[j + 2][0].bias, P["dn_a"][j + 2])
+            P["utd"][j] = pack_utd_blob(*args)             # k_utd (every wave both phases)
+            P["utd2"][j] = pack_utd_blob(*args, layout=2)  # k_utd2 (producer / consumer waves)
         P["utd_out"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0)
         P["cv_w_pk"] = f(self.conv_out[0].weight.permute(2, 3, 1, 0))  # [dy][dx][ci][3]
         P["cv_frags"] = pack_conv_out_frags(self.conv_out[0].weight)
@@ -342,6 +343,16 @@ class SRProjectionModule(nn.Module):
         segs = max(1, min(-(-h // 8), -(-256 // wgs)))
         return -(-h // segs)
 
+    def _utd2(self, a, blob_v2, N, h, w):
+        """Fused up -> tran -> down stage, producer/consumer wave roles (experimental variant, see _forward_f16)."""
+        out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
+        tok = L.TIMER.start("sr_utd2_f16")
+        L.check(L.load().vsr_sr_utd2_f16(L.dptr(a, torch.float16), L.dptr(blob_v2, torch.uint8), L.dptr(out, torch.float16), N, h, w,
+                                         self._rows_per_segment(N, h, w), int(self._pack["slopes_le_one"]), L.stream()),
+                "sr_utd2_f16")
+        L.TIMER.stop(tok)
+        return out
+
     def _utd(self, a, blob, N, h, w, deconv_only=False):
         out = torch.empty((N, 4 * h, 4 * w, _NF) if deconv_only else (N, h, w, _NF), dtype=torch.float16, device=a.device)
         tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else "sr_utd_f16")
@@ -374,6 +385,9 @@ class SRProjectionModule(nn.Module):
             j = 0
             while j + 3 <= G:
                 a = self._c1h([(live[j], P["ut_w"][j], _NF * (j + 1))], P["ut_b"][j], P["ut_a"][j], N, hp)
+                # k_utd (every wave runs both phases) measured 7 % faster than the producer/consumer variant k_utd2
+                # (1.219 vs 1.306 ms, interleaved on one device): the deconv -> PReLU -> 1x1 -> PReLU chain is the long
+                # pole and concentrating it in four waves lengthens it
                 live[j + 3] = self._utd(a, P["utd"][j], N, h, w).view(N, hp, _NF)
                 j += 3
             ins = [(live[k], P["co_w"], _NF * (k - 1)) for k in sorted(live) if k > 0]
@@ -417,7 +431,7 @@ def _chunk_channel_order(device):
     return torch.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4))  # [4,8]
 
 
-def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a) -> torch.Tensor:
+def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a, layout: int = 1) -> torch.Tensor:
     """Weights of one fused up->tran->down stage in the per-wave MFMA fragment order of csrc/sr_f16.hip.
 
     up_w [32(in),32(out),8,8] ConvTranspose2d weight; tr_w [32,ld] 1x1 weight whose live slice starts at column
@@ -440,6 +454,11 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a)
     co = 16 * MT + (LN & 15)
     ky = (W >> 1) + 4 * (T >> 1)
     kx = 2 * (W & 1) + C + 4 * (T & 1)
+    if layout == 2:  # [producer p 4][phase c 4][tap 4][mt 2]: HR row phase p, column phase c
+        PP = torch.arange(4, device=dev).view(4, 1, 1, 1, 1, 1)
+        CC = torch.arange(4, device=dev).view(1, 4, 1, 1, 1, 1)
+        ky = PP + 4 * (T >> 1)
+        kx = CC + 4 * (T & 1)
     ci, co, ky, kx = torch.broadcast_tensors(ci, co, ky, kx)
     up_frag = up_w.detach().float()[ci, co, ky, kx].to(torch.float16).contiguous()
     blob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
@@ -459,6 +478,15 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a)
         co = 16 * (W >> 2) + col_l.view(1, 1, 1, 64, 1)
         ci = perm[g].view(1, 1, 1, 64, 8)
         ky = (W & 3) + 4 * HL
+        if layout == 2:  # [consumer q 4][lo/hi 2][kx 8][mt 2][lane][j]: kernel rows q and q+4, both channel halves
+            Q = torch.arange(4, device=dev).view(4, 1, 1, 1, 1, 1)
+            HL6 = torch.arange(2, device=dev).view(1, 2, 1, 1, 1, 1)
+            KX6 = torch.arange(8, device=dev).view(1, 1, 8, 1, 1, 1)
+            MT6 = torch.arange(2, device=dev).view(1, 1, 1, 2, 1, 1)
+            co = 16 * MT6 + col_l.view(1, 1, 1, 1, 64, 1)
+            ci = perm[g].view(1, 1, 1, 1, 64, 8)
+            ky = Q + 4 * HL6
+            KX = KX6
         co, ci, ky, kx = torch.broadcast_tensors(co, ci, ky, KX)
         dn_frag = dn_w.detach().float()[co, ci, ky, kx].to(torch.float16).contiguous()
         blob[off_dn:off_dt] = dn_frag.view(torch.uint8).reshape(-1)
