@@ -204,6 +204,14 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
                         int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
                         vsr_stream_t stream);
 
+/* NHWC fp16 glue of the hourglass (pytorch_DIW_scratch.py: MaxPool2d/AvgPool2d((2,2),(2,2)), UpsamplingNearest2d(2),
+ * coolAddTensors :29-31).  Inputs may be channel slices of wider buffers; outputs are dense [N,.,.,C].
+ * pool: mode 0 max, 1 average.  resize_add: out = nearest_resize(a -> HxW) (+ b if given). */
+int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int N, int H, int W, int C, int mode,
+                         vsr_stream_t stream);
+int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,
+                            void* out, int N, int H, int W, int C, vsr_stream_t stream);
+
 /* Tuning hook for benchmarks: 0 heuristic choice between the gather kernel and the LDS-patch kernel (cout <= 16,
  * stride 1), 1 never the patch kernel, 2 whenever legal.  Returns the previous mode. */
 int vsr_conv2d_tuning(int patch_mode);

@@ -317,6 +317,55 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const ConvP p) {
 
 }  // namespace
 
+
+// ---- NHWC fp16 glue of the hourglass (pytorch_DIW_scratch.py: MaxPool2d / AvgPool2d 2x2, UpsamplingNearest2d(2),
+//      coolAddTensors = nearest-resize + add): 16 bytes (8 channels) per thread, channel-slice aware on the input side.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+
+// mode 0: 2x2 max pool, 1: 2x2 average pool.  in [N,H,W,in_ld] slice [in_coff, +C) -> out [N,H/2,W/2,C]
+__global__ void __launch_bounds__(256) k_pool2(const _Float16* __restrict__ in, int in_ld, int in_coff, _Float16* __restrict__ out,
+                                               int N, int H, int W, int C, int mode) {
+    const int Ho = H >> 1, Wo = W >> 1, c8n = C >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * Ho * Wo * c8n) return;
+    const int c8 = (int)(idx % c8n);
+    long long r = idx / c8n;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const _Float16* p00 = in + (((size_t)n * H + 2 * oy) * W + 2 * ox) * in_ld + in_coff + 8 * c8;
+    const h8v a = *reinterpret_cast<const h8v*>(p00), b = *reinterpret_cast<const h8v*>(p00 + in_ld);
+    const h8v c = *reinterpret_cast<const h8v*>(p00 + (size_t)W * in_ld), d = *reinterpret_cast<const h8v*>(p00 + (size_t)W * in_ld + in_ld);
+    h8v o;
+    if (mode == 0) {
+        o = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)(((float)a[e] + (float)b[e] + (float)c[e] + (float)d[e]) * 0.25f);
+    }
+    *reinterpret_cast<h8v*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + 8 * c8) = o;
+}
+
+// out[n,y,x,:] = a[n, y*Ha/H, x*Wa/W, slice a] (nearest, as F.interpolate(size)) + b[n,y,x, slice b]; b == null: resize only.
+__global__ void __launch_bounds__(256) k_resize_add(const _Float16* __restrict__ a, int a_ld, int a_coff, int Ha, int Wa,
+                                                    const _Float16* __restrict__ b, int b_ld, int b_coff,
+                                                    _Float16* __restrict__ out, int N, int H, int W, int C) {
+    const int c8n = C >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * H * W * c8n) return;
+    const int c8 = (int)(idx % c8n);
+    long long r = idx / c8n;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    // ATen nearest: src = min(floor(dst * (in / out)), in - 1) with a float scale
+    const int ya = min((int)floorf((float)y * ((float)Ha / (float)H)), Ha - 1);
+    const int xa = min((int)floorf((float)x * ((float)Wa / (float)W)), Wa - 1);
+    h8v v = *reinterpret_cast<const h8v*>(a + (((size_t)n * Ha + ya) * Wa + xa) * a_ld + a_coff + 8 * c8);
+    if (b) v += *reinterpret_cast<const h8v*>(b + (((size_t)n * H + y) * W + x) * b_ld + b_coff + 8 * c8);
+    *reinterpret_cast<h8v*>(out + (((size_t)n * H + y) * W + x) * C + 8 * c8) = v;
+}
+
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal (tuning hook)
 
 extern "C" {
@@ -325,6 +374,29 @@ int vsr_conv2d_tuning(int patch_mode) {
     const int old = g_patch_mode;
     g_patch_mode = patch_mode;
     return old;
+}
+
+int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int N, int H, int W, int C, int mode,
+                         vsr_stream_t stream) {
+    VSR_REQUIRE(in && out, "pool2x2: null pointer");
+    VSR_REQUIRE(N > 0 && H >= 2 && W >= 2 && C > 0 && (C & 7) == 0 && (in_ld & 7) == 0 && (in_coff & 7) == 0 && in_coff + C <= in_ld &&
+                    (mode == 0 || mode == 1), "pool2x2: bad arguments");
+    const long long total = (long long)N * (H >> 1) * (W >> 1) * (C >> 3);
+    hipLaunchKernelGGL(k_pool2, dim3(vsr::cdiv(total, 256)), dim3(256), 0, vsr::S(stream), (const _Float16*)in, in_ld, in_coff,
+                       (_Float16*)out, N, H, W, C, mode);
+    return vsr::launched("pool2x2");
+}
+
+int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,
+                            void* out, int N, int H, int W, int C, vsr_stream_t stream) {
+    VSR_REQUIRE(a && out, "resize_add: null pointer");
+    VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ha > 0 && Wa > 0 && C > 0 && (C & 7) == 0 && (a_ld & 7) == 0 && (a_coff & 7) == 0 &&
+                    a_coff + C <= a_ld, "resize_add: bad arguments");
+    VSR_REQUIRE(!b_or_null || ((b_ld & 7) == 0 && (b_coff & 7) == 0 && b_coff + C <= b_ld), "resize_add: bad addend slice");
+    const long long total = (long long)N * H * W * (C >> 3);
+    hipLaunchKernelGGL(k_resize_add, dim3(vsr::cdiv(total, 256)), dim3(256), 0, vsr::S(stream), (const _Float16*)a, a_ld, a_coff, Ha,
+                       Wa, (const _Float16*)b_or_null, b_ld, b_coff, (_Float16*)out, N, H, W, C);
+    return vsr::launched("resize_add");
 }
 
 int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,

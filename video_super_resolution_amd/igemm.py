@@ -124,3 +124,23 @@ class HDeconv4s2:
         for c in self.phases:
             c(x, out=out, out_coff=out_coff, in_coff=in_coff, out_hw=(H, W))
         return out
+
+
+def pool2x2(x, coff, c, mode):
+    """2x2 stride-2 max (mode 0) / average (mode 1) pool of channel slice [coff, coff+c) -> dense [N,H/2,W/2,c]."""
+    N, H, W, ld = x.shape
+    out = torch.empty((N, H // 2, W // 2, c), dtype=torch.float16, device=x.device)
+    L.check(L.load().vsr_pool2x2_nhwc_f16(L.dptr(x, torch.float16), ld, coff, L.dptr(out, torch.float16), N, H, W, c, mode, L.stream()),
+            "pool2x2")
+    return out
+
+
+def resize_add(a, a_coff, c, out_hw, b=None, b_coff=0):
+    """nearest-resize slice [a_coff, +c) of `a` to out_hw and (optionally) add slice [b_coff, +c) of `b` -> dense [N,H,W,c]."""
+    N, Ha, Wa, a_ld = a.shape
+    H, W = out_hw
+    out = torch.empty((N, H, W, c), dtype=torch.float16, device=a.device)
+    L.check(L.load().vsr_resize_add_nhwc_f16(L.dptr(a, torch.float16), a_ld, a_coff, Ha, Wa, L.optr(b, torch.float16),
+                                             b.shape[3] if b is not None else 0, b_coff, L.dptr(out, torch.float16), N, H, W, c,
+                                             L.stream()), "resize_add")
+    return out

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .depth import HOURGLASS
-from .igemm import ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HDeconv4s2, pad32, to_nhwc_half
+from .igemm import ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HDeconv4s2, pad32, pool2x2, resize_add, to_nhwc_half
 
 
 def _fold(conv: nn.Conv2d, bn):
@@ -123,11 +123,9 @@ class HourglassExec:
     def _run(self, node, x, coff, c):
         """x: NHWC buffer whose live channels are [coff, coff+c) -> (buffer, coff, c)."""
         if node == "max" or node == "avg":
-            v = _nchw(x[..., coff:coff + c])
-            y = F.max_pool2d(v, 2, 2) if node == "max" else F.avg_pool2d(v, 2, 2)
-            return _nhwc(y), 0, c
+            return pool2x2(x, coff, c, 0 if node == "max" else 1), 0, c
         if node == "up":
-            return _nhwc(F.interpolate(_nchw(x[..., coff:coff + c]), scale_factor=2, mode="nearest")), 0, c
+            return resize_add(x, coff, c, (2 * x.shape[1], 2 * x.shape[2])), 0, c
         tag = node[0]
         if tag == "conv":
             out = node[1](x, in_coff=coff)
@@ -139,8 +137,7 @@ class HourglassExec:
             for ch in node[1]:
                 if ch == "+":
                     (a, ca, na), (b, cb, nb) = x  # list from the preceding fan-out
-                    av, bv = _nchw(a[..., ca:ca + na]), _nchw(b[..., cb:cb + nb])
-                    x, coff, c = _nhwc(F.interpolate(av, bv.shape[-2:]) + bv), 0, nb
+                    x, coff, c = resize_add(a, ca, nb, (b.shape[1], b.shape[2]), b, cb), 0, nb
                 elif isinstance(ch, tuple) and ch[0] == "M":
                     x = [self._run(sub, x, coff, c) for sub in ch[1]]
                 else:
