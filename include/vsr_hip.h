@@ -174,13 +174,6 @@ int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out
 int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,
                          int nplanes, int hidden, float* out, int P, int out_nhwc, vsr_stream_t stream);
 
-/* conv_out 3x3 + bilinear skip + add_mean + fusion MLP in one pass over the HR map of all planes
- * (SRProjectionModule.py:136,142-143,146).  hr_nhwc [8,4h,4w,32] fp16; w_out_packed = conv_out weight [3,32,3,3]
- * permuted to [dy][dx][ci][3]; out [3,4h,4w] (or [4h,4w,3] if out_nhwc); prefc_or_null: optional [8,3,4h,4w] tap. */
-int vsr_sr_tail_fc_f16(const void* hr_nhwc, const float* w_out_packed, const float* b_out, const float* x,
-                       const float* sub_scale3, const float* sub_bias3, const float* add_scale3, const float* add_bias3,
-                       const float* w1, const float* b1, const float* w2, const float* b2, int nplanes, int hidden,
-                       float* out, float* prefc_or_null, int h, int w, int out_nhwc, vsr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Guidance trunks (FlowNet2 models.py:73-128 and networks/FlowNet{C,S,SD,Fusion}.py, depth hourglass pytorch_DIW_scratch.py:34-837, OSVOS

@@ -97,18 +97,19 @@ def test_chunk_channel_order_is_a_permutation():
     assert p[1].tolist() == [4, 5, 6, 7, 20, 21, 22, 23]
 
 
-def test_batchnorm_folding_preserves_the_hourglass(cpu_vsr):
-    """Execution copies fold eval-mode BatchNorm into the preceding conv: same function, 155 fewer layers."""
+def test_batchnorm_folding_is_exact(cpu_vsr):
+    """The trunk executors fold eval-mode BatchNorm into the preceding conv (trunk_exec._fold): same function."""
     import torch.nn as nn
-    from video_super_resolution_amd.trunks import ExecCopy
+    import torch.nn.functional as F
+    from video_super_resolution_amd.trunk_exec import _fold
     netg = cpu_vsr.DepthModule.model.netG
-    folded = ExecCopy(netg, fold_bn=True).get(torch.float32)
-    assert folded is not netg
     assert sum(isinstance(m, nn.BatchNorm2d) for m in netg.modules()) == 155
-    assert sum(isinstance(m, nn.BatchNorm2d) for m in folded.modules()) == 0
-    x = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (1, 3, 32, 48)).astype(np.float32))
+    conv, bn = netg[0], netg[1]  # stem: affine BatchNorm
+    blk = netg[3][0][0][1][1]    # an inception branch: conv -> BN(affine=False) -> ReLU -> conv -> BN -> ReLU
+    x = torch.from_numpy(np.random.RandomState(0).randn(1, 3, 12, 14).astype(np.float32))
     with torch.no_grad():
-        a, b = netg(x), folded(x)
-    assert (a - b).abs().max() <= 1e-5 * a.abs().max()
-    # the master keeps its parameters and keys
-    assert len(netg.state_dict()) == len(cpu_vsr.DepthModule.model.netG.state_dict())
+        for c, b, inp in ((conv, bn, x), (blk[0], blk[1], torch.randn(1, 128, 6, 7)), (blk[3], blk[4], torch.randn(1, 32, 6, 7))):
+            w, bias = _fold(c, b)
+            ref = b(c(inp))
+            got = F.conv2d(inp, w, bias, padding=c.padding)
+            assert (ref - got).abs().max() <= 1e-5 * ref.abs().max()

@@ -534,85 +534,13 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
     }
 }
 
-// ---- tail: conv_out 3x3 (32->3) over the HR map (NHWC fp16) of all planes + bilinear skip + add_mean + fusion MLP.
-//      One thread = one HR pixel, loops over the planes and keeps the 3 pre-fusion values of each
-//      (SRProjectionModule.py:136,142-143,146).  w_out repacked to [dy][dx][ci][3] fp32.
+// bilinear x4, align_corners=False, as ATen's upsample_bilinear2d: src = (dst+0.5)/4-0.5 clamped at 0
 __device__ __forceinline__ void bil4(int dst, int n, int& i0, int& i1, float& l1) {
     float src = ((float)dst + 0.5f) * 0.25f - 0.5f;
     if (src < 0.0f) src = 0.0f;
     i0 = (int)src;
     i1 = i0 + (i0 < n - 1 ? 1 : 0);
     l1 = src - (float)i0;
-}
-
-template <int NPL, int HID>
-__global__ void __launch_bounds__(256)
-k_tail_fc_h(const _Float16* __restrict__ hr, const float* __restrict__ w_pk, const float* __restrict__ b_out,
-            const float* __restrict__ x, const float* __restrict__ sub_scale, const float* __restrict__ sub_bias,
-            const float* __restrict__ add_scale, const float* __restrict__ add_bias, const float* __restrict__ w1,
-            const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-            float* __restrict__ out, float* __restrict__ prefc, int h, int w, int nhwc) {
-    const int H = 4 * h, W = 4 * w;
-    const int Y = blockIdx.y;
-    const int X = blockIdx.x * 256 + threadIdx.x;
-    if (X >= W) return;
-    const size_t hw = (size_t)h * w, HW = (size_t)H * W;
-    int y0, y1, x0, x1;
-    float ly, lx;
-    bil4(Y, h, y0, y1, ly);
-    bil4(X, w, x0, x1, lx);
-    // hidden pre-activations of the fusion MLP, accumulated plane by plane (all indices static: registers)
-    float hs[HID][3];
-#pragma unroll
-    for (int j = 0; j < HID; ++j) hs[j][0] = hs[j][1] = hs[j][2] = b1[j];
-#pragma unroll 1
-    for (int n = 0; n < NPL; ++n) {
-        float acc[3] = {b_out[0], b_out[1], b_out[2]};
-        const _Float16* hb = hr + (size_t)n * HW * NF;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int yy = Y + dy - 1;
-            if (yy < 0 || yy >= H) continue;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int xc = X + dx - 1;
-                if (xc < 0 || xc >= W) continue;
-                const _Float16* pp = hb + ((size_t)yy * W + xc) * NF;
-                const float* wt = w_pk + (dy * 3 + dx) * NF * 3;
-#pragma unroll
-                for (int c8 = 0; c8 < 4; ++c8) {
-                    const h8 v = *reinterpret_cast<const h8*>(pp + 8 * c8);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float a = (float)v[e];
-                        acc[0] += wt[(8 * c8 + e) * 3 + 0] * a;
-                        acc[1] += wt[(8 * c8 + e) * 3 + 1] * a;
-                        acc[2] += wt[(8 * c8 + e) * 3 + 2] * a;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* xp = x + ((size_t)n * 3 + c) * hw;
-            const float s = sub_scale[c], b = sub_bias[c];
-            const float v00 = xp[(size_t)y0 * w + x0] * s + b, v01 = xp[(size_t)y0 * w + x1] * s + b;
-            const float v10 = xp[(size_t)y1 * w + x0] * s + b, v11 = xp[(size_t)y1 * w + x1] * s + b;
-            const float skip = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
-            const float pv = (skip + acc[c]) * add_scale[c] + add_bias[c];
-            if (prefc) prefc[((size_t)n * 3 + c) * HW + (size_t)Y * W + X] = pv;
-#pragma unroll
-            for (int j = 0; j < HID; ++j) hs[j][c] += w1[j * NPL + n] * pv;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float o = b2[0];
-#pragma unroll
-        for (int j = 0; j < HID; ++j) o += w2[j] * fmaxf(hs[j][c], 0.0f);
-        o = fmaxf(o, 0.0f);
-        if (nhwc) out[((size_t)Y * W + X) * 3 + c] = o; else out[(size_t)c * HW + (size_t)Y * W + X] = o;
-    }
 }
 
 
@@ -1150,20 +1078,5 @@ int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, c
     return vsr::launched("sr_fc_planes");
 }
 
-int vsr_sr_tail_fc_f16(const void* hr_nhwc, const float* w_out_packed, const float* b_out, const float* x,
-                       const float* sub_scale3, const float* sub_bias3, const float* add_scale3, const float* add_bias3,
-                       const float* w1, const float* b1, const float* w2, const float* b2, int nplanes, int hidden,
-                       float* out, float* prefc_or_null, int h, int w, int out_nhwc, vsr_stream_t stream) {
-    VSR_REQUIRE(hr_nhwc && w_out_packed && b_out && x && sub_scale3 && sub_bias3 && add_scale3 && add_bias3 && w1 && b1 &&
-                    w2 && b2 && out, "sr_tail_fc_f16: null pointer");
-    VSR_REQUIRE(h > 0 && w > 0 && 4 * h <= 65535 && hidden > 0, "sr_tail_fc_f16: bad shape");
-    if (nplanes != 8 || hidden != 32)
-        return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail_fc_f16: %d planes / %d hidden units (the reference fuses 8 through 32)",
-                         nplanes, hidden);
-    hipLaunchKernelGGL((k_tail_fc_h<8, 32>), dim3(vsr::cdiv(4 * w, 256), 4 * h), dim3(256), 0, vsr::S(stream),
-                       (const _Float16*)hr_nhwc, w_out_packed, b_out, x, sub_scale3, sub_bias3, add_scale3, add_bias3, w1,
-                       b1, w2, b2, out, prefc_or_null, h, w, out_nhwc);
-    return vsr::launched("sr_tail_fc_f16");
-}
 
 }  // extern "C"

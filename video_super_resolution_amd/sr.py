@@ -166,7 +166,6 @@ class SRProjectionModule(nn.Module):
             P["utd"][j] = pack_utd_blob(*args)             # k_utd (every wave both phases)
             P["utd2"][j] = pack_utd_blob(*args, layout=2)  # k_utd2 (producer / consumer waves)
         P["utd_out"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0)
-        P["cv_w_pk"] = f(self.conv_out[0].weight.permute(2, 3, 1, 0))  # [dy][dx][ci][3]
         P["cv_frags"] = pack_conv_out_frags(self.conv_out[0].weight)
         P["tail_par"] = torch.cat((P["cv_b"], P["sub_s"], P["sub_b"], P["add_s"], P["add_b"])).contiguous()
         P["slopes_le_one"] = all(a <= 1.0 for a in P["up_a"] + P["dn_a"] + P["dt_a"] + [P["out_a"]])
