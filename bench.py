@@ -20,6 +20,9 @@ import time
 # MIOpen reads its find mode when the library is loaded (i.e. at `import torch`): set it first.  Without a gfx950
 # find-db the default mode benchmarks every solver per new conv shape -- minutes of start-up at 540x960.
 os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+# the fast mode's AI ("TunaNet") solver predictor aborted the process twice in ~30 runs of the fp32 configuration
+# (abort() inside torch conv -> MIOpen, no message); the plain heuristic fallback has not
+os.environ.setdefault("MIOPEN_DEBUG_ENABLE_AI_IMMED_MODE_FALLBACK", "0")
 os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")
 
 import numpy as np  # noqa: E402

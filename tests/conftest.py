@@ -1,6 +1,9 @@
 import os
 
 os.environ.setdefault("MIOPEN_FIND_MODE", "2")  # must precede `import torch` (read at library load)
+# the fast mode's AI ("TunaNet") solver predictor aborted the process twice in ~30 runs of the fp32 configuration
+# (abort() inside torch conv -> MIOpen, no message); the plain heuristic fallback has not
+os.environ.setdefault("MIOPEN_DEBUG_ENABLE_AI_IMMED_MODE_FALLBACK", "0")
 os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")
 import sys
 

@@ -1,6 +1,6 @@
 """Stage-by-stage wall times of one VSR.forward at a given LR size (prints progressively)."""
 import sys, time, os
-os.environ.setdefault('MIOPEN_FIND_MODE','2'); os.environ.setdefault('MIOPEN_LOG_LEVEL','2')
+os.environ.setdefault('MIOPEN_FIND_MODE','2'); os.environ.setdefault('MIOPEN_LOG_LEVEL','2'); os.environ.setdefault('MIOPEN_DEBUG_ENABLE_AI_IMMED_MODE_FALLBACK','0')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_super_resolution_amd import VSR, _lib

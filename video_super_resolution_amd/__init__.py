@@ -13,6 +13,7 @@ import os as _os
 # NOTE: MIOpen reads the variable when it is loaded, so this only helps if this package is imported before
 # `torch`; bench.py, tests/conftest.py and __graft_entry__.py therefore also set it before importing torch.
 _os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+_os.environ.setdefault("MIOPEN_DEBUG_ENABLE_AI_IMMED_MODE_FALLBACK", "0")  # plain heuristic fallback (see bench.py)
 _os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")  # errors only: the fallback heuristic is chatty at warning level
 
 from .vsr import VSR  # noqa: F401,E402
