@@ -144,6 +144,15 @@ int vsr_sr_utd_strip_width(void); /* LR columns one workgroup marches down (31) 
 int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int deconv_only,
                    int slopes_le_one, vsr_stream_t stream);
 
+/* Build of the fused stage vsr_sr_utd_f16 launches (process-wide; results are bit-identical across builds):
+ *   0  k_utd3, one wave per SIMD, 144 MFMAs per LR row in one hand-ordered instruction stream (default)
+ *   1  k_utd, two waves per SIMD (the first design; 17 % slower on MI355X)
+ *   2 / 3  builds 0 / 1 with s_memtime stamps around their phases (diagnostics: tools/utd_stamps.py). */
+int vsr_sr_utd_variant(int variant);
+/* Device buffer the stamped builds write to: [workgroup][wave 8][8] uint64 (phase cycle sums, loop cycles, loop time in
+ * 10 ns ticks).  NULL detaches. */
+int vsr_sr_utd_stamp_buffer(void* device_buf);
+
 /* The same fused stage with specialised wave roles (4 producer waves: deconv + 1x1 into the LDS ring; 4 consumer
  * waves: stride-4 conv out of it).  Measured 7 % slower than vsr_sr_utd_f16 on MI355X (the producer chain is the long
  * pole); kept, tested, as the starting point for unequal role splits.  blob_v2: fragment order of sr.py:pack_utd_blob(...,

@@ -28,8 +28,8 @@ def _stage_reference(m, j, a_nchw):
 @pytest.mark.parametrize("chain", [0, 3])
 @pytest.mark.parametrize("kernel", ["roles", "uniform"])
 def test_fused_up_tran_down_stage(gpu_vsr_f16, shape, chain, kernel):
-    """Both builds of the fused stage: k_utd (every wave runs both phases; the one the forward runs) and k_utd2
-    (producer/consumer wave roles; kept as a measured alternative)."""
+    """The fused stage as the forward runs it (k_utd3) and the producer/consumer variant k_utd2 (kept as a measured
+    alternative) against an fp32 evaluation with stock ops."""
     m = gpu_vsr_f16.model
     N, h, w = shape
     P = m._packed()
@@ -41,6 +41,31 @@ def test_fused_up_tran_down_stage(gpu_vsr_f16, shape, chain, kernel):
         got = got.float().permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()
     assert err <= 3e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7), (1, 9, 40), (3, 20, 70), (1, 2, 2), (1, 33, 31), (2, 37, 95)])
+@pytest.mark.parametrize("rps", [0, 6])
+def test_stage_builds_bit_identical(gpu_vsr_f16, shape, rps):
+    """k_utd3 (one wave per SIMD, hand-ordered step; the default) and k_utd (two waves per SIMD) follow the same
+    arithmetic order per accumulator: identical bits, also across row segments and on border strips."""
+    from video_super_resolution_amd import _lib as L
+    m = gpu_vsr_f16.model
+    N, h, w = shape
+    P = m._packed()
+    a = torch.from_numpy((np.random.RandomState(h * 100 + w).randn(N, h, w, 32) * 20).astype(np.float16)).cuda()
+    lib = L.load()
+    outs = []
+    try:
+        for variant in (0, 1):
+            L.check(lib.vsr_sr_utd_variant(variant))
+            out = torch.empty((N, h, w, 32), dtype=torch.float16, device="cuda")
+            L.check(lib.vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(P["utd"][0], torch.uint8), L.dptr(out, torch.float16),
+                                       N, h, w, rps or h, 0, 1, L.stream()))
+            outs.append(out)
+    finally:
+        lib.vsr_sr_utd_variant(0)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_stage_row_segments_agree(gpu_vsr_f16):

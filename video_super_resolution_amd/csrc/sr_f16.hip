@@ -25,80 +25,17 @@
 //
 // MFMA lane maps used (cdna_hip_programming.md section 3), v_mfma_f32_16x16x32_f16:
 //   A[m = lane&15][k = 8*(lane>>4) + j],  B[k = 8*(lane>>4) + j][n = lane&15],  D[m = 4*(lane>>4) + r][n = lane&15].
-#include "vsr_common.h"
+#include "sr_f16_common.h"
 
 namespace {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-constexpr int NF = 32;
-constexpr int TX = 31;              // LR output columns per strip (TX + 1 = 32 deconv positions = 2 MFMA tiles)
-constexpr int RING_COLS = 132;      // 128 live HR columns + 4 never-written ones read by the discarded 32nd output
-constexpr int COL_PITCH = 80;       // bytes per HR pixel in the ring (64 + 16 pad: bank spreading)
-constexpr int ROW_PITCH = RING_COLS * COL_PITCH;
-constexpr int SLOT_PITCH = 4 * ROW_PITCH;
-constexpr int RING_BYTES = 2 * SLOT_PITCH;
-constexpr int PART_PX_PITCH = 144;  // bytes per pixel row of a partial tile (32 fp32 + 16 pad)
-constexpr int PART_W_PITCH = 32 * PART_PX_PITCH;
-constexpr int PART_BUF = 4 * PART_W_PITCH;  // one output row: 4 partial tiles (kernel-row pairs)
-constexpr int PART_BYTES = 2 * PART_BUF;    // double buffered
-constexpr int LR_COLS = 33;         // LR columns x0-1 .. x0+31
-constexpr int LR_SLOT = LR_COLS * 64;
-constexpr int LR_BYTES = 3 * LR_SLOT;
-constexpr int BIAS_BYTES = 256 + 2048;  // b_up[32], b_dt[32] fp32 + the two 1x1 weight fragments (re-read per use: VGPR cap)
-constexpr int UTD_LDS = RING_BYTES + PART_BYTES + LR_BYTES + BIAS_BYTES;
-
-// packed weight blob (built by the host, see vsr_sr_utd_blob_layout in include/vsr_hip.h)
-constexpr int BLOB_UP = 0;                    // [wave 8][phase 2][tap 4][mt 2][lane 64][8] fp16
-constexpr int BLOB_DN = 8 * 16 * 1024;        // [wave 8][lo/hi 2][kx 8][lane 64][8] fp16 (kernel rows w&3, (w&3)+4; co half w>>2)
-constexpr int BLOB_DT = BLOB_DN + 8 * 16 * 1024;  // [mt 2][lane 64][8] fp16
-constexpr int BLOB_F32 = BLOB_DT + 2 * 1024;  // b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn
-constexpr int BLOB_BYTES = BLOB_F32 + 512;
-
-static_assert(RING_BYTES % 16 == 0 && PART_BYTES % 16 == 0 && LR_SLOT % 16 == 0, "LDS carve must stay 16-B aligned");
-static_assert(UTD_LDS <= 160 * 1024, "LDS budget");
-
-__device__ __forceinline__ float prelu(float v, float a) { return v >= 0.0f ? v : v * a; }
-
-// PReLU on packed fp16 pairs: max(v, a*v) for a <= 1, min(v, a*v) for a > 1 (one v_pk_mul + one v_pk_max/min per pair)
-__device__ __forceinline__ h2 prelu_h2(h2 v, h2 a, bool use_max) {
-    const h2 m = v * a;
-    return use_max ? __builtin_elementwise_max(v, m) : __builtin_elementwise_min(v, m);
-}
-
-// Two accumulator registers blocks (rows 4g..4g+3 of tile 0 and tile 1) -> PReLU -> 8 packed fp16, the operand /
-// ring order of this lane.  v_cvt_pk_f16_f32 (round to nearest even) + packed PReLU: 3 VALU per value pair.
-__device__ __forceinline__ h8 act_pack(f4 lo, f4 hi, h2 a, bool use_max) {
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    const h2 p0 = prelu_h2(__builtin_convertvector(f2v{lo[0], lo[1]}, h2), a, use_max);
-    const h2 p1 = prelu_h2(__builtin_convertvector(f2v{lo[2], lo[3]}, h2), a, use_max);
-    const h2 p2 = prelu_h2(__builtin_convertvector(f2v{hi[0], hi[1]}, h2), a, use_max);
-    const h2 p3 = prelu_h2(__builtin_convertvector(f2v{hi[2], hi[3]}, h2), a, use_max);
-    return h8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
-}
-
-__device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-
-// byte offset of (column cc, 16-byte chunk) inside a ring row
-// (80-byte pitch + chunk XOR column bits 3-4: every ds_read_b128 / ds_write_b128 lane group of the access patterns
-// below lands on distinct banks -- checked by exhaustive simulation of the gfx950 lane groups, tools/lds_bank_sim.py)
-__device__ __forceinline__ int ring_off(int cc, int chunk) { return cc * COL_PITCH + ((chunk ^ ((cc >> 3) & 3)) << 4); }
-// byte offset of (pixel p, 16-byte chunk) inside an LR ring slot (64-byte pitch, chunk XOR pixel bits 1-2)
-__device__ __forceinline__ int lr_off(int p, int chunk) { return p * 64 + ((chunk ^ ((p >> 1) & 3)) << 4); }
-
-constexpr bool kBranchFree = false;
-
-template <bool B>
-struct BoolC { static constexpr bool value = B; };
 
 // MODE 0: full up -> tran -> down stage, `out` = LR map [N,h,w,32] fp16.
 // MODE 1: deconv + PReLU only, `out` = HR map [N,4h,4w,32] fp16 (used for the `out` DeconvBlock of the tail).
 // ALLMAX: every PReLU slope of the stage is <= 1, so prelu(v) = max(v, a*v) (one compare-free packed op);
 //         otherwise both max and min forms are evaluated and selected per slope.
-template <int MODE, bool ALLMAX>
+__device__ unsigned long long* g_stamp_ptr = nullptr;
+
+template <int MODE, bool ALLMAX, int DIAG = 0>
 __global__ void __launch_bounds__(512, 2)
 k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _Float16* __restrict__ out, int h, int w,
       int rows_per_seg) {
@@ -187,6 +124,15 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
     // ---- P1(i): HR rows of group G(i) = {4i+2 .. 4i+5}: reads LR rows i (slot s_i) and i+1 (slot s_i1), writes ring slot
     //      `rbase`.  CHECK: rows may lie outside the image (first / last group) -> zeros.  EDGE: border strip -> zero
     //      the out-of-image columns.
+    auto p1_load = [&](int s_i, int s_i1, h8 (&Bf)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int dy = t >> 1, dx = t & 1;
+            const unsigned char* base = lrr + (dy ? s_i : s_i1);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) Bf[t][nt] = *reinterpret_cast<const h8*>(base + lr_b[dx][nt]);
+        }
+    };
     auto phase1 = [&](int i, int s_i, int s_i1, unsigned char* rbase, auto checkc, auto edgec) __attribute__((always_inline)) {
         constexpr bool CHECK = decltype(checkc)::value;
         constexpr bool EDGE = decltype(edgec)::value;
@@ -195,13 +141,7 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
         const bool row_ok = !CHECK || ((r_hr >= 0) && (r_hr < 4 * h));
         if (row_ok) {
             h8 Bf[4][2];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int dy = t >> 1, dx = t & 1;
-                const unsigned char* base = lrr + (dy ? s_i : s_i1);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) Bf[t][nt] = *reinterpret_cast<const h8*>(base + lr_b[dx][nt]);
-            }
+            p1_load(s_i, s_i1, Bf);
             // both column phases' deconv MFMAs are issued before either epilogue: the second phase's 16 MFMAs cover
             // the MFMA->VALU latency and the PReLU/convert VALU work of the first
             f4 acc2c[2][2][2];
@@ -218,6 +158,15 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) acc2c[c][mt][nt] = mfma16(Aup[c][t][mt], Bf[t][nt], acc2c[c][mt][nt]);
             }
+            h8 adt_r[2];
+            f4 bdt_r[2];
+            if (MODE == 0) {   // once per phase: the ring stores between the four chains would force a re-read each
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    adt_r[mt] = *reinterpret_cast<const h8*>(adt_s + mt * 1024);
+                    bdt_r[mt] = bias_dt(mt);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int px = pxb + c;
@@ -227,9 +176,9 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
                     const h8 hb = act_pack(acc[0][nt], acc[1][nt], a_up2, up_max);
                     const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
                     if (MODE == 0) {
-                        f4 a2[2] = {bias_dt(0), bias_dt(1)};
+                        f4 a2[2];
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) a2[mt] = mfma16(*reinterpret_cast<const h8*>(adt_s + mt * 1024), hb, a2[mt]);
+                        for (int mt = 0; mt < 2; ++mt) a2[mt] = mfma16(adt_r[mt], hb, bdt_r[mt]);
                         h8 ob = act_pack(a2[0], a2[1], a_dt2, dt_max);
                         if (EDGE) {
                             const bool col_ok = (c_hr >= 0) && (c_hr < 4 * w);
@@ -313,38 +262,50 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
         // group G(r0-1): rows 4r0-2 .. 4r0+1 (recomputed halo of the segment, zeros above the image)
         phase1(r0 - 1, lr_slot(r0 - 1), lr_slot(r0), ring + ((r0 - 1) & 1) * SLOT_PITCH, BoolC<true>{}, BoolC<true>{});
         __syncthreads();
+        // the prologue's global loads have landed: tell the vmcnt bookkeeping (see k_utd3)
+        __builtin_amdgcn_s_waitcnt(0);
         // rotating slot offsets: LR rows i-1, i, i+1; ring / partial buffers of parity i&1 and (i-1)&1
         int s_im1 = lr_slot(r0 - 1), s_i = lr_slot(r0), s_i1 = lr_slot(r0 + 1);
         int ring_cur = (r0 & 1) * SLOT_PITCH, part_cur = (r0 & 1) * PART_BUF;
+        unsigned long long stamp[4] = {0, 0, 0, 0};
+        const unsigned long long rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0, ct0 = DIAG ? __builtin_amdgcn_s_memtime() : 0;
         auto march = [&](auto edgec) __attribute__((always_inline)) {
             for (int i = r0; i < r1; ++i) {
                 uint4 nxt = make_uint4(0, 0, 0, 0);
                 if (wv < 3) nxt = fetch_lr(i + 2);  // wave-uniform skip for the five waves that load nothing
                 const unsigned char* ring_prev = ring + (ring_cur ^ SLOT_PITCH);
                 unsigned char* part_prev = part + (part_cur ^ PART_BUF);
-                // steady state: every row of G(i) is inside the image and rows i-1, i-2 belong to this segment.
-                // kBranchFree: one big basic block per step lets hipcc overlap the two phases, but it then hoists
-                // every ds_read and overshoots the 256-VGPR budget (spills to scratch: 2.0 ms vs 1.5 ms measured);
-                // kept off until the block is hand-scheduled with sched_group_barrier.
-                if (kBranchFree && i >= r0 + 2 && i <= h - 2) {
-                    phase2(ring_prev, part_prev);                      // G(i-1) -> partial tiles of row i-1
-                    __builtin_amdgcn_sched_barrier(0);                 // keep the two phases' live ranges apart (VGPR cap)
-                    phase1(i, s_i, s_i1, ring + ring_cur, BoolC<false>{}, edgec);
-                    __builtin_amdgcn_sched_barrier(0);
-                    reduce_store(i - 2, part + part_cur);              // partial buffer of parity (i-2)&1 == i&1
-                } else {
-                    phase2(ring_prev, part_prev);                      // (row r0-1 is never reduced: harmless)
+                if (DIAG) {   // diagnostic build (tools/utd_stamps.py): shader-clock sums per phase, per wave
+                    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                    phase2(ring_prev, part_prev);
+                    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
                     phase1(i, s_i, s_i1, ring + ring_cur, BoolC<true>{}, edgec);
+                    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
                     if (i - 2 >= r0) reduce_store(i - 2, part + part_cur);
+                    if (wv < 3 && lr_loader) *reinterpret_cast<uint4*>(lrr + s_im1 + lr_st) = nxt;
+                    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+                    __syncthreads();
+                    const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+                    stamp[0] += t1 - t0; stamp[1] += t2 - t1; stamp[2] += t3 - t2; stamp[3] += t4 - t3;
+                } else {
+                    phase2(ring_prev, part_prev);                      // G(i-1) -> partial tiles of row i-1 (row r0-1: never reduced)
+                    phase1(i, s_i, s_i1, ring + ring_cur, BoolC<true>{}, edgec);
+                    if (i - 2 >= r0) reduce_store(i - 2, part + part_cur);   // partial buffer of parity (i-2)&1 == i&1
+                    if (wv < 3 && lr_loader) *reinterpret_cast<uint4*>(lrr + s_im1 + lr_st) = nxt;  // row i+2 -> slot of row i-1
+                    __syncthreads();
                 }
-                if (wv < 3 && lr_loader) *reinterpret_cast<uint4*>(lrr + s_im1 + lr_st) = nxt;  // row i+2 -> slot of row i-1
-                __syncthreads();
                 const int t = s_im1; s_im1 = s_i; s_i = s_i1; s_i1 = t;
                 ring_cur ^= SLOT_PITCH;
                 part_cur ^= PART_BUF;
             }
         };
         if (edge_strip) march(BoolC<true>{}); else march(BoolC<false>{});
+        if (DIAG && g_stamp_ptr && (tid & 63) == 0) {
+            unsigned long long* d = g_stamp_ptr + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wv) * 8;
+            for (int k = 0; k < 4; ++k) d[k] = stamp[k];
+            d[4] = __builtin_amdgcn_s_memtime() - ct0;
+            d[5] = __builtin_amdgcn_s_memrealtime() - rt0;
+        }
         // after the loop *_cur has the parity of r1: row r1-1 lives in the other buffers
         phase2(ring + (ring_cur ^ SLOT_PITCH), part + (part_cur ^ PART_BUF));
         if (r1 - 2 >= r0) reduce_store(r1 - 2, part + part_cur);
@@ -961,7 +922,26 @@ k_fc_planes(const float* __restrict__ prefc, const float* __restrict__ w1, const
 
 }  // namespace
 
+static int g_utd_variant = 0;
+
+namespace vsr {
+int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                int diag, hipStream_t stream);
+int utd3_set_stamps(void* buf);
+}
+
 extern "C" {
+
+int vsr_sr_utd_variant(int v) {
+    VSR_REQUIRE(v >= 0 && v <= 3, "sr_utd_variant: 0 one wave per SIMD, 1 two waves per SIMD, 2 / 3 their stamped diagnostic builds");
+    g_utd_variant = v;
+    return VSR_OK;
+}
+
+int vsr_sr_utd_stamp_buffer(void* buf) {
+    vsr::utd3_set_stamps(buf);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_ptr), &buf, sizeof(buf));
+}
 
 size_t vsr_sr_utd_blob_bytes(void) { return BLOB_BYTES; }
 
@@ -984,7 +964,14 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
                 return vsr::fail(VSR_E_LAUNCH, "sr_utd: cannot reserve %d bytes of LDS", UTD_LDS);
         attr_done = true;
     }
-    const kern_t k = kerns[(deconv_only ? 2 : 0) + (slopes_le_one ? 1 : 0)];
+    // fused stage: one wave per SIMD (k_utd3, sr_utd3.hip) unless the two-waves-per-SIMD build is selected
+    if (!deconv_only && (g_utd_variant == 0 || g_utd_variant == 2))
+        return vsr::launch_utd3(in, blob, out, N, h, w, rows_per_seg, slopes_le_one, g_utd_variant == 2, vsr::S(stream));
+    kern_t k = kerns[(deconv_only ? 2 : 0) + (slopes_le_one ? 1 : 0)];
+    if (!deconv_only && g_utd_variant == 3) {
+        k = k_utd<0, true, 1>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS);
+    }
     hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(512), UTD_LDS, vsr::S(stream), (const _Float16*)in,
                        (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
     return vsr::launched("sr_utd");
