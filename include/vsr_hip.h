@@ -147,7 +147,8 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
 /* Build of the fused stage vsr_sr_utd_f16 launches (process-wide; results are bit-identical across builds):
  *   0  k_utd3, one wave per SIMD, 144 MFMAs per LR row in one hand-ordered instruction stream (default)
  *   1  k_utd, two waves per SIMD (the first design; 17 % slower on MI355X)
- *   2 / 3  builds 0 / 1 with s_memtime stamps around their phases (diagnostics: tools/utd_stamps.py). */
+ *   2 / 3  builds 0 / 1 with s_memtime stamps around their phases (diagnostics: tools/utd_stamps.py)
+ *   4  build 0 stamped around the whole march only (cycles and clock without perturbing the step). */
 int vsr_sr_utd_variant(int variant);
 /* Device buffer the stamped builds write to: [workgroup][wave 8][8] uint64 (phase cycle sums, loop cycles, loop time in
  * 10 ns ticks).  NULL detaches. */

@@ -1,5 +1,5 @@
 """Stamped diagnostic builds of the fused stage: per-wave shader-clock sums per phase of the march, and the
-in-kernel clock (s_memtime / s_memrealtime).  usage: utd_stamps.py [2|3]   (2: k_utd3, 3: k_utd)"""
+in-kernel clock (s_memtime / s_memrealtime).  usage: utd_stamps.py [2|3|4]   (2: k_utd3, 3: k_utd, 4: k_utd3 totals only)"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

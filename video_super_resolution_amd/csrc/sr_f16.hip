@@ -214,9 +214,10 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
         f4 acc[2] = {carry[0], carry[1]};
         f4 nc[2] = {f4{0.0f, 0.0f, 0.0f, 0.0f}, f4{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
-        for (int kx = 0; kx < 8; ++kx)
+        for (int kk = 0; kk < 8; ++kk)   // tap order 0,4,1,5,2,6,3,7: the order k_utd3 needs (bit-identical outputs)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
+                const int kx = (kk >> 1) + 4 * (kk & 1);
                 const h8 b = *reinterpret_cast<const h8*>(rowbase + (kx < 4 ? ring_lo[nt] : ring_hi[nt]) + kx * COL_PITCH);
                 acc[nt] = mfma16(Adn[1][kx], b, acc[nt]);
                 nc[nt] = mfma16(Adn[0][kx], b, nc[nt]);
@@ -933,7 +934,7 @@ int utd3_set_stamps(void* buf);
 extern "C" {
 
 int vsr_sr_utd_variant(int v) {
-    VSR_REQUIRE(v >= 0 && v <= 3, "sr_utd_variant: 0 one wave per SIMD, 1 two waves per SIMD, 2 / 3 their stamped diagnostic builds");
+    VSR_REQUIRE(v >= 0 && v <= 4, "sr_utd_variant: 0 one wave per SIMD, 1 two waves per SIMD, 2 / 3 their stamped diagnostic builds, 4 build 0 with loop totals only");
     g_utd_variant = v;
     return VSR_OK;
 }
@@ -965,8 +966,8 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
         attr_done = true;
     }
     // fused stage: one wave per SIMD (k_utd3, sr_utd3.hip) unless the two-waves-per-SIMD build is selected
-    if (!deconv_only && (g_utd_variant == 0 || g_utd_variant == 2))
-        return vsr::launch_utd3(in, blob, out, N, h, w, rows_per_seg, slopes_le_one, g_utd_variant == 2, vsr::S(stream));
+    if (!deconv_only && (g_utd_variant == 0 || g_utd_variant == 2 || g_utd_variant == 4))
+        return vsr::launch_utd3(in, blob, out, N, h, w, rows_per_seg, slopes_le_one, g_utd_variant / 2, vsr::S(stream));
     kern_t k = kerns[(deconv_only ? 2 : 0) + (slopes_le_one ? 1 : 0)];
     if (!deconv_only && g_utd_variant == 3) {
         k = k_utd<0, true, 1>;

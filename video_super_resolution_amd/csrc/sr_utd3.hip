@@ -1,22 +1,25 @@
 // sr_utd3.hip -- k_utd3: the fused  up (deconv k8 s4 + PReLU) -> tran (1x1 + PReLU) -> down (conv k8 s4 + PReLU)
 // stage of the FeedbackBlock (reference SRProjectionModule.py:62-65,77-80 under the zero-fill semantic), one wave per
-// SIMD.  Same LDS layout, weight blob and per-accumulator arithmetic order as k_utd (sr_f16.hip): bit-identical output.
+// SIMD, the x4 feature map handed from the deconv to the conv IN REGISTERS.  Same weight blob and per-accumulator
+// arithmetic order as k_utd (sr_f16.hip): bit-identical output.
 //
-// Why a second kernel: s_memtime stamps on k_utd (tools/utd_stamps.py) showed its two waves per SIMD running the same
-// phase at the same time -- the older wave wins the MFMA issue, then idles ~1400 of ~4400 cycles per step at the
-// barrier, and the VALU-heavy deconv epilogue (convert / PReLU / 1x1 / PReLU) of either wave never sits beside MFMAs.
-// Here one wave owns HR row `wv` of a group with all four column phases (P1) and ring row `wv` with both out-channel
-// halves (P2): the step is ONE instruction stream of 144 MFMAs whose order is written out by hand --
-//     A  deconv phases 0,1 (32 MFMA)                      || reduce of LR row i-2
-//     B  deconv phases 2,3 (32)                            || first PReLU of phases 0,1
-//     C  1x1 of phases 0,1 (8) + down conv taps 0..15      || first PReLU of phases 2,3
-//     D  down conv 16..23, 1x1 of 2,3 (8), down 24..39     || second PReLU of 0,1 -> ring
-//     E  down conv 40..63                                  || second PReLU of 2,3 -> ring
-// -- with every VALU / LDS instruction placed in the issue gap of an MFMA (<= 2 VALU per 16x16x32 MFMA, the gfx950
-// issue budget) and the schedule pinned by sched_barrier fences (hipcc's own order put the reduce and half of the
-// epilogue after the MFMAs).  The 64 weight fragments live in AGPRs (MFMA reads A from either file), everything the
-// VALU touches in VGPRs (compiled with -mllvm -amdgpu-mfma-vgpr-form).  LDS operand reads halve against k_utd: a B
-// fragment feeds 4 MFMAs in the down conv and 8 in the deconv.
+// Why this kernel (all measured on k_utd / earlier builds of this file with s_memtime stamps and ablations,
+// tools/utd_stamps.py):
+//  * k_utd's two waves per SIMD run the same phase at the same time; the older wave wins the MFMA issue, then idles
+//    ~1400 of ~4400 cycles per LR row at the barrier, and the VALU-heavy epilogue never sits beside MFMAs.  Here one
+//    wave owns HR row `wv` of every group with all four column phases and both out-channel halves: one instruction
+//    stream of 144 MFMAs per LR row, its order written out by hand and pinned with sched_barrier fences.
+//  * the wave that produces HR row 4i+2+wv is the wave that convolves it (kernel rows wv and wv+4 of the stride-4 conv),
+//    and the conv's B operand for tap kx is the deconv's output tile of column phase kx&3 -- as it lies in the
+//    accumulator-derived registers for kx < 4, shifted by one pixel (two DPP moves per register) for kx >= 4.  So the
+//    LDS ring of k_utd is not needed: 8 of 13 ds_write_b128 and 16 of 28 ds_read_b128 per wave and row disappear
+//    (ablation: the 13 stores cost ~460 of 3750 cycles per row; all 192 PReLU/convert VALU together only ~210).
+//  * step i = [deconv phases 0,1 of group G(i) + reduce of row i-3: nothing another wave writes in this step]
+//    BARRIER [deconv phases 2,3, the 1x1s and PReLUs of G(i), the down conv over G(i-1) from registers, partial tiles]:
+//    the barrier never waits for LDS traffic to drain and no LDS latency is exposed behind it.
+//  * the 64 weight fragments live in AGPRs (MFMA reads A from either file), everything the VALU touches in VGPRs
+//    (compiled with -mllvm -amdgpu-mfma-vgpr-form); out-of-image lanes use buffer loads/stores with an out-of-range
+//    offset instead of branches, so a step is one basic block.
 #include "sr_f16_common.h"
 
 namespace {
@@ -46,18 +49,19 @@ __device__ __forceinline__ h8 act_result(const ActU& u) {
 
 #define VSR_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+constexpr int UTD3_LDS = PART_BYTES + LR_BYTES;   // no HR ring: the x4 map never leaves the registers
+
 template <bool ALLMAX, int DIAG>
 __global__ void __launch_bounds__(256)
 k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _Float16* __restrict__ out, int h, int w,
        int rows_per_seg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const ring = smem;
-    unsigned char* const part = smem + RING_BYTES;
-    unsigned char* const lrr = smem + RING_BYTES + PART_BYTES;
+    unsigned char* const part = smem;                 // 2 x 4 fp32 partial tiles
+    unsigned char* const lrr = smem + PART_BYTES;     // 3 LR rows
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // HR row of the group (P1) = ring row (P2)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // HR row of every group this wave deconvolves and convolves
     const int l15 = lane & 15, g = lane >> 4;
     const int x0 = blockIdx.x * TX;
     const int n = blockIdx.z;
@@ -111,12 +115,10 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     const h2 a_up2 = {(_Float16)a_up, (_Float16)a_up}, a_dt2 = {(_Float16)a_dt, (_Float16)a_dt};
     const bool up_max = ALLMAX || a_up <= 1.0f, dt_max = ALLMAX || a_dt <= 1.0f;
     const bool edge_strip = (x0 == 0) || (4 * (x0 + 32) - 2 >= 4 * w);
-    int ring_lo[2], ring_hi[2], lr_b[2][2];
+    int lr_b[2][2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int j = 16 * nt + l15;
-        ring_lo[nt] = j * (4 * COL_PITCH) + ((g ^ ((j >> 1) & 3)) << 4);
-        ring_hi[nt] = j * (4 * COL_PITCH) + ((g ^ (((j + 1) >> 1) & 3)) << 4);
         lr_b[0][nt] = lr_off(j + 1, g);
         lr_b[1][nt] = lr_off(j, g);
     }
@@ -132,10 +134,14 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 1 + lr_px;
     const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
     const int lr_st = lr_off(lr_px, lr_ch);
-    auto fetch_lr = [&](int r) __attribute__((always_inline)) -> uint4 {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (lr_col_ok && r >= 0 && r < h) v = *reinterpret_cast<const uint4*>(in_n + ((size_t)r * w + lr_col) * NF + lr_ch * 8);
-        return v;
+    // LR row r -> 16-byte piece of this thread.  A buffer load: lanes outside the image (or without a piece) read from
+    // an out-of-range offset and get zeros -- no branch, so the value is not a phi and hipcc waits for it where it is
+    // used (the LDS store at the end of the step), not at the top of the step
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    auto fetch_lr = [&](int r) __attribute__((always_inline)) -> u4 {
+        const unsigned off = (lr_col_ok && r >= 0 && r < h) ? (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
+        return __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
     };
     auto lr_slot = [&](int r) __attribute__((always_inline)) { return ((r + 1) % 3) * LR_SLOT; };
 
@@ -166,18 +172,44 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
         const int c = k >> 2, nt = (k >> 1) & 1, mt = k & 1;
         a2[c][nt][mt] = mfma16(adt[mt], act_result(ua[c * 2 + nt]), bdt[mt]);
     };
-    // ring operand of down-conv group gq = kx*2 + nt
-    auto ring_read = [&](const unsigned char* rowbase, int gq) __attribute__((always_inline)) -> h8 {
-        const int kx = gq >> 1, nt = gq & 1;
-        return *reinterpret_cast<const h8*>(rowbase + (kx < 4 ? ring_lo[nt] : ring_hi[nt]) + kx * COL_PITCH);
+    // Down-conv operand of group gq = kx*2 + nt (output pixel j = 16 nt + lane&15, tap kx): HR column 4j + kx - 2 is
+    // deconv position j, column phase kx for kx < 4, and position j + 1, phase kx - 4 for kx >= 4 -- the tile of that
+    // phase moved down one lane inside each 16-lane row, lane 15 of tile 0 taking lane 0 of tile 1 (lane 15 of tile 1
+    // feeds only the discarded 32nd output).
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    struct ShU {
+        unsigned w[2][4];
     };
-    // k-th down-conv MFMA: group gq = k>>2 (kx, nt), then out-channel half m, then {finish current row, start next row}
-    auto pmf = [&](int k, const h8& b, f4 (&acc)[2][2], f4 (&nc)[2][2]) __attribute__((always_inline)) {
-        const int gq = k >> 2, kx = gq >> 1, nt = gq & 1, m = (k >> 1) & 1;
-        if ((k & 1) == 0) acc[m][nt] = mfma16(Adn[m][1][kx], b, kx == 0 ? carry[m][nt] : acc[m][nt]);
-        else nc[m][nt] = mfma16(Adn[m][0][kx], b, kx == 0 ? f4{0.0f, 0.0f, 0.0f, 0.0f} : nc[m][nt]);
+    // 12 single DPP moves, each placed in an MFMA gap: 0-3 row_ror:15 of tile 1 into the tile-0 registers (supplies
+    // their lane 15), 4-7 the same into the tile-1 registers, 8-11 row_shl:1 of tile 0 over lanes 0-14 of the first set.
+    // (Writing both copies with a DPP move avoids a plain copy plus the 2-wait-state VALU->DPP hazard per register.)
+    auto dpp_stage = [&](ShU& sh, int j, const h8 (&ob)[2]) __attribute__((always_inline)) {
+        const int q = j & 3;
+        if (j < 4) {          // (bound_ctrl differs from the next case only so that the two moves are not merged into move + copy)
+            sh.w[0][q] = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(u4v, ob[1])[q], 0x12F, 0xF, 0xF, true);
+        } else if (j < 8) {
+            sh.w[1][q] = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(u4v, ob[1])[q], 0x12F, 0xF, 0xF, false);
+        } else {
+            sh.w[0][q] = __builtin_amdgcn_update_dpp(sh.w[0][q], __builtin_bit_cast(u4v, ob[0])[q], 0x101, 0xF, 0xF, false);
+        }
     };
-    auto ring_store = [&](unsigned char* rowbase, int px, int nt, ActU& u, auto edgec) __attribute__((always_inline)) {
+    auto sh_tile = [&](const ShU& sh, int nt) __attribute__((always_inline)) -> h8 {
+        return __builtin_bit_cast(h8, u4v{sh.w[nt][0], sh.w[nt][1], sh.w[nt][2], sh.w[nt][3]});
+    };
+    // k-th down-conv MFMA: group gq = k>>2 = (tap slot kk, nt), then out-channel half m, then {finish current row, start
+    // next row}.  Tap order 0,4,1,5,2,6,3,7: both uses of a column phase's tile (tap px as it lies, tap px+4 shifted)
+    // are adjacent, so its registers die early.  (k_utd accumulates in the same order.)
+    auto pmf = [&](int k, const h8 (&obP)[4][2], const ShU (&sh)[4], f4 (&acc)[2][2]) __attribute__((always_inline)) {
+        const int gq = k >> 2, kk = gq >> 1, nt = gq & 1, m = (k >> 1) & 1;
+        const int kx = (kk >> 1) + 4 * (kk & 1);
+        const h8 b = kx < 4 ? obP[kx][nt] : sh_tile(sh[kx - 4], nt);
+        // the carried accumulator is read by the first MFMA of its chain and restarted (from zero) by the next one
+        if ((k & 1) == 0) acc[m][nt] = mfma16(Adn[m][1][kx], b, kk == 0 ? carry[m][nt] : acc[m][nt]);
+        else carry[m][nt] = mfma16(Adn[m][0][kx], b, kk == 0 ? f4{0.0f, 0.0f, 0.0f, 0.0f} : carry[m][nt]);
+    };
+    // finished PReLU unit -> operand tile of (column phase px, pixel tile nt); columns outside the image are the conv's
+    // zero padding
+    auto ob_finish = [&](int px, int nt, ActU& u, auto edgec) __attribute__((always_inline)) -> h8 {
         constexpr bool EDGE = decltype(edgec)::value;
         if (EDGE) {
             const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
@@ -186,7 +218,7 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) u.r[q] = col_ok ? u.r[q] : z;
         }
-        *reinterpret_cast<h8*>(rowbase + ring_lo[nt] + px * COL_PITCH) = act_result(u);
+        return act_result(u);
     };
     auto store_partials = [&](unsigned char* pbase, const f4 (&acc)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
@@ -231,189 +263,204 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
 #pragma unroll
         for (int j = 0; j < 31; ++j) red_stage(j, i, pr, u);
     };
-    // whole P1 of one HR row, unscheduled (prologue / first and last steps)
-    auto p1_plain = [&](int s_i, int s_i1, unsigned char* rowbase, auto edgec) __attribute__((always_inline)) {
-        h8 Bf[4][2];
-        load_lr_frags(s_i, s_i1, Bf);
+    // whole deconv -> PReLU -> 1x1 -> PReLU of one HR row (prologue / first and last steps): unit by unit, fenced, so
+    // that this cold path does not set the kernel's register peak
+    auto p1_plain = [&](const h8 (&Bf)[4][2], h8 (&ob)[4][2], auto edgec) __attribute__((always_inline)) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            f4 acc[2][2][2], a2[2][2][2];
-            ActU ua[4], ub[4];
+            f4 acc[2][2][2];
 #pragma unroll
             for (int k = 0; k < 32; ++k) dmf(half, k, Bf, acc);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < 12; ++j) act_stage(ua[u], j, acc[u >> 1][0][u & 1], acc[u >> 1][1][u & 1], a_up2, up_max);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) tmf(k, ua, a2);
+            VSR_FENCE();
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                const int c = u >> 1, nt = u & 1;
+                ActU ua, ub;
+                f4 a2[2];
 #pragma unroll
-                for (int j = 0; j < 12; ++j) act_stage(ub[u], j, a2[u >> 1][u & 1][0], a2[u >> 1][u & 1][1], a_dt2, dt_max);
-                ring_store(rowbase, 2 * half + (u >> 1), u & 1, ub[u], edgec);
+                for (int j = 0; j < 12; ++j) act_stage(ua, j, acc[c][0][nt], acc[c][1][nt], a_up2, up_max);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) a2[mt] = mfma16(adt[mt], act_result(ua), bdt[mt]);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) act_stage(ub, j, a2[0], a2[1], a_dt2, dt_max);
+                ob[2 * half + c][nt] = ob_finish(2 * half + c, nt, ub, edgec);
+                VSR_FENCE();
             }
         }
     };
-    auto down_plain = [&](const unsigned char* rbase, f4 (&acc)[2][2]) __attribute__((always_inline)) {
-        const unsigned char* const rowbase = rbase + wv * ROW_PITCH;
-        f4 nc[2][2];
-#pragma unroll
-        for (int gq = 0; gq < 16; ++gq) {
-            const h8 b = ring_read(rowbase, gq);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pmf(4 * gq + q, b, acc, nc);
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) carry[m][nt] = nc[m][nt];
-    };
-    auto zero_ring_row = [&](unsigned char* rowbase) __attribute__((always_inline)) {
+    auto zero_row = [&](h8 (&ob)[4][2]) __attribute__((always_inline)) {
         h8 z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
 #pragma unroll
         for (int px = 0; px < 4; ++px)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<h8*>(rowbase + ring_lo[nt] + px * COL_PITCH) = z;
+            for (int nt = 0; nt < 2; ++nt) ob[px][nt] = z;
+    };
+    auto down_plain = [&](const h8 (&obP)[4][2], f4 (&acc)[2][2]) __attribute__((always_inline)) {
+        ShU sh[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {   // taps px (as it lies) and px + 4 (shifted); fenced to keep live ranges short
+#pragma unroll
+            for (int j = 0; j < 12; ++j) dpp_stage(sh[px], j, obP[px]);
+#pragma unroll
+            for (int k = 16 * px; k < 16 * px + 16; ++k) pmf(k, obP, sh, acc);
+            VSR_FENCE();
+        }
     };
 
-    // ---- prologue: LR rows r0-1, r0, r0+1 -> LDS; group G(r0-1) (recomputed halo of the segment, zeros above the image)
+    // ---- prologue: LR rows r0-1, r0, r0+1 -> LDS; group G(r0-1) (recomputed halo of the segment, zeros above the
+    //      image); then row r0+2 over row r0-1 (the march keeps rows i, i+1, i+2 resident during step i)
     if (lr_loader) {
-        *reinterpret_cast<uint4*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
-        *reinterpret_cast<uint4*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
-        *reinterpret_cast<uint4*>(lrr + lr_slot(r0 + 1) + lr_st) = fetch_lr(r0 + 1);
+        *reinterpret_cast<u4*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
+        *reinterpret_cast<u4*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
+        *reinterpret_cast<u4*>(lrr + lr_slot(r0 + 1) + lr_st) = fetch_lr(r0 + 1);
     }
     __syncthreads();
+    h8 obP[4][2];   // this wave's HR row of the previous group, as down-conv operand tiles [column phase][pixel tile]
     {
         const int i = r0 - 1, r_hr = 4 * i + 2 + wv;
-        unsigned char* const rowbase = ring + (i & 1) * SLOT_PITCH + wv * ROW_PITCH;
-        if (r_hr >= 0 && r_hr < 4 * h) p1_plain(lr_slot(i), lr_slot(i + 1), rowbase, BoolC<true>{});
-        else zero_ring_row(rowbase);
+        if (r_hr >= 0 && r_hr < 4 * h) {
+            h8 Bf[4][2];
+            load_lr_frags(lr_slot(i), lr_slot(i + 1), Bf);
+            p1_plain(Bf, obP, BoolC<true>{});
+        } else {
+            zero_row(obP);
+        }
     }
     __syncthreads();
+    if (lr_loader) *reinterpret_cast<u4*>(lrr + lr_slot(r0 + 2) + lr_st) = fetch_lr(r0 + 2);
     // every global load of the prologue (weights, biases) has landed: say so, or the in-order vmcnt bookkeeping makes
     // the first use of a preloaded constant inside the loop wait for the LR row prefetch issued at the top of the step
     __builtin_amdgcn_s_waitcnt(0);
 
-    int s_im1 = lr_slot(r0 - 1), s_i = lr_slot(r0), s_i1 = lr_slot(r0 + 1);
-    int ring_cur = (r0 & 1) * SLOT_PITCH, part_cur = (r0 & 1) * PART_BUF;
+    // Step i:   [LR operands of rows i, i+1 -> registers; deconv phases 0,1; reduce of row i-3]   -- touches no shared
+    //           state another wave writes in this step --  BARRIER  [the rest; writes the partial tiles of row i-1 and LR
+    //           row i+3].  The barrier therefore never waits for LDS traffic to drain, and no LDS
+    //           latency is exposed behind it: the MFMAs that follow it have their operands in registers.
+    int s_i = lr_slot(r0), s_i1 = lr_slot(r0 + 1), s_i2 = lr_slot(r0 + 2);
+    int part_cur = (r0 & 1) * PART_BUF;
+    // LR operands (rows i, i+1) of step i: loop-carried, requested during the last gaps of step i-1 so that step i
+    // opens with MFMAs instead of an LDS round trip
+    h8 Bf[4][2];
+    load_lr_frags(s_i, s_i1, Bf);
     unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
     const unsigned long long rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0, ct0 = DIAG ? __builtin_amdgcn_s_memtime() : 0;
-    auto march = [&](auto edgec) __attribute__((always_inline)) {
-        for (int i = r0; i < r1; ++i) {
-            uint4 nxt = make_uint4(0, 0, 0, 0);
-            if (wv < 3) nxt = fetch_lr(i + 2);
-            const unsigned char* const prow = ring + (ring_cur ^ SLOT_PITCH) + wv * ROW_PITCH;   // ring row wv of G(i-1)
-            unsigned char* part_prev = part + (part_cur ^ PART_BUF);
-            unsigned char* const rowbase = ring + ring_cur + wv * ROW_PITCH;
+    // one LR row.  obP holds this wave's HR row of G(i-1) on entry and of G(i) on exit: with the tap order 0,4,1,5,...
+    // the tile of column phase px has had both its uses before the new tile of that phase is finished, so the
+    // registers are updated in place.
+    auto step = [&](int i, h8 (&obP)[4][2], auto edgec) __attribute__((always_inline)) {
+        {
+            const u4 nxt = fetch_lr(i + 3);
+            unsigned char* part_prev = part + (part_cur ^ PART_BUF);   // rows i-1 (written below) and i-3 (reduced above the barrier)
             const int r_hr = 4 * i + 2 + wv;
+            const bool row_ok = r_hr >= 0 && r_hr < 4 * h;
             f4 accd[2][2];
-            const unsigned long long t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0;
-            if (i >= r0 + 2 && r_hr < 4 * h) {
+            const unsigned long long t0 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+            if (i >= r0 + 3 && r_hr < 4 * h) {
                 // ======================= steady state: the hand-ordered step (see the file header)
-                h8 Bf[4][2], bq[16];
-                f4 pr[4], accA[2][2][2], accB[2][2][2], a2A[2][2][2], a2B[2][2][2], nc[2][2];
+                ShU sh[4];
+                f4 pr[4], accA[2][2][2], accB[2][2][2], a2A[2][2][2], a2B[2][2][2];
                 RedU ru;
                 ActU uA[4], uB[4], fA[4], fB[4];
-                load_lr_frags(s_i, s_i1, Bf);
                 VSR_FENCE();
-                // ---- A: partial tiles of row i-2 requested in the first gaps, reduced one VALU per gap from slot 6 on
+                // ---- A: partial tiles of row i-3 requested in the first gaps, reduced one VALU per gap from slot 6 on
 #pragma unroll
                 for (int s = 0; s < 32; ++s) {
                     dmf(0, s, Bf, accA);
-                    if (s < 4) pr[s] = *reinterpret_cast<const f4*>(part + part_cur + part_rd + s * PART_W_PITCH);
+                    if (s < 4) pr[s] = *reinterpret_cast<const f4*>(part_prev + part_rd + s * PART_W_PITCH);
                     if (s >= 6) {
 #pragma unroll
-                        for (int v = ((s - 6) * 31) / 26; v < ((s - 5) * 31) / 26; ++v) red_stage(v, i - 2, pr, ru);
+                        for (int v = ((s - 6) * 31) / 26; v < ((s - 5) * 31) / 26; ++v) red_stage(v, i - 3, pr, ru);
                     }
                     VSR_FENCE();
                 }
-                const unsigned long long tA = DIAG ? __builtin_amdgcn_s_memtime() : 0;
-                // ---- B: 48 VALU over 32 MFMAs; ring operands of the first 4 down-conv groups requested at the end
+                const unsigned long long tA = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+                __syncthreads();
+                const unsigned long long tBar = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+                VSR_FENCE();
+                // ---- B: 48 VALU over 32 MFMAs
 #pragma unroll
                 for (int s = 0; s < 32; ++s) {
                     dmf(1, s, Bf, accB);
 #pragma unroll
                     for (int v = (3 * s) / 2; v < (3 * (s + 1)) / 2; ++v)
                         act_stage(uA[v / 12], v % 12, accA[v / 24][0][(v / 12) & 1], accA[v / 24][1][(v / 12) & 1], a_up2, up_max);
-                    if (s >= 24 && (s & 1) == 0) bq[(s - 24) / 2] = ring_read(prow, (s - 24) / 2);
                     VSR_FENCE();
                 }
-                const unsigned long long tB = DIAG ? __builtin_amdgcn_s_memtime() : 0;
+                const unsigned long long tB = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
                 // ---- C: 8 1x1 MFMAs, down-conv groups 0..3; first PReLU of phases 2,3 (2 VALU per MFMA)
 #pragma unroll
                 for (int s = 0; s < 24; ++s) {
                     if (s < 8) tmf(s, uA, a2A);
-                    else pmf(s - 8, bq[(s - 8) >> 2], accd, nc);
+                    else pmf(s - 8, obP, sh, accd);
 #pragma unroll
                     for (int v = 2 * s; v < 2 * s + 2; ++v)
                         act_stage(uB[v / 12], v % 12, accB[v / 24][0][(v / 12) & 1], accB[v / 24][1][(v / 12) & 1], a_up2, up_max);
-                    if (s >= 8 && (s & 3) == 0) bq[4 + (s - 8) / 4] = ring_read(prow, 4 + (s - 8) / 4);
+                    if (s >= 4 && s < 16) dpp_stage(sh[0], s - 4, obP[0]);   // tap 4 (first used in slot 16)
                     VSR_FENCE();
                 }
-                const unsigned long long tC = DIAG ? __builtin_amdgcn_s_memtime() : 0;
-                // ---- D: down-conv groups 4,5 | 1x1 of phases 2,3 | groups 6..9; second PReLU of phases 0,1 -> ring
+                const unsigned long long tC = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+                // ---- D: down-conv groups 4,5 | 1x1 of phases 2,3 | groups 6..9; second PReLU of phases 0,1
 #pragma unroll
                 for (int s = 0; s < 32; ++s) {
-                    if (s < 8) pmf(16 + s, bq[4 + (s >> 2)], accd, nc);
+                    if (s < 8) pmf(16 + s, obP, sh, accd);
                     else if (s < 16) tmf(s - 8, uB, a2B);
-                    else pmf(24 + (s - 16), bq[6 + ((s - 16) >> 2)], accd, nc);
+                    else pmf(24 + (s - 16), obP, sh, accd);
 #pragma unroll
                     for (int v = (3 * s) / 2; v < (3 * (s + 1)) / 2; ++v) {
                         const int u = v / 12;
                         act_stage(fA[u], v % 12, a2A[u >> 1][u & 1][0], a2A[u >> 1][u & 1][1], a_dt2, dt_max);
-                        if (v % 12 == 11) ring_store(rowbase, u >> 1, u & 1, fA[u], edgec);
+                        if (v % 12 == 11) obP[u >> 1][u & 1] = ob_finish(u >> 1, u & 1, fA[u], edgec);
                     }
-                    if (s == 2 || s == 6 || s == 18 || s == 22) {
-                        const int gq = 8 + (s == 2 ? 0 : s == 6 ? 1 : s == 18 ? 2 : 3);
-                        bq[gq] = ring_read(prow, gq);
-                    }
+                    if (s >= 4 && s < 16) dpp_stage(sh[1], s - 4, obP[1]);   // tap 5 (first used in slot 16)
+                    if (s >= 20) dpp_stage(sh[2], s - 20, obP[2]);   // tap 6 (first used in slot 0 of E)
                     VSR_FENCE();
                 }
-                const unsigned long long tD = DIAG ? __builtin_amdgcn_s_memtime() : 0;
-                // ---- E: down-conv groups 10..15; second PReLU of phases 2,3 -> ring
+                const unsigned long long tD = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+                // ---- E: down-conv groups 10..15; second PReLU of phases 2,3; LR operands of the next step
 #pragma unroll
                 for (int s = 0; s < 24; ++s) {
-                    pmf(40 + s, bq[10 + (s >> 2)], accd, nc);
+                    pmf(40 + s, obP, sh, accd);
 #pragma unroll
                     for (int v = 2 * s; v < 2 * s + 2; ++v) {
                         const int u = v / 12;
                         act_stage(fB[u], v % 12, a2B[u >> 1][u & 1][0], a2B[u >> 1][u & 1][1], a_dt2, dt_max);
-                        if (v % 12 == 11) ring_store(rowbase, 2 + (u >> 1), u & 1, fB[u], edgec);
+                        if (v % 12 == 11) obP[2 + (u >> 1)][u & 1] = ob_finish(2 + (u >> 1), u & 1, fB[u], edgec);
                     }
-                    if (s < 16 && (s & 3) == 0) bq[12 + s / 4] = ring_read(prow, 12 + s / 4);
+                    if (s >= 4 && s < 16) dpp_stage(sh[3], s - 4, obP[3]);   // tap 7 (first used in slot 16)
+                    if (s >= 16) {   // LR operands of step i+1 (rows i+1, i+2; the deconv of this step is done with Bf)
+                        const int t = (s - 16) >> 1, nt = (s - 16) & 1;
+                        Bf[t][nt] = *reinterpret_cast<const h8*>(lrr + ((t >> 1) ? s_i1 : s_i2) + lr_b[t & 1][nt]);
+                    }
                     VSR_FENCE();
                 }
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) carry[m][nt] = nc[m][nt];
-                if (DIAG) {
+                if (DIAG == 1) {
                     const unsigned long long tE = __builtin_amdgcn_s_memtime();
-                    stamp[0] += tA - t0; stamp[1] += tB - tA; stamp[2] += tC - tB; stamp[3] += tD - tC; stamp[4] += tE - tD;
+                    stamp[0] += tA - t0; stamp[1] += tB - tBar; stamp[2] += tC - tB; stamp[3] += tD - tC; stamp[4] += tE - tD;
+                    stamp[5] += tBar - tA;
                 }
             } else {
-                if (r_hr >= 0 && r_hr < 4 * h) p1_plain(s_i, s_i1, rowbase, edgec);
-                else zero_ring_row(rowbase);
-                down_plain(ring + (ring_cur ^ SLOT_PITCH), accd);   // (the partial row of i = r0 is row r0-1's: never reduced)
-                if (i - 2 >= r0) reduce_store(i - 2, part + part_cur);
+                if (i - 3 >= r0) reduce_store(i - 3, part_prev);
+                __syncthreads();
+                h8 obN[4][2];
+                if (row_ok) p1_plain(Bf, obN, edgec);
+                else zero_row(obN);
+                down_plain(obP, accd);   // (the partial row of i = r0 is row r0-1's: never reduced)
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) obP[px][nt] = obN[px][nt];
+                load_lr_frags(s_i1, s_i2, Bf);
             }
-            const unsigned long long t1 = DIAG ? __builtin_amdgcn_s_memtime() : 0;
             store_partials(part_prev, accd);
-            if (wv < 3 && lr_loader) *reinterpret_cast<uint4*>(lrr + s_im1 + lr_st) = nxt;  // row i+2 -> slot of row i-1
-            const unsigned long long t2 = DIAG ? __builtin_amdgcn_s_memtime() : 0;
-            __syncthreads();
-            if (DIAG) {
-                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-                stamp[5] += t3 - t1;
-                (void)t2;
-            }
-            const int t = s_im1; s_im1 = s_i; s_i = s_i1; s_i1 = t;
-            ring_cur ^= SLOT_PITCH;
+            if (wv < 3 && lr_loader) *reinterpret_cast<u4*>(lrr + s_i + lr_st) = nxt;  // row i+3 -> slot of row i
+            const int t = s_i; s_i = s_i1; s_i1 = s_i2; s_i2 = t;
             part_cur ^= PART_BUF;
         }
+    };
+    auto march = [&](auto edgec) __attribute__((always_inline)) {
+        for (int i = r0; i < r1; ++i) step(i, obP, edgec);
     };
     if (edge_strip) march(BoolC<true>{}); else march(BoolC<false>{});
     if (DIAG && g_stamp3_ptr && lane == 0) {
@@ -422,10 +469,13 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
         d[6] = __builtin_amdgcn_s_memtime() - ct0;
         d[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
-    // after the loop *_cur has the parity of r1: row r1-1 lives in the other buffers
+    // after the loop part_cur has the parity of r1.  Left over: rows r1-3 (tiles visible), r1-2 (tiles written in the
+    // last step), r1-1 (group G(r1-1) in obP, not yet convolved)
+    if (r1 - 3 >= r0) reduce_store(r1 - 3, part + (part_cur ^ PART_BUF));
+    __syncthreads();
     {
         f4 accd[2][2];
-        down_plain(ring + (ring_cur ^ SLOT_PITCH), accd);
+        down_plain(obP, accd);
         store_partials(part + (part_cur ^ PART_BUF), accd);
     }
     if (r1 - 2 >= r0) reduce_store(r1 - 2, part + part_cur);
@@ -443,18 +493,18 @@ int utd3_set_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stam
 int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                 int diag, hipStream_t stream) {
     typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
-    static const kern_t kerns[3] = {k_utd3<false, 0>, k_utd3<true, 0>, k_utd3<true, 1>};
+    static const kern_t kerns[4] = {k_utd3<false, 0>, k_utd3<true, 0>, k_utd3<true, 1>, k_utd3<true, 2>};
     static bool attr_done = false;
     if (!attr_done) {
         for (kern_t k : kerns)
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS) != hipSuccess)
-                return vsr::fail(VSR_E_LAUNCH, "sr_utd3: cannot reserve %d bytes of LDS", UTD_LDS);
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, UTD3_LDS) != hipSuccess)
+                return vsr::fail(VSR_E_LAUNCH, "sr_utd3: cannot reserve %d bytes of LDS", UTD3_LDS);
         attr_done = true;
     }
-    if ((size_t)N * h * w * NF * 2 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_utd3: output beyond 2 GiB");
+    if ((size_t)N * h * w * NF * 2 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_utd3: tensors beyond 2 GiB");
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
-    const kern_t k = diag ? kerns[2] : kerns[slopes_le_one ? 1 : 0];
-    hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(256), UTD_LDS, stream, (const _Float16*)in, (const unsigned char*)blob,
+    const kern_t k = diag ? kerns[1 + diag] : kerns[slopes_le_one ? 1 : 0];
+    hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(256), UTD3_LDS, stream, (const _Float16*)in, (const unsigned char*)blob,
                        (_Float16*)out, h, w, rows_per_seg);
     return vsr::launched("sr_utd3");
 }
