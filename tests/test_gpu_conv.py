@@ -24,6 +24,9 @@ CASES = [  # (N, Cin, H, W, Cout, k, stride, pad, act)
     (1, 64, 20, 50, 16, 11, 1, 5, igemm.ACT_RELU),     # 16-wide 11x11 inception branch: patch path
     (1, 194, 33, 47, 2, 3, 1, 1, igemm.ACT_NONE),      # predict_flow2: patch path over 7 channel chunks
     (1, 32, 9, 40, 16, 7, 1, 3, igemm.ACT_RELU),       # patch path, ragged tile edges
+    (1, 128, 259, 271, 208, 1, 1, 0, igemm.ACT_RELU),  # fused inception 1x1s, many pixels: streaming 1x1 kernel (ragged last block)
+    (2, 256, 190, 181, 160, 1, 1, 0, igemm.ACT_RELU),  # streaming 1x1, 8 channel chunks
+    (1, 96, 300, 230, 77, 1, 1, 0, igemm.ACT_LEAKY),   # streaming 1x1, odd out-channel count
 ]
 
 

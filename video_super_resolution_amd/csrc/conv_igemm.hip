@@ -187,6 +187,101 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions over many pixels (the hourglass's fused inception 1x1s: 128 -> 208 at 4 x 540 x 960 ...): HBM-bound
+// (cin + cout) * 2 bytes per pixel against 2*cin*cout FLOP.  k_conv_igemm re-reads the input once per 64 out-channels;
+// here a persistent workgroup stages the whole weight matrix in LDS once, each wave keeps the K = cin operand of its 32
+// pixels in registers (read once from HBM) and walks every out-channel tile from LDS.
+//   512 threads = 8 waves x 32 pixels; LDS: [cin/32][cout_pad][32] fp16, rows of 64 B with the usual chunk swizzle.
+constexpr int C1_MAX_CHUNKS = 8;   // cin <= 256
+template <int NCH>
+__global__ void __launch_bounds__(512) k_conv1x1_stream(const ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    // weights -> LDS (once per workgroup): piece q = 16 bytes = row q>>2 (a (chunk, cout) pair), chunk-of-row q&3
+    const int rows = NCH * p.cout_pad;
+    for (int q = tid; q < rows * 4; q += 512)
+        *reinterpret_cast<uint4*>(wsm + sw_off(q >> 2, q & 3)) = *reinterpret_cast<const uint4*>(p.wpk + (size_t)q * 8);
+    __syncthreads();
+    const int ntile = p.cout_pad >> 4;
+    const long long nblk = (M + 255) / 256;
+    // this wave's 32 pixels x cin, straight into MFMA B-operand registers (lane: pixel l15 of tile nt, chunk piece g);
+    // the next block's pixels are requested before this block's tiles are computed and stored
+    h8 bf[NCH][2], nx[NCH][2];
+    auto fetch = [&](long long blk, h8 (&dst)[NCH][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const long long m = blk * 256 + 32 * wv + 16 * nt + l15;
+            const _Float16* src = p.in + (size_t)(m < M ? m : M - 1) * p.in_ld + p.in_coff + 8 * g;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) dst[c][nt] = *reinterpret_cast<const h8*>(src + 32 * c);
+        }
+    };
+    if ((long long)blockIdx.x < nblk) fetch(blockIdx.x, nx);
+    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long long mbase = blk * 256 + 32 * wv;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bf[c][nt] = nx[c][nt];
+        if (blk + gridDim.x < nblk) fetch(blk + gridDim.x, nx);
+        // out-channel blocks of 32 as two MFMA row tiles whose rows are interleaved in groups of four (tile A row i =
+        // channel 8(i>>2) + (i&3), tile B the same + 4): a lane then owns 8 consecutive channels of a pixel -> 16-byte
+        // stores, 64 contiguous bytes per pixel and instruction.  A trailing 16-channel tile uses rows in natural order.
+        for (int t = 0; t < ntile; t += 2) {
+            const bool pair = t + 1 < ntile;
+            f4 acc[2][2];
+#pragma unroll
+            for (int wh = 0; wh < 2; ++wh)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[wh][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            const int rowA = pair ? 16 * t + 8 * (l15 >> 2) + (l15 & 3) : 16 * t + l15;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const h8 a0 = *reinterpret_cast<const h8*>(wsm + sw_off(c * p.cout_pad + rowA, g));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf[c][nt], acc[0][nt], 0, 0, 0);
+                if (pair) {
+                    const h8 a1 = *reinterpret_cast<const h8*>(wsm + sw_off(c * p.cout_pad + rowA + 4, g));
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[c][nt], acc[1][nt], 0, 0, 0);
+                }
+            }
+            // this lane: channels c0 .. c0+7 (pair) or c0 .. c0+3 (single tile) of pixels l15 (nt 0) and 16 + l15 (nt 1)
+            const int c0 = pair ? 16 * t + 8 * g : 16 * t + 4 * g;
+            const int nch = pair ? 8 : 4;
+            if (c0 >= p.cout) continue;
+            float bz[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bz[r] = (p.bias && r < nch && c0 + r < p.cout) ? p.bias[c0 + r] : 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const long long m = mbase + 16 * nt + l15;
+                if (m >= M) continue;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float x = acc[r >> 2][nt][r & 3] + bz[r];
+                    if (p.act == 1) x = fmaxf(x, 0.0f);
+                    else if (p.act == 2) x = x >= 0.0f ? x : x * p.slope;
+                    v[r] = x;
+                }
+                _Float16* dst = p.out + (size_t)m * p.out_ld + p.out_coff + c0;
+                if (pair && c0 + 8 <= p.cout && ((p.out_coff + c0) & 7) == 0 && (p.out_ld & 7) == 0) {
+                    *reinterpret_cast<h8*>(dst) = h8{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3],
+                                                     (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        if (r < nch && c0 + r < p.cout) dst[r] = (_Float16)v[r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Stride-1 convolutions with a spatial kernel (the hourglass's 3x3..11x11 inception branches and final conv, FlowNet's
 // 3x3 layers and predict_flow, OSVOS's VGG stages): the tap-by-tap gather of k_conv_igemm re-reads every input pixel
 // kh*kw times from L2, which bounds these layers by L2 bandwidth; here a workgroup stages the 2-D input patch of an
@@ -437,6 +532,26 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
         else
             hipLaunchKernelGGL(k_conv_patch<1>, dim3(tiles, N, cout_pad / 16), dim3(256), patch_lds, vsr::S(stream), p);
         return vsr::launched("conv2d_nhwc_f16/patch");
+    }
+    // 1x1 over many pixels with more than one 64-channel block of outputs: the streaming kernel (input read once)
+    const size_t w_lds = (size_t)(cin >> 5) * cout_pad * 64;
+    if (kh == 1 && kw == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && oy_mul == 1 && ox_mul == 1 && oy_off == 0 && ox_off == 0 &&
+        outH == Ho && outW == Wo && (cin >> 5) <= C1_MAX_CHUNKS && w_lds <= 128 * 1024 && cout_pad > 64 && M >= 65536 &&
+        g_patch_mode != 1) {
+        p.ws = nullptr;
+        p.splits = 1;
+        typedef void (*k1_t)(const ConvP);
+        static const k1_t k1[C1_MAX_CHUNKS] = {k_conv1x1_stream<1>, k_conv1x1_stream<2>, k_conv1x1_stream<3>, k_conv1x1_stream<4>,
+                                               k_conv1x1_stream<5>, k_conv1x1_stream<6>, k_conv1x1_stream<7>, k_conv1x1_stream<8>};
+        const k1_t k = k1[(cin >> 5) - 1];
+        if (w_lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w_lds) != hipSuccess)
+            return vsr::fail(VSR_E_LAUNCH, "conv2d/1x1: cannot reserve %zu bytes of LDS", w_lds);
+        const int per_cu = (int)((160 * 1024) / w_lds) < 2 ? 1 : 2;   // 512-thread workgroups resident per CU
+        const long long nblk = (M + 255) / 256;
+        const unsigned grid = (unsigned)(nblk < 256LL * per_cu ? nblk : 256LL * per_cu);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), w_lds, vsr::S(stream), p);
+        return vsr::launched("conv2d_nhwc_f16/1x1");
     }
     const unsigned gx = vsr::cdiv(M, BM);
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);  // widest tile the padded count fills

@@ -90,11 +90,14 @@ class HConv:
             out = torch.zeros((N, Ho * self.oy[0], Wo * self.ox[0], pad32(out_coff + self.cout)), dtype=torch.float16,
                               device=x.device) if pad32(out_coff + self.cout) != out_coff + self.cout else \
                 torch.empty((N, Ho * self.oy[0], Wo * self.ox[0], out_coff + self.cout), dtype=torch.float16, device=x.device)
+        tok = L.TIMER.start(f"conv N{N} {H}x{W} c{self.cin_pad}->{self.cout} k{self.kh}x{self.kw} s{self.stride}"
+                            f"{' ph' if self.oy[0] > 1 else ''}") if L.TIMER.enabled else None
         L.check(L.load().vsr_conv2d_nhwc_f16(
             L.dptr(x, torch.float16), in_ld, in_coff, L.dptr(self.w, torch.float16), L.optr(self.b), L.dptr(out, torch.float16),
             out.shape[3], out_coff, N, H, W, self.cin_pad, Ho, Wo, self.cout, self.cout_pad, self.kh, self.kw, self.stride,
             self.pad_y, self.pad_x, out.shape[1], out.shape[2], self.oy[0], self.oy[1], self.ox[0], self.ox[1], self.act,
             L.cf(self.slope), L.dptr(_splitk_ws(x.device)), ctypes.c_size_t(_WS_BYTES), L.stream()), "conv2d_nhwc_f16")
+        L.TIMER.stop(tok)
         return out
 
 
