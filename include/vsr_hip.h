@@ -166,6 +166,26 @@ int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* i
                        const void* in2, const float* w2, int ldw2, const float* bias, const float* cmap_nhwc, float slope,
                        void* out, int N, int P, vsr_stream_t stream);
 
+/* Up to three chained 32-channel 1x1 convolutions (+bias, +constant map, PReLU) in one pass over [N,P,32] fp16 tensors:
+ * stage s reads up to two tensors from memory (in/w/ldw, natural channel order) and, for s > 0, the previous stage's
+ * output (w_prev/ldw_prev) without a memory round trip; `out` may be NULL for an intermediate stage.  One launch for
+ * compress_out -> compress_in -> first uptran slice of the FeedbackBlock (SRProjectionModule.py:47-48,55-61,99). */
+typedef struct {
+    int nstages;
+    struct {
+        const void* in[2];
+        const float* w[2];
+        int ldw[2];
+        const float* w_prev;
+        int ldw_prev;
+        const float* bias;
+        const float* cmap_nhwc;
+        float slope;
+        void* out;
+    } stage[3];
+} vsr_chain1x1_t;
+int vsr_sr_chain1x1_f16(const vsr_chain1x1_t* chain, int N, int P, vsr_stream_t stream);
+
 /* vsr_sr_head_f32 writing NHWC fp16 [N,h,w,32]. */
 int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bias3, const float* w_in, const float* b_in,
                     float slope_in, int nmid, const float* w_feat, const float* b_feat, float slope_feat, void* out_nhwc,
@@ -214,6 +234,12 @@ int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int 
                          vsr_stream_t stream);
 int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,
                             void* out, int N, int H, int W, int C, vsr_stream_t stream);
+
+/* OSVOS head (reference networks/vgg_osvos.py forward: upscale ConvTranspose2d(16,16,k=2s,stride=s) of each side
+ * output -> centre crop -> cat -> fuse 1x1 to one logit) in one pass.  side[b] [N,hs[b],ws[b],ld] fp16 (channels 0..15
+ * live), weff[b] [2s][2s][16] fp16 = the branch's transposed-conv kernel with the fuse row folded in; out [N,h,w] fp32. */
+int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, int ld, const void* const* weff, const int* strides,
+                       int nbranch, float bias, float* out, int N, int h, int w, vsr_stream_t stream);
 
 /* Tuning hook for benchmarks: 0 heuristic choice between the gather kernel and the LDS-patch kernel (cout <= 16,
  * stride 1), 1 never the patch kernel, 2 whenever legal.  Returns the previous mode. */

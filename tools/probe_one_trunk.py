@@ -1,4 +1,4 @@
-"""Runs ONE guidance trunk a few times (target for rocprofv3 --kernel-trace --stats): usage probe_one_trunk.py flow|depth|depth1|vos [reps]"""
+"""Runs ONE guidance trunk a few times (target for rocprofv3 --kernel-trace --stats): usage probe_one_trunk.py flow|depth|depth1|vos|sr [reps]"""
 import os, sys
 os.environ.setdefault('MIOPEN_FIND_MODE', '2'); os.environ.setdefault('MIOPEN_LOG_LEVEL', '2')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,8 @@ h, w = 540, 960
 m = fill_module_(VSR().eval(), 0).cuda()
 fr = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (4, h, w, 3)).astype(np.float32)).cuda()
 fx, hx, ox = m._flow_exec.get(), m._depth_exec.get(), m._vos_exec.get()
-fn = {"flow": lambda: m.FlowModule.forward_pairs([(fr[0], fr[1]), (fr[1], fr[2])], fx),
+x8 = torch.cat([fr[:3].permute(0, 3, 1, 2)] * 2 + [fr[:2].permute(0, 3, 1, 2)], 0).contiguous()
+fn = {"sr": lambda: m.model(x8), "flow": lambda: m.FlowModule.forward_pairs([(fr[0], fr[1]), (fr[1], fr[2])], fx),
       "depth": lambda: hx(fr), "depth1": lambda: hx(fr[:1]), "vos": lambda: m.VOSModule(fr[0], fr[1], ox)}[which]
 fn(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

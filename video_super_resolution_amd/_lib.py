@@ -85,6 +85,17 @@ def cf(v: float) -> ctypes.c_float:
     return ctypes.c_float(float(v))
 
 
+class _ChainStage(ctypes.Structure):
+    _fields_ = [("inp", ctypes.c_void_p * 2), ("w", ctypes.c_void_p * 2), ("ldw", ctypes.c_int * 2), ("w_prev", ctypes.c_void_p),
+                ("ldw_prev", ctypes.c_int), ("bias", ctypes.c_void_p), ("cmap", ctypes.c_void_p), ("slope", ctypes.c_float),
+                ("out", ctypes.c_void_p)]
+
+
+class Chain1x1(ctypes.Structure):
+    """vsr_chain1x1_t of include/vsr_hip.h (all pointers as integers)."""
+    _fields_ = [("nstages", ctypes.c_int), ("stage", _ChainStage * 3)]
+
+
 class EventTimer:
     """HIP-event timing of selected kernel launches on the current stream (used by bench.py for the roofline
     leg).  Disabled (no events, no overhead) unless `enabled` is set."""

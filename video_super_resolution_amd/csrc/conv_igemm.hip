@@ -461,6 +461,55 @@ __global__ void __launch_bounds__(256) k_resize_add(const _Float16* __restrict__
     *reinterpret_cast<h8v*>(out + (((size_t)n * H + y) * W + x) * C + 8 * c8) = v;
 }
 
+// ---- OSVOS head (reference networks/vgg_osvos.py: side_prep -> upscale ConvTranspose2d(16,16,k=2s,stride=s) -> centre
+//      crop -> cat -> fuse 1x1 (64 -> 1)).  Nothing non-linear sits between the transposed convolutions and the fuse,
+//      so the fuse row is folded into each branch's kernel on the host (weff[b][ky][kx][ci] = sum_co fuse[16b+co] *
+//      up_b[ci][co][ky][kx]) and one pass writes the logit: per output pixel 4 branches x 2x2 source pixels x 16
+//      channels, fp32 accumulate.  Replaces 4 transposed convolutions on 16-channel full-resolution maps, 4 crops, a
+//      concat and a convolution.
+struct OsvosP {
+    const _Float16* side[4];   // [N, hs, ws, ld] fp16, channels 0..15 live
+    const _Float16* weff[4];   // [2s][2s][16] fp16
+    int hs[4], ws[4], stride[4], oy[4], ox[4];   // crop offsets: output (y,x) = upsampled (y + oy, x + ox)
+    int ld;
+    float bias;
+    float* out;                // [N, h, w] fp32
+    int N, h, w, nb;
+};
+__global__ void __launch_bounds__(256) k_osvos_fuse(const OsvosP p) {
+    const long long total = (long long)p.N * p.h * p.w;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % p.w);
+    const int y = (int)((i / p.w) % p.h);
+    const int n = (int)(i / ((long long)p.w * p.h));
+    float acc = p.bias;
+    for (int b = 0; b < p.nb; ++b) {
+        const int s = p.stride[b], Y = y + p.oy[b], X = x + p.ox[b];
+        const int iy1 = Y / s, ix1 = X / s;          // source pixel reached with tap (Y - iy1 s, X - ix1 s) in [0, s)
+        const int ky1 = Y - iy1 * s, kx1 = X - ix1 * s;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int iy = iy1 - dy, ky = ky1 + dy * s;
+            if (iy < 0 || iy >= p.hs[b]) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int ix = ix1 - dx, kx = kx1 + dx * s;
+                if (ix < 0 || ix >= p.ws[b]) continue;
+                const h8* sp = reinterpret_cast<const h8*>(p.side[b] + (((size_t)n * p.hs[b] + iy) * p.ws[b] + ix) * p.ld);
+                const h8* wp = reinterpret_cast<const h8*>(p.weff[b] + ((size_t)ky * 2 * s + kx) * 16);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const h8 a = sp[q], wv = wp[q];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)wv[e];
+                }
+            }
+        }
+    }
+    p.out[i] = acc;
+}
+
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal (tuning hook)
 
 extern "C" {
@@ -492,6 +541,26 @@ int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa,
     hipLaunchKernelGGL(k_resize_add, dim3(vsr::cdiv(total, 256)), dim3(256), 0, vsr::S(stream), (const _Float16*)a, a_ld, a_coff, Ha,
                        Wa, (const _Float16*)b_or_null, b_ld, b_coff, (_Float16*)out, N, H, W, C);
     return vsr::launched("resize_add");
+}
+
+int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, int ld, const void* const* weff, const int* strides,
+                       int nbranch, float bias, float* out, int N, int h, int w, vsr_stream_t stream) {
+    VSR_REQUIRE(side && hs && ws && weff && strides && out, "osvos_fuse: null pointer");
+    VSR_REQUIRE(nbranch >= 1 && nbranch <= 4 && N > 0 && h > 0 && w > 0 && ld >= 16 && (ld & 7) == 0, "osvos_fuse: bad arguments");
+    OsvosP p;
+    for (int b = 0; b < 4; ++b) {
+        p.side[b] = nullptr; p.weff[b] = nullptr; p.hs[b] = p.ws[b] = p.stride[b] = 1; p.oy[b] = p.ox[b] = 0;
+        if (b >= nbranch) continue;
+        VSR_REQUIRE(side[b] && weff[b] && strides[b] >= 1 && hs[b] > 0 && ws[b] > 0, "osvos_fuse: branch %d", b);
+        const int uh = (hs[b] + 1) * strides[b], uw = (ws[b] + 1) * strides[b];   // (hs - 1) s + 2 s
+        VSR_REQUIRE(uh >= h && uw >= w, "osvos_fuse: branch %d upsamples to %dx%d < %dx%d", b, uh, uw, h, w);
+        p.side[b] = (const _Float16*)side[b]; p.weff[b] = (const _Float16*)weff[b];
+        p.hs[b] = hs[b]; p.ws[b] = ws[b]; p.stride[b] = strides[b];
+        p.oy[b] = (uh - h) / 2; p.ox[b] = (uw - w) / 2;   // centre crop (vgg_osvos.py center_crop)
+    }
+    p.ld = ld; p.bias = bias; p.out = out; p.N = N; p.h = h; p.w = w; p.nb = nbranch;
+    hipLaunchKernelGGL(k_osvos_fuse, dim3(vsr::cdiv((long long)N * h * w, 256)), dim3(256), 0, vsr::S(stream), p);
+    return vsr::launched("osvos_fuse");
 }
 
 int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,

@@ -396,6 +396,104 @@ k_conv1x1_h(const _Float16* __restrict__ in0, const float* __restrict__ w0, int 
     }
 }
 
+// ---- chain of up to three 1x1 convolutions (32 out-channels each) in one pass over the pixels: stage s takes up to
+//      two NHWC fp16 tensors from memory and/or the previous stage's output, adds bias (+ an fp32 constant map), PReLU.
+//      The previous stage's accumulator tiles are PReLU'd, packed to fp16 and used in place as the B operand of the
+//      next MFMA (weight K order permuted to the accumulator's channel order), exactly what an fp16 round trip
+//      through HBM would hand over.  FeedbackBlock glue: compress_out -> compress_in -> first uptran slice
+//      (SRProjectionModule.py:47-48,55-61,99) is one launch instead of three; HBM-bound like k_conv1x1_h.
+struct ChainStage {
+    const _Float16* in[2];
+    const float* w[2];
+    int ld[2];
+    const float* w_prev;
+    int ld_prev;
+    const float* bias;
+    const float* cmap;
+    float slope;
+    _Float16* out;
+};
+struct ChainP {
+    int nstages;
+    ChainStage st[3];
+};
+
+__global__ void __launch_bounds__(256)
+k_chain1x1_h(const ChainP cp, size_t P, size_t total_px) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, g = lane >> 4;
+    h8 A[3][3][2];   // [stage][memory input 0,1 | previous stage][out-channel tile]
+    f4 bz[3][2];
+    h2 a2[3];
+    bool use_max[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const ChainStage& st = cp.st[s];
+        const bool on = s < cp.nstages;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                h8 a;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (_Float16)0.0f;
+                const float* wp = !on ? nullptr : (t < 2 ? (st.in[t] ? st.w[t] : nullptr) : st.w_prev);
+                if (wp) {
+                    const int ld = t < 2 ? st.ld[t] : st.ld_prev;
+                    const float* wr = wp + (size_t)(16 * mt + l15) * ld;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)   // memory inputs: k = 8g + e; chained input: the accumulator's channel order
+                        a[e] = (_Float16)wr[t < 2 ? 8 * g + e : (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
+                }
+                A[s][t][mt] = a;
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bz[s][mt][r] = on ? st.bias[16 * mt + 4 * g + r] : 0.0f;
+        const float sl = on ? st.slope : 1.0f;
+        a2[s] = h2{(_Float16)sl, (_Float16)sl};
+        use_max[s] = sl <= 1.0f;
+    }
+    const size_t ntiles = (total_px + 15) / 16;
+    const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    for (size_t tile = wave0; tile < ntiles; tile += nwaves) {
+        const size_t px = tile * 16 + l15;
+        const size_t pc = px < total_px ? px : total_px - 1;
+        h8 prev;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) prev[e] = (_Float16)0.0f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (s >= cp.nstages) break;
+            const ChainStage& st = cp.st[s];
+            f4 acc[2] = {bz[s][0], bz[s][1]};
+            if (st.cmap) {
+                const size_t pp = pc % P;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt] += *reinterpret_cast<const f4*>(st.cmap + pp * NF + 16 * mt + 4 * g);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (!st.in[t]) continue;
+                const h8 bfrag = *reinterpret_cast<const h8*>(st.in[t] + pc * NF + 8 * g);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma16(A[s][t][mt], bfrag, acc[mt]);
+            }
+            if (s > 0 && st.w_prev) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma16(A[s][2][mt], prev, acc[mt]);
+            }
+            prev = act_pack(acc[0], acc[1], a2[s], use_max[s]);   // channels {4g..4g+3, 16+4g..16+4g+3} of pixel l15
+            if (st.out && px < total_px) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<h4*>(st.out + px * NF + 4 * g) = h4{prev[0], prev[1], prev[2], prev[3]};
+                *reinterpret_cast<h4*>(st.out + px * NF + 16 + 4 * g) = h4{prev[4], prev[5], prev[6], prev[7]};
+            }
+        }
+    }
+}
+
 // ---- head on MFMA: sub_mean -> conv_in 3x3 (3->128) + PReLU -> feat_in 1x1 (128->32) + PReLU -> NHWC fp16
 //      (SRProjectionModule.py:135,137-138).  One wave = 16 pixels per trip.  First product: M = 128 mid channels
 //      (8 tiles), K = 27 taps padded to 32, B = the mean-shifted 3x3x3 neighbourhood gathered by the lanes (zero
@@ -991,6 +1089,34 @@ int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* i
                        (const _Float16*)in1, w1, ldw1, (const _Float16*)in2, w2, ldw2, bias, cmap_nhwc, slope,
                        (_Float16*)out, (size_t)P, total);
     return vsr::launched("sr_conv1x1_f16");
+}
+
+int vsr_sr_chain1x1_f16(const vsr_chain1x1_t* chain, int N, int P, vsr_stream_t stream) {
+    VSR_REQUIRE(chain && chain->nstages >= 1 && chain->nstages <= 3, "sr_chain1x1_f16: 1..3 stages");
+    VSR_REQUIRE(N > 0 && P > 0 && N <= 65535, "sr_chain1x1_f16: bad shape");
+    ChainP cp;
+    cp.nstages = chain->nstages;
+    for (int s = 0; s < 3; ++s) {
+        ChainStage& d = cp.st[s];
+        d = ChainStage{};
+        if (s >= chain->nstages) continue;
+        const auto& c = chain->stage[s];
+        VSR_REQUIRE(c.bias, "sr_chain1x1_f16: stage %d has no bias", s);
+        VSR_REQUIRE(c.in[0] || (s > 0 && c.w_prev), "sr_chain1x1_f16: stage %d has no input", s);
+        VSR_REQUIRE(s > 0 || !c.w_prev, "sr_chain1x1_f16: the first stage has no previous stage");
+        for (int t = 0; t < 2; ++t) {
+            VSR_REQUIRE((c.in[t] == nullptr) == (c.w[t] == nullptr), "sr_chain1x1_f16: stage %d input/weight mismatch", s);
+            d.in[t] = (const _Float16*)c.in[t]; d.w[t] = c.w[t]; d.ld[t] = c.ldw[t];
+        }
+        d.w_prev = c.w_prev; d.ld_prev = c.ldw_prev; d.bias = c.bias; d.cmap = c.cmap_nhwc; d.slope = c.slope;
+        d.out = (_Float16*)c.out;
+    }
+    VSR_REQUIRE(cp.st[chain->nstages - 1].out, "sr_chain1x1_f16: the last stage must have an output");
+    const size_t total = (size_t)N * P;
+    const size_t tiles = (total + 15) / 16;
+    const unsigned grid = (unsigned)(tiles / 4 + 1 < 2048 ? tiles / 4 + 1 : 2048);  // 4 waves per block, grid-stride
+    hipLaunchKernelGGL(k_chain1x1_h, dim3(grid), dim3(256), 0, vsr::S(stream), cp, (size_t)P, total);
+    return vsr::launched("sr_chain1x1_f16");
 }
 
 int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bias3, const float* w_in, const float* b_in,

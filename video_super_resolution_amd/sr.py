@@ -334,6 +334,40 @@ class SRProjectionModule(nn.Module):
         return out
 
     @staticmethod
+    def _chain(stages, N, P, keep):
+        """One launch of up to three chained 1x1 stages (csrc/sr_f16.hip k_chain1x1_h).  stages: dicts with `ins`
+        [(tensor [N,P,32] half, weight [32,ld] float, first column)], optional `prev` (weight, first column) for the
+        previous stage's output, `bias`, `slope`, optional `cmap`.  keep[s]: write stage s to memory.  -> outputs list
+        (None where not kept)."""
+        dev = stages[0]["bias"].device
+        c = L.Chain1x1()
+        c.nstages = len(stages)
+        outs, hold = [], []
+        for s, st in enumerate(stages):
+            d = c.stage[s]
+            for t, (ten, wm, col) in enumerate(st["ins"]):
+                ws = wm[:, col:col + _NF]
+                hold.append(ws)
+                d.inp[t] = L.dptr(ten, torch.float16).value
+                d.w[t] = ctypes_ptr(ws).value
+                d.ldw[t] = wm.shape[1]
+            if st.get("prev") is not None:
+                wm, col = st["prev"]
+                ws = wm[:, col:col + _NF]
+                hold.append(ws)
+                d.w_prev = ctypes_ptr(ws).value
+                d.ldw_prev = wm.shape[1]
+            d.bias = L.dptr(st["bias"]).value
+            if st.get("cmap") is not None:
+                d.cmap = L.dptr(st["cmap"]).value
+            d.slope = float(st["slope"])
+            o = torch.empty((N, P, _NF), dtype=torch.float16, device=dev) if keep[s] else None
+            d.out = L.dptr(o, torch.float16).value if o is not None else None
+            outs.append(o)
+        L.check(L.load().vsr_sr_chain1x1_f16(ctypes.byref(c), N, P, L.stream()), "sr_chain1x1_f16")
+        return outs
+
+    @staticmethod
     def _rows_per_segment(N, h, w):
         strips = -(-w // L.load().vsr_sr_utd_strip_width())
         wgs = strips * N
@@ -377,26 +411,44 @@ class SRProjectionModule(nn.Module):
         nchw = lambda t: t.view(N, h, w, _NF).permute(0, 3, 1, 2).float()
         if taps is not None:
             taps["feat_in"] = nchw(feat)
-        last = feat
+        if G < 3:
+            raise NotImplementedError("num_groups < 3 leaves compress_out without a live input")
+        want_lr0 = taps is not None
+        # stage descriptors of the 1x1 glue (SRProjectionModule.py:47-48 compress_in, :55-61 uptran slice, :99 compress_out)
+        ci = lambda last: dict(ins=[(feat, P["ci_w"], 0), (last, P["ci_w"], _NF)], bias=P["ci_b"], slope=P["ci_a"])
+        ut = lambda j, src=None: dict(ins=[] if src is None else [(src, P["ut_w"][j], _NF * (j + 1))],
+                                      prev=None if src is not None else (P["ut_w"][j], _NF * (j + 1)), bias=P["ut_b"][j], slope=P["ut_a"][j])
+        co = lambda live: dict(ins=[(live[k], P["co_w"], _NF * (k - 1)) for k in sorted(live) if k > 0], bias=P["co_b"], slope=P["co_a"],
+                               cmap=cmap_nhwc)
+        live = {}
         hid = None
         for step in range(self.num_steps):
-            live = {0: self._c1h([(feat, P["ci_w"], 0), (last, P["ci_w"], _NF)], P["ci_b"], P["ci_a"], N, hp)}
+            # one launch: (compress_out of the previous step ->) compress_in -> uptran slice of group 1
+            if step > 0 and len(co(live)["ins"]) > 2:   # more than 6 groups: compress_out on its own (three inputs)
+                hid = self._c1h(co(live)["ins"], P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
+                outs = [hid] + self._chain([ci(hid), ut(0)], N, hp, keep=[want_lr0, True])
+            elif step > 0:
+                ci_chained = dict(ins=[(feat, P["ci_w"], 0)], prev=(P["ci_w"], _NF), bias=P["ci_b"], slope=P["ci_a"])
+                outs = self._chain([co(live), ci_chained, ut(0)], N, hp, keep=[taps is not None, want_lr0, True])
+            else:
+                outs = self._chain([ci(feat), ut(0)], N, hp, keep=[want_lr0, True])
+            if taps is not None and step > 0:
+                taps[f"block{step - 1}"] = nchw(outs[0])
+            live = {0: outs[-2]} if want_lr0 else {}
+            a = outs[-1]
             j = 0
             while j + 3 <= G:
-                a = self._c1h([(live[j], P["ut_w"][j], _NF * (j + 1))], P["ut_b"][j], P["ut_a"][j], N, hp)
-                # k_utd (every wave runs both phases) measured 7 % faster than the producer/consumer variant k_utd2
-                # (1.219 vs 1.306 ms, interleaved on one device): the deconv -> PReLU -> 1x1 -> PReLU chain is the long
-                # pole and concentrating it in four waves lengthens it
+                if j > 0:
+                    a = self._chain([ut(j, live[j])], N, hp, keep=[True])[0]
                 live[j + 3] = self._utd(a, P["utd"][j], N, h, w).view(N, hp, _NF)
                 j += 3
-            ins = [(live[k], P["co_w"], _NF * (k - 1)) for k in sorted(live) if k > 0]
-            hid = self._c1h(ins, P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
-            last = hid
-            if taps is not None:
-                taps[f"block{step}"] = nchw(hid)
-                if step == self.num_steps - 1:
-                    for k, v in live.items():
-                        taps[f"lr{k}"] = nchw(v)
+            if taps is not None and step == self.num_steps - 1:
+                for k, v in live.items():
+                    taps[f"lr{k}"] = nchw(v)
+        hid = self._chain([co(live)], N, hp, keep=[True])[0] if len(co(live)["ins"]) <= 2 else \
+            self._c1h(co(live)["ins"], P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
+        if taps is not None:
+            taps[f"block{self.num_steps - 1}"] = nchw(hid)
         prefc = torch.empty((N, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev)
         tok = L.TIMER.start("sr_tail_f16")
         L.check(lib.vsr_sr_tail_f16(L.dptr(hid, torch.float16), L.dptr(P["utd_out"], torch.uint8), L.dptr(P["cv_frags"], torch.float16),

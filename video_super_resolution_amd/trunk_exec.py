@@ -11,10 +11,13 @@ channel slices of the destination buffer.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib as L
 from . import ops
 from .depth import HOURGLASS
 from .igemm import ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HDeconv4s2, pad32, pool2x2, resize_add, to_nhwc_half
@@ -361,13 +364,18 @@ class OSVOSExec:
                     items.append(HConv(m.weight, m.bias, pad=1, act=ACT_RELU, cin_pad=32 if m.in_channels == 3 else None))
             self.stages.append(items)
         self.side = [HConv(m.weight, m.bias, pad=1, act=ACT_NONE) for m in net.side_prep]
-        self.up_w = [m.weight.detach().half() for m in net.upscale]
+        # upscale (ConvTranspose2d 16->16, k = 2s, stride s) -> centre crop -> cat -> fuse 1x1 is linear: fold the fuse
+        # row into each branch's transposed-conv kernel, weff[ky][kx][ci] (csrc/conv_igemm.hip k_osvos_fuse)
+        fw = net.fuse.weight.detach().float().view(-1)
         self.up_s = [m.stride[0] for m in net.upscale]
-        self.fuse_w, self.fuse_b = net.fuse.weight.detach().half(), net.fuse.bias.detach().half()
+        self.weff = [torch.einsum("iokl,o->kli", m.weight.detach().float(), fw[16 * b:16 * b + 16]).contiguous().half()
+                     for b, m in enumerate(net.upscale)]
+        self.fuse_b = float(net.fuse.bias.detach())
 
     @torch.no_grad()
     def __call__(self, x_nchw):
         """[2,3,h,w] mean-subtracted frames -> fused logit [2,1,h,w] float32."""
+        N = x_nchw.shape[0]
         hh, ww = x_nchw.shape[-2:]
         x = to_nhwc_half(x_nchw)
         sides = []
@@ -375,11 +383,15 @@ class OSVOSExec:
             for it in items:
                 x = _nhwc(F.max_pool2d(_nchw(x), 2, 2, ceil_mode=True)) if it == "M" else it(x)
             if si > 0:
-                s = self.side[si - 1](x)  # [2,h',w',32] (16 live)
-                up = F.conv_transpose2d(s[..., :16].permute(0, 3, 1, 2), self.up_w[si - 1], None, stride=self.up_s[si - 1])
-                dh, dw = up.shape[2] - hh, up.shape[3] - ww
-                sides.append(up[:, :, dh // 2: up.shape[2] - (dh - dh // 2), dw // 2: up.shape[3] - (dw - dw // 2)])
-        return F.conv2d(torch.cat(sides, 1), self.fuse_w, self.fuse_b).float()
+                sides.append(self.side[si - 1](x))  # [N,h',w',32] (16 live)
+        nb = len(sides)
+        out = torch.empty((N, 1, hh, ww), dtype=torch.float32, device=x.device)
+        vp = ctypes.c_void_p * nb
+        ip = ctypes.c_int * nb
+        L.check(L.load().vsr_osvos_fuse_f16(vp(*[t.data_ptr() for t in sides]), ip(*[t.shape[1] for t in sides]),
+                                            ip(*[t.shape[2] for t in sides]), sides[0].shape[3], vp(*[t.data_ptr() for t in self.weff]),
+                                            ip(*self.up_s), nb, L.cf(self.fuse_b), L.dptr(out), N, hh, ww, L.stream()), "osvos_fuse")
+        return out
 
 
 class TrunkExecCache:
