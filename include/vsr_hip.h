@@ -235,6 +235,20 @@ int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int 
 int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,
                             void* out, int N, int H, int W, int C, vsr_stream_t stream);
 
+/* ConvTranspose2d(k=4, s=2, p=1) (+bias +activation) as its four 2x2-tap phase convolutions in ONE launch (grid.z walks
+ * phase and split-K slice).  w_packed4[py*2+px]: the phase's taps packed like vsr_conv2d_nhwc_f16 weights (kernel rows
+ * (3,1) for py = 0, (2,0) for py = 1; same along x).  in [N,H,W,in_ld] -> out [N,2H,2W,out_ld], slice [out_coff,+cout). */
+int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* const* w_packed4, const float* bias, void* out,
+                           int out_ld, int out_coff, int N, int H, int W, int cin, int cout, int cout_pad, int act, float slope,
+                           void* splitk_ws, size_t splitk_ws_bytes, vsr_stream_t stream);
+
+/* First convolution of a trunk on an image with <= 4 channels: in4 [N,H,W,4] fp16, w_packed [kh][cout_pad][32] fp16 with
+ * k = 4 kx + c (zero for kx >= kw, c >= cin): one K chunk per kernel row instead of one per tap (hourglass 7x7 stem:
+ * 7 chunks instead of 49 zero-padded ones).  kw <= 8.  Otherwise as vsr_conv2d_nhwc_f16. */
+int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias, void* out, int out_ld, int out_coff, int N,
+                        int H, int W, int Ho, int Wo, int cout, int cout_pad, int kh, int kw, int stride, int pad_y, int pad_x,
+                        int act, float slope, vsr_stream_t stream);
+
 /* OSVOS head (reference networks/vgg_osvos.py forward: upscale ConvTranspose2d(16,16,k=2s,stride=s) of each side
  * output -> centre crop -> cat -> fuse 1x1 to one logit) in one pass.  side[b] [N,hs[b],ws[b],ld] fp16 (channels 0..15
  * live), weff[b] [2s][2s][16] fp16 = the branch's transposed-conv kernel with the fuse row folded in; out [N,h,w] fp32. */

@@ -52,6 +52,23 @@ def test_conv_matches_torch(case):
         assert float(out[..., cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", [(2, 3, 37, 45, 128, 7, 1, 3, igemm.ACT_RELU), (4, 3, 64, 96, 64, 7, 2, 3, igemm.ACT_LEAKY),
+                                  (1, 3, 33, 29, 64, 3, 1, 1, igemm.ACT_RELU), (1, 4, 20, 20, 16, 5, 1, 2, igemm.ACT_NONE)])
+def test_stem_conv_matches_torch(case):
+    """Dense-K first convolution ([N,H,W,4] input, one K chunk per kernel row) of the hourglass / FlowNetC / VGG."""
+    N, cin, H, W, cout, k, s, p, act = case
+    rs = np.random.RandomState(cout + k)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.conv2d(x.float(), w, b, stride=s, padding=p)
+    ref = F.relu(ref) if act == igemm.ACT_RELU else (F.leaky_relu(ref, 0.1) if act == igemm.ACT_LEAKY else ref)
+    out = igemm.HConvStem(w, b, stride=s, pad=p, act=act)(igemm.to_nhwc_half(x, 4))
+    got = igemm.to_nchw_float(out, cout)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
 def test_conv_writes_into_channel_slices():
     rs = np.random.RandomState(0)
     x = torch.from_numpy(rs.randn(1, 64, 10, 12).astype(np.float32)).cuda().half()

@@ -27,7 +27,11 @@ print(f"{which}: {e0.elapsed_time(e1):.2f} ms wall with events, {tot:.2f} ms ins
 def flops(name, n):
     import re
     mm = re.match(r"conv N(\d+) (\d+)x(\d+) c(\d+)->(\d+) k(\d+)x(\d+) s(\d+)", name)
-    N, H, W, ci, co, kh, kw, st = map(int, mm.groups())
-    return 2.0 * N * (H // st) * (W // st) * ci * co * kh * kw
+    if mm:
+        N, H, W, ci, co, kh, kw, st = map(int, mm.groups())
+        return 2.0 * N * (H // st) * (W // st) * ci * co * kh * kw
+    mm = re.match(r"deconv4s2 N(\d+) (\d+)x(\d+) c(\d+)->(\d+)", name)
+    N, H, W, ci, co = map(int, mm.groups())
+    return 2.0 * N * H * W * ci * co * 16
 for name, (n, ms) in sorted(S.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:top]:
     print(f"{name:46s} x{n:3d}  {ms*1e3:8.1f} us each  {n*ms:7.3f} ms  {flops(name, n) / (ms * 1e-3) / 1e12:7.1f} TFLOP/s")

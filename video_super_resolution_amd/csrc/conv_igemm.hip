@@ -33,13 +33,21 @@ struct ConvP {
     int outH, outW, oy_mul, oy_off, ox_mul, ox_off;
     int act;
     float slope;
-    float* ws;      // split-K partial sums [splits][M][cout_pad] fp32, or null
+    float* ws;      // split-K partial sums [splits][phases][M][cout_pad] fp32, or null
     int splits;
+    // the four phases of a k4 s2 transposed convolution in ONE launch (blockIdx.z = split * 4 + phase): per-phase packed
+    // weights, padding and output offset; nphase <= 1: the scalar fields above
+    int nphase;
+    const _Float16* wpk_ph[4];
+    int pad_y_ph[4], pad_x_ph[4], oy_off_ph[4], ox_off_ph[4];
 };
 
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
-template <int BN>
+// STEM: the input has 4 channels per pixel ([N,H,W,4] fp16, 3 live) and one K chunk is a whole kernel ROW: k = 4 kx + c
+// for kx < 8 (packed weights [ky][cout_pad][32], zero where kx >= kw or c >= cin).  A 7x7 stem on an RGB image is 7 K
+// chunks instead of 49 chunks that are 29/32 zero padding.
+template <int BN, bool STEM = false>
 __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     constexpr int MT = BN / 16;                 // out-channel tiles per wave
     constexpr int A_HALF = BN * 64;             // weight tile of one (tap, chunk)
@@ -55,13 +63,18 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const long long m0 = (long long)blockIdx.x * BM;
     const int co0 = blockIdx.y * BN;
-    const int nchunk = p.cin >> 5;
-    const int npair = p.kh * p.kw * nchunk;     // (tap, chunk) pairs
+    const int nchunk = STEM ? 1 : p.cin >> 5;
+    const int npair = STEM ? p.kh : p.kh * p.kw * nchunk;     // (tap, chunk) pairs; STEM: one per kernel row
     const int nk_all = (npair + 1) >> 1;        // K steps of two pairs (the odd tail pair is zero-filled)
     // split-K (small pixel counts with long K, e.g. the 1/32 and 1/64-resolution FlowNet layers): blockIdx.z owns a
     // contiguous range of K steps and writes an fp32 partial tile; k_splitk_finish sums them in a fixed order
+    const int ph = p.nphase > 1 ? (int)(blockIdx.z & 3) : 0;
+    const int zsplit = p.nphase > 1 ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
+    const _Float16* const wpk = p.nphase > 1 ? p.wpk_ph[ph] : p.wpk;
+    const int pad_y = p.nphase > 1 ? p.pad_y_ph[ph] : p.pad_y, pad_x = p.nphase > 1 ? p.pad_x_ph[ph] : p.pad_x;
+    const int oy_off = p.nphase > 1 ? p.oy_off_ph[ph] : p.oy_off, ox_off = p.nphase > 1 ? p.ox_off_ph[ph] : p.ox_off;
     const int ks_per = (nk_all + p.splits - 1) / p.splits;
-    const int ks0 = blockIdx.z * ks_per;
+    const int ks0 = zsplit * ks_per;
     const int nk = min(nk_all, ks0 + ks_per);
 
     // ---- the two pixel pieces this thread stages per pair: piece q = tid + 256 r -> row q>>2, chunk q&3
@@ -77,8 +90,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
         const int rem = (int)(mm - (long long)n * p.Ho * p.Wo);
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         pn[r] = n;
-        piy0[r] = oy * p.stride - p.pad_y;
-        pix0[r] = ox * p.stride - p.pad_x;
+        piy0[r] = oy * p.stride - pad_y;
+        pix0[r] = ox * p.stride - pad_x;
     }
     const int bchunk = tid & 3;
     const int brow[2] = {tid >> 2, (tid + 256) >> 2};
@@ -91,17 +104,24 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
             const bool live = pr < npair;
             const int prc = live ? pr : 0;
             const int tap = prc / nchunk, ch = prc - tap * nchunk;
-            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            const int ky = STEM ? tap : tap / p.kw, kx = STEM ? 2 * bchunk : tap - ky * p.kw;
             ra[hf] = make_uint4(0, 0, 0, 0);
             if (live && tid < A_PIECES)  // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0.. contiguous
-                ra[hf] = *reinterpret_cast<const uint4*>(p.wpk + ((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8);
+                ra[hf] = *reinterpret_cast<const uint4*>(wpk + ((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int iy = piy0[r] + ky, ix = pix0[r] + kx;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (live && pok[r] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                if (STEM) {   // this 16-byte piece = taps kx, kx+1 of kernel row ky: two 8-byte pixels
+                    if (live && pok[r] && iy >= 0 && iy < p.H) {
+                        const _Float16* rowp = p.in + ((size_t)pn[r] * p.H + iy) * p.W * 4;
+                        if (ix >= 0 && ix < p.W) { const uint2 t = *reinterpret_cast<const uint2*>(rowp + (size_t)ix * 4); v.x = t.x; v.y = t.y; }
+                        if (ix + 1 >= 0 && ix + 1 < p.W) { const uint2 t = *reinterpret_cast<const uint2*>(rowp + (size_t)(ix + 1) * 4); v.z = t.x; v.w = t.y; }
+                    }
+                } else if (live && pok[r] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
                     v = *reinterpret_cast<const uint4*>(p.in + (((size_t)pn[r] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff +
                                                        ch * 32 + bchunk * 8);
+                }
                 rb[hf][r] = v;
             }
         }
@@ -152,7 +172,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
         const long long m = m0 + 32 * wv + 16 * nt + l15;
         if (m >= M) continue;
         if (p.splits > 1) {
-            float* wsp = p.ws + ((size_t)blockIdx.z * M + m) * p.cout_pad + co0;
+            float* wsp = p.ws + (((size_t)zsplit * (p.nphase > 1 ? 4 : 1) + ph) * M + m) * p.cout_pad + co0;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4*>(wsp + 16 * mt + 4 * g) = acc[mt][nt];
             continue;
@@ -160,7 +180,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
         const int n = (int)(m / ((long long)p.Ho * p.Wo));
         const int rem = (int)(m - (long long)n * p.Ho * p.Wo);
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
+        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + oy_off) * p.outW + ox * p.ox_mul + ox_off) * p.out_ld +
                         p.out_coff;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -393,12 +413,14 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const ConvP p) {
     const long long m = idx / c4n;
     const int c = (int)(idx - m * c4n) * 4;
     if (c >= p.cout) return;
+    const int ph = blockIdx.y, nph = p.nphase > 1 ? 4 : 1;
+    const int oy_off = p.nphase > 1 ? p.oy_off_ph[ph] : p.oy_off, ox_off = p.nphase > 1 ? p.ox_off_ph[ph] : p.ox_off;
     f4 s = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int z = 0; z < p.splits; ++z) s += *reinterpret_cast<const f4*>(p.ws + ((size_t)z * M + m) * p.cout_pad + c);
+    for (int z = 0; z < p.splits; ++z) s += *reinterpret_cast<const f4*>(p.ws + (((size_t)z * nph + ph) * M + m) * p.cout_pad + c);
     const int n = (int)(m / ((long long)p.Ho * p.Wo));
     const int rem = (int)(m - (long long)n * p.Ho * p.Wo);
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
+    _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + oy_off) * p.outW + ox * p.ox_mul + ox_off) * p.out_ld +
                     p.out_coff;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -563,6 +585,79 @@ int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, in
     return vsr::launched("osvos_fuse");
 }
 
+int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* const* w_packed4, const float* bias, void* out,
+                           int out_ld, int out_coff, int N, int H, int W, int cin, int cout, int cout_pad, int act, float slope,
+                           void* splitk_ws, size_t splitk_ws_bytes, vsr_stream_t stream) {
+    VSR_REQUIRE(in && w_packed4 && out, "deconv4s2: null pointer");
+    VSR_REQUIRE(N > 0 && H > 0 && W > 0 && cout > 0 && cin > 0 && (cin & 31) == 0, "deconv4s2: bad shape");
+    VSR_REQUIRE((in_ld & 7) == 0 && (in_coff & 7) == 0 && in_coff + cin <= in_ld, "deconv4s2: input slice");
+    VSR_REQUIRE(out_coff >= 0 && out_coff + cout <= out_ld && cout_pad >= cout && (cout_pad & 15) == 0, "deconv4s2: output slice");
+    VSR_REQUIRE(act >= 0 && act <= 2, "deconv4s2: activation %d", act);
+    ConvP p;
+    p.in = (const _Float16*)in; p.wpk = nullptr; p.bias = bias; p.out = (_Float16*)out;
+    p.in_ld = in_ld; p.in_coff = in_coff; p.out_ld = out_ld; p.out_coff = out_coff;
+    p.N = N; p.H = H; p.W = W; p.cin = cin; p.Ho = H; p.Wo = W; p.cout = cout; p.cout_pad = cout_pad;
+    p.kh = 2; p.kw = 2; p.stride = 1; p.pad_y = 0; p.pad_x = 0;
+    p.outH = 2 * H; p.outW = 2 * W; p.oy_mul = 2; p.oy_off = 0; p.ox_mul = 2; p.ox_off = 0;
+    p.act = act; p.slope = slope;
+    p.nphase = 4;
+    for (int ph = 0; ph < 4; ++ph) {   // phase (py, px): output (2y + py, 2x + px); py = 0 gathers input rows y-1, y (HDeconv4s2)
+        const int py = ph >> 1, px = ph & 1;
+        VSR_REQUIRE(w_packed4[ph], "deconv4s2: phase %d weights", ph);
+        p.wpk_ph[ph] = (const _Float16*)w_packed4[ph];
+        p.pad_y_ph[ph] = py == 0 ? 1 : 0; p.pad_x_ph[ph] = px == 0 ? 1 : 0;
+        p.oy_off_ph[ph] = py; p.ox_off_ph[ph] = px;
+    }
+    const long long M = (long long)N * H * W;
+    const unsigned gx = vsr::cdiv(M, BM);
+    const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
+    const unsigned gy = cout_pad / bn;
+    const int nk_all = (4 * (cin >> 5) + 1) >> 1;
+    int splits = 1;
+    if (splitk_ws && (long long)gx * gy * 4 < 128 && nk_all >= 8) {
+        splits = (int)(256 / ((long long)gx * gy * 4));
+        if (splits > nk_all / 4) splits = nk_all / 4;
+        if (splits > 32) splits = 32;
+        while (splits > 1 && (size_t)splits * 4 * M * cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
+        if (splits < 1) splits = 1;
+    }
+    p.ws = splits > 1 ? (float*)splitk_ws : nullptr;
+    p.splits = splits;
+    const dim3 grid(gx, gy, 4 * splits);
+    if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, vsr::S(stream), p);
+    else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, vsr::S(stream), p);
+    else hipLaunchKernelGGL(k_conv_igemm<16>, grid, dim3(256), 0, vsr::S(stream), p);
+    if (splits > 1) {
+        int rc = vsr::launched("deconv4s2_nhwc_f16");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_splitk_finish, dim3(vsr::cdiv(M * (cout_pad >> 2), 256), 4), dim3(256), 0, vsr::S(stream), p);
+    }
+    return vsr::launched("deconv4s2_nhwc_f16");
+}
+
+int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias, void* out, int out_ld, int out_coff, int N,
+                        int H, int W, int Ho, int Wo, int cout, int cout_pad, int kh, int kw, int stride, int pad_y, int pad_x,
+                        int act, float slope, vsr_stream_t stream) {
+    VSR_REQUIRE(in4 && w_packed && out, "conv2d_stem: null pointer");
+    VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && cout > 0 && kh > 0 && kw > 0 && kw <= 8 && stride > 0, "conv2d_stem: bad shape");
+    VSR_REQUIRE(out_coff >= 0 && out_coff + cout <= out_ld && cout_pad >= cout && (cout_pad & 15) == 0, "conv2d_stem: output slice");
+    VSR_REQUIRE(act >= 0 && act <= 2, "conv2d_stem: activation %d", act);
+    ConvP p;
+    p.in = (const _Float16*)in4; p.wpk = (const _Float16*)w_packed; p.bias = bias; p.out = (_Float16*)out;
+    p.in_ld = 4; p.in_coff = 0; p.out_ld = out_ld; p.out_coff = out_coff;
+    p.N = N; p.H = H; p.W = W; p.cin = 32; p.Ho = Ho; p.Wo = Wo; p.cout = cout; p.cout_pad = cout_pad;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.outH = Ho; p.outW = Wo; p.oy_mul = 1; p.oy_off = 0; p.ox_mul = 1; p.ox_off = 0;
+    p.act = act; p.slope = slope; p.ws = nullptr; p.splits = 1; p.nphase = 0;
+    const long long M = (long long)N * Ho * Wo;
+    const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
+    const dim3 grid(vsr::cdiv(M, BM), cout_pad / bn, 1);
+    if (bn == 64) hipLaunchKernelGGL((k_conv_igemm<64, true>), grid, dim3(256), 0, vsr::S(stream), p);
+    else if (bn == 32) hipLaunchKernelGGL((k_conv_igemm<32, true>), grid, dim3(256), 0, vsr::S(stream), p);
+    else hipLaunchKernelGGL((k_conv_igemm<16, true>), grid, dim3(256), 0, vsr::S(stream), p);
+    return vsr::launched("conv2d_stem_f16");
+}
+
 int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
                         int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
                         int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
@@ -583,7 +678,7 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
     p.N = N; p.H = H; p.W = W; p.cin = cin; p.Ho = Ho; p.Wo = Wo; p.cout = cout; p.cout_pad = cout_pad;
     p.kh = kh; p.kw = kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
     p.outH = outH; p.outW = outW; p.oy_mul = oy_mul; p.oy_off = oy_off; p.ox_mul = ox_mul; p.ox_off = ox_off;
-    p.act = act; p.slope = slope;
+    p.act = act; p.slope = slope; p.nphase = 0;
     const long long M = (long long)N * Ho * Wo;
     // stride-1 layers with a real spatial kernel and enough pixels: the 2-D LDS patch kernel (stages the input once per
     // 32-channel chunk instead of gathering it kh*kw times from L2).  Measured on MI355X (tools/conv_microbench.py).

@@ -101,6 +101,44 @@ class HConv:
         return out
 
 
+class HConvStem:
+    """First convolution of a trunk on an image with <= 4 channels: input [N,H,W,4] float16 (`to_nhwc_half(x, 4)`), one
+    MFMA K chunk per kernel row (k = 4 kx + c) instead of one zero-padded 32-channel chunk per tap."""
+
+    def __init__(self, weight, bias, stride=1, pad=0, act=ACT_NONE, slope=0.1):
+        weight = weight.detach().float()
+        cout, cin, kh, kw = weight.shape
+        if cin > 4 or kw > 8:
+            raise ValueError("HConvStem: at most 4 input channels and 8 kernel columns")
+        dev = weight.device
+        self.cout, self.kh, self.kw, self.stride, self.pad = cout, kh, kw, stride, pad
+        self.act, self.slope = act, slope
+        self.cout_pad = _cout_pad(cout)
+        wp = torch.zeros((kh, self.cout_pad, 8, 4), dtype=torch.float32, device=dev)   # [ky][co][kx][c]
+        wp[:, :cout, :kw, :cin] = weight.permute(2, 0, 3, 1)
+        self.w = wp.view(kh, self.cout_pad, 32).to(torch.float16).contiguous()
+        self.b = None
+        if bias is not None:
+            self.b = torch.zeros(self.cout_pad, dtype=torch.float32, device=dev)
+            self.b[:cout] = bias.detach().float()
+
+    def __call__(self, x4, out=None, out_coff=0):
+        N, H, W, c4 = x4.shape
+        assert c4 == 4 and x4.dtype == torch.float16
+        Ho = (H + 2 * self.pad - self.kh) // self.stride + 1
+        Wo = (W + 2 * self.pad - self.kw) // self.stride + 1
+        if out is None:
+            cp = pad32(out_coff + self.cout)
+            out = (torch.zeros if cp != out_coff + self.cout else torch.empty)((N, Ho, Wo, cp), dtype=torch.float16, device=x4.device)
+        tok = L.TIMER.start(f"conv N{N} {H}x{W} c4->{self.cout} k{self.kh}x{self.kw} s{self.stride} stem") if L.TIMER.enabled else None
+        L.check(L.load().vsr_conv2d_stem_f16(L.dptr(x4, torch.float16), L.dptr(self.w, torch.float16), L.optr(self.b),
+                                             L.dptr(out, torch.float16), out.shape[3], out_coff, N, H, W, Ho, Wo, self.cout,
+                                             self.cout_pad, self.kh, self.kw, self.stride, self.pad, self.pad, self.act,
+                                             L.cf(self.slope), L.stream()), "conv2d_stem_f16")
+        L.TIMER.stop(tok)
+        return out
+
+
 class HDeconv4s2:
     """ConvTranspose2d(k=4, s=2, p=1) (+bias +activation) as four 2x2-tap phase convolutions.
     weight [Cin,Cout,4,4].  Output row oy = 2y+py gathers input rows y+a+base(py), a in {0,1}:
@@ -120,12 +158,18 @@ class HDeconv4s2:
                 self.phases.append(c)
 
     def __call__(self, x, out=None, out_coff=0, in_coff=0):
-        N, H, W, _ = x.shape
+        N, H, W, in_ld = x.shape
         if out is None:
             cp = pad32(out_coff + self.cout)
             out = torch.zeros((N, 2 * H, 2 * W, cp), dtype=torch.float16, device=x.device)
-        for c in self.phases:
-            c(x, out=out, out_coff=out_coff, in_coff=in_coff, out_hw=(H, W))
+        c0 = self.phases[0]
+        tok = L.TIMER.start(f"deconv4s2 N{N} {H}x{W} c{c0.cin_pad}->{self.cout}") if L.TIMER.enabled else None
+        wp = (ctypes.c_void_p * 4)(*[c.w.data_ptr() for c in self.phases])
+        L.check(L.load().vsr_deconv4s2_nhwc_f16(
+            L.dptr(x, torch.float16), in_ld, in_coff, wp, L.optr(c0.b), L.dptr(out, torch.float16), out.shape[3], out_coff, N, H, W,
+            c0.cin_pad, self.cout, c0.cout_pad, c0.act, L.cf(c0.slope), L.dptr(_splitk_ws(x.device)), ctypes.c_size_t(_WS_BYTES),
+            L.stream()), "deconv4s2_nhwc_f16")
+        L.TIMER.stop(tok)
         return out
 
 

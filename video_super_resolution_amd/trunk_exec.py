@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from . import _lib as L
 from . import ops
 from .depth import HOURGLASS
-from .igemm import ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HDeconv4s2, pad32, pool2x2, resize_add, to_nhwc_half
+from .igemm import ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvStem, HDeconv4s2, pad32, pool2x2, resize_add, to_nhwc_half
 
 
 def _fold(conv: nn.Conv2d, bn):
@@ -111,7 +111,10 @@ class HourglassExec:
                     j = i + (2 if bn is not None else 1)
                     relu = j < len(children) and isinstance(children[j], nn.ReLU)
                     w, b = _fold(children[i], bn)
-                    items.append(("conv", HConv(w, b, pad=ch[4], act=ACT_RELU if relu else ACT_NONE), ch[2]))
+                    if w.shape[1] <= 4 and w.shape[3] <= 8:   # the 7x7 stem on the RGB frame: dense-K launch on [k,h,w,4]
+                        items.append(("stem", HConvStem(w, b, pad=ch[4], act=ACT_RELU if relu else ACT_NONE), ch[2]))
+                    else:
+                        items.append(("conv", HConv(w, b, pad=ch[4], act=ACT_RELU if relu else ACT_NONE), ch[2]))
                     i = j + (1 if relu else 0)
                     continue
                 items.append(self._build(ch, children[i]))
@@ -133,6 +136,8 @@ class HourglassExec:
         if tag == "conv":
             out = node[1](x, in_coff=coff)
             return out, 0, node[2]
+        if tag == "stem":
+            return node[1](x), 0, node[2]
         if tag == "I":
             buf, m, ctot = node[1](x, coff)
             return buf, m, ctot
@@ -152,7 +157,8 @@ class HourglassExec:
     def __call__(self, frames_nhwc3: torch.Tensor) -> torch.Tensor:
         """[k,h,w,3] float frames -> [k,1,h,w] float depth predictions."""
         k, h, w, _ = frames_nhwc3.shape
-        x = torch.zeros((k, h, w, 32), dtype=torch.float16, device=frames_nhwc3.device)
+        stem_first = self.prog[0] == "S" and isinstance(self.prog[1][0], tuple) and self.prog[1][0][0] == "stem"
+        x = torch.zeros((k, h, w, 4 if stem_first else 32), dtype=torch.float16, device=frames_nhwc3.device)
         x[..., :3] = frames_nhwc3
         out, coff, c = self._run(self.prog, x, 0, 32)
         return out[..., coff:coff + 1].permute(0, 3, 1, 2).float()
@@ -228,7 +234,8 @@ class _FlowNetSExec:
 
 class _FlowNetCExec:
     def __init__(self, net):
-        self.conv1 = _cv(net.conv1, cin_pad=32)
+        c1 = net.conv1[0] if isinstance(net.conv1, nn.Sequential) else net.conv1
+        self.conv1 = HConvStem(c1.weight, c1.bias, stride=c1.stride[0], pad=(c1.kernel_size[0] - 1) // 2, act=ACT_LEAKY, slope=0.1)
         self.conv2, self.conv3 = _cv(net.conv2), _cv(net.conv3)
         self.redir = _cv(net.conv_redir)
         self.conv3_1 = _cv(net.conv3_1, cin_pad=pad32(473))
@@ -240,7 +247,7 @@ class _FlowNetCExec:
         """x6: [B,H,W,32] with the two normalised frames in channels 0-2 and 3-5."""
         B, H, W, _ = x6.shape
         dev = x6.device
-        both = torch.zeros((2 * B, H, W, 32), dtype=torch.float16, device=dev)
+        both = torch.zeros((2 * B, H, W, 4), dtype=torch.float16, device=dev)   # 4-channel pixels for the dense-K stem
         both[:B, ..., :3] = x6[..., 0:3]
         both[B:, ..., :3] = x6[..., 3:6]
         c2 = self.conv2(self.conv1(both))           # [2B,H/4,W/4,128]
@@ -361,7 +368,8 @@ class OSVOSExec:
                 if isinstance(m, nn.MaxPool2d):
                     items.append("M")
                 elif isinstance(m, nn.Conv2d):
-                    items.append(HConv(m.weight, m.bias, pad=1, act=ACT_RELU, cin_pad=32 if m.in_channels == 3 else None))
+                    items.append(HConvStem(m.weight, m.bias, pad=1, act=ACT_RELU) if m.in_channels == 3 else
+                                 HConv(m.weight, m.bias, pad=1, act=ACT_RELU))
             self.stages.append(items)
         self.side = [HConv(m.weight, m.bias, pad=1, act=ACT_NONE) for m in net.side_prep]
         # upscale (ConvTranspose2d 16->16, k = 2s, stride s) -> centre crop -> cat -> fuse 1x1 is linear: fold the fuse
@@ -377,7 +385,7 @@ class OSVOSExec:
         """[2,3,h,w] mean-subtracted frames -> fused logit [2,1,h,w] float32."""
         N = x_nchw.shape[0]
         hh, ww = x_nchw.shape[-2:]
-        x = to_nhwc_half(x_nchw)
+        x = to_nhwc_half(x_nchw, 4)   # the first VGG conv is a dense-K stem launch
         sides = []
         for si, items in enumerate(self.stages):
             for it in items:
