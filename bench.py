@@ -166,9 +166,9 @@ def main():
             flop = 8 * h * w * per_px
             achieved = flop / (ms * 1e-3) / 1e12
             # HBM bytes per launch of this kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-            # separate passes, gfx950 correction applied; profiles/r01_k_utd_pmc.json) -- same launch geometry only
+            # separate passes, gfx950 correction applied; profiles/r01_k_utd3_pmc.json) -- same launch geometry only
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_k_utd_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", "r01_k_utd3_pmc.json")
             if name == "sr_utd_f16" and (h, w) == (540, 960) and os.path.exists(pmc):
                 with open(pmc) as f:
                     traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"]

@@ -532,12 +532,17 @@ __global__ void __launch_bounds__(256) k_osvos_fuse(const OsvosP p) {
     p.out[i] = acc;
 }
 
+static int g_splitk_fill = 256;   // split K when a launch has fewer workgroups than this (measured: tools/probe_splitk.py)
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal (tuning hook)
 
 extern "C" {
 
 int vsr_conv2d_tuning(int patch_mode) {
     const int old = g_patch_mode;
+    if (patch_mode >= 1000) {   // 1000 + n: split-K fill threshold n (experiments; default 256)
+        g_splitk_fill = patch_mode - 1000;
+        return old;
+    }
     g_patch_mode = patch_mode;
     return old;
 }
@@ -723,8 +728,8 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
     // split-K when the launch cannot fill the chip and K is long
     const int nk_all = (kh * kw * (cin >> 5) + 1) >> 1;
     int splits = 1;
-    if (splitk_ws && (long long)gx * gy < 128 && nk_all >= 8) {
-        splits = (int)(256 / ((long long)gx * gy));
+    if (splitk_ws && (long long)gx * gy < g_splitk_fill && nk_all >= 8) {
+        splits = (int)((g_splitk_fill * 2 + (long long)gx * gy - 1) / ((long long)gx * gy));
         if (splits > nk_all / 4) splits = nk_all / 4;
         if (splits > 32) splits = 32;
         while (splits > 1 && (size_t)splits * M * cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
