@@ -42,6 +42,9 @@ struct ConvP {
     int pad_y_ph[4], pad_x_ph[4], oy_off_ph[4], ox_off_ph[4];
 };
 
+struct C0 { static constexpr int value = 0; };
+struct C1 { static constexpr int value = 1; };
+
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
 // STEM: the input has 4 channels per pixel ([N,H,W,4] fp16, 3 live) and one K chunk is a whole kernel ROW: k = 4 kx + c
@@ -96,8 +99,19 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     const int bchunk = tid & 3;
     const int brow[2] = {tid >> 2, (tid + 256) >> 2};
 
-    uint4 ra[2], rb[2][2];
-    auto gload = [&](int ks) __attribute__((always_inline)) {
+    // Global -> register staging, two K steps deep: the loads of step ks+2 are issued at the top of step ks and stored to
+    // LDS at the end of step ks+1.  Every load is a buffer load whose offset is out of range when the piece does not
+    // exist (padding, tail, idle thread) -- the hardware returns zeros -- so a step issues a FIXED number of loads and
+    // hipcc can wait with vmcnt(6) for the older set only (conditional loads forced vmcnt(0): one step of cover).
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(wpk), 0, (int)((size_t)(STEM ? p.kh : p.kh * p.kw * nchunk) * p.cout_pad * 64), 0x00020000);
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.in_ld * 2), 0x00020000);
+    u4 ra[2][2], rb[2][2][2];
+    auto gload = [&](int ks, auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int pr = 2 * ks + hf;
@@ -105,33 +119,35 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
             const int prc = live ? pr : 0;
             const int tap = prc / nchunk, ch = prc - tap * nchunk;
             const int ky = STEM ? tap : tap / p.kw, kx = STEM ? 2 * bchunk : tap - ky * p.kw;
-            ra[hf] = make_uint4(0, 0, 0, 0);
-            if (live && tid < A_PIECES)  // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0.. contiguous
-                ra[hf] = *reinterpret_cast<const uint4*>(wpk + ((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8);
+            // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0.. contiguous
+            const unsigned woff = (live && tid < A_PIECES) ? (unsigned)((((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8) * 2) : 0xFFFFFFFFu;
+            ra[S][hf] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, woff, 0, 0);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int iy = piy0[r] + ky, ix = pix0[r] + kx;
-                uint4 v = make_uint4(0, 0, 0, 0);
+                const bool rowok = live && pok[r] && iy >= 0 && iy < p.H;
                 if (STEM) {   // this 16-byte piece = taps kx, kx+1 of kernel row ky: two 8-byte pixels
-                    if (live && pok[r] && iy >= 0 && iy < p.H) {
-                        const _Float16* rowp = p.in + ((size_t)pn[r] * p.H + iy) * p.W * 4;
-                        if (ix >= 0 && ix < p.W) { const uint2 t = *reinterpret_cast<const uint2*>(rowp + (size_t)ix * 4); v.x = t.x; v.y = t.y; }
-                        if (ix + 1 >= 0 && ix + 1 < p.W) { const uint2 t = *reinterpret_cast<const uint2*>(rowp + (size_t)(ix + 1) * 4); v.z = t.x; v.w = t.y; }
-                    }
-                } else if (live && pok[r] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                    v = *reinterpret_cast<const uint4*>(p.in + (((size_t)pn[r] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff +
-                                                       ch * 32 + bchunk * 8);
+                    const size_t rowb = ((size_t)pn[r] * p.H + iy) * p.W * 8;
+                    const unsigned o0 = (rowok && ix >= 0 && ix < p.W) ? (unsigned)(rowb + (size_t)ix * 8) : 0xFFFFFFFFu;
+                    const unsigned o1 = (rowok && ix + 1 >= 0 && ix + 1 < p.W) ? (unsigned)(rowb + (size_t)(ix + 1) * 8) : 0xFFFFFFFFu;
+                    const u2 t0 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, o0, 0, 0);
+                    const u2 t1 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, o1, 0, 0);
+                    rb[S][hf][r] = u4{t0[0], t0[1], t1[0], t1[1]};
+                } else {
+                    const unsigned off = (rowok && ix >= 0 && ix < p.W)
+                        ? (unsigned)(((((size_t)pn[r] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + ch * 32 + bchunk * 8) * 2) : 0xFFFFFFFFu;
+                    rb[S][hf][r] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
                 }
-                rb[hf][r] = v;
             }
         }
     };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
+    auto lstore = [&](int buf, auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            if (tid < A_PIECES) *reinterpret_cast<uint4*>(As(buf, hf) + sw_off(tid >> 2, tid & 3)) = ra[hf];
+            if (tid < A_PIECES) *reinterpret_cast<u4*>(As(buf, hf) + sw_off(tid >> 2, tid & 3)) = ra[S][hf];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) *reinterpret_cast<uint4*>(Bs(buf, hf) + sw_off(brow[r], bchunk)) = rb[hf][r];
+            for (int r = 0; r < 2; ++r) *reinterpret_cast<u4*>(Bs(buf, hf) + sw_off(brow[r], bchunk)) = rb[S][hf][r];
         }
     };
 
@@ -142,13 +158,15 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 
     if (ks0 < nk) {
-        gload(ks0);
-        lstore(ks0 & 1);
+        gload(ks0, C0{});
+        lstore(ks0 & 1, C0{});
+        if (ks0 + 1 < nk) gload(ks0 + 1, C1{});
     }
     __syncthreads();
-    for (int ks = ks0; ks < nk; ++ks) {
+    // step ks: its data is in LDS buffer ks&1, step ks+1 is in register set `other`, step ks+2 is requested into set `mine`
+    auto body = [&](int ks, auto mine, auto other) __attribute__((always_inline)) {
         const int buf = ks & 1;
-        if (ks + 1 < nk) gload(ks + 1);
+        if (ks + 2 < nk) gload(ks + 2, mine);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             h8 bf[2];
@@ -162,8 +180,12 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
             }
         }
-        if (ks + 1 < nk) lstore(buf ^ 1);
+        if (ks + 1 < nk) lstore(buf ^ 1, other);
         __syncthreads();
+    };
+    for (int ks = ks0; ks < nk; ks += 2) {
+        body(ks, C0{}, C1{});
+        if (ks + 1 < nk) body(ks + 1, C1{}, C0{});
     }
 
     // ---- epilogue: this lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15
