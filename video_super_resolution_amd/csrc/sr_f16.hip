@@ -878,10 +878,13 @@ k_tail(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 1 + lr_px;
     const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
     const int lr_st = lr_off(lr_px, lr_ch);
-    auto fetch_lr = [&](int r) __attribute__((always_inline)) -> uint4 {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (lr_col_ok && r >= 0 && r < h) v = *reinterpret_cast<const uint4*>(in_n + ((size_t)r * w + lr_col) * NF + lr_ch * 8);
-        return v;
+    // buffer load with an out-of-range offset (zeros) for lanes / rows outside the image: no branch, so the prefetched
+    // row is waited for where it is stored to LDS, not at the top of the step (see k_utd3)
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    typedef unsigned int u4b __attribute__((ext_vector_type(4)));
+    auto fetch_lr = [&](int r) __attribute__((always_inline)) -> u4b {
+        const unsigned off = (lr_col_ok && r >= 0 && r < h) ? (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
+        return __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
     };
     auto lr_slot = [&](int r) __attribute__((always_inline)) { return ((r + 1) % 3) * LR_SLOT; };
     auto ring_slot = [&](int gi) __attribute__((always_inline)) { return ring + ((gi + 3) % 3) * SLOT_PITCH; };
@@ -978,20 +981,20 @@ k_tail(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     };
 
     if (lr_loader) {
-        *reinterpret_cast<uint4*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
-        *reinterpret_cast<uint4*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
-        *reinterpret_cast<uint4*>(lrr + lr_slot(r0 + 1) + lr_st) = fetch_lr(r0 + 1);
+        *reinterpret_cast<u4b*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
+        *reinterpret_cast<u4b*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
+        *reinterpret_cast<u4b*>(lrr + lr_slot(r0 + 1) + lr_st) = fetch_lr(r0 + 1);
     }
     __syncthreads();
     phase1(r0 - 1);
     __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0);   // the prologue's global loads have landed: clear the vmcnt bookkeeping (see k_utd3)
     for (int i = r0; i <= r1 + 1; ++i) {
-        uint4 nxt = make_uint4(0, 0, 0, 0);
         const bool produce = i <= r1 - 1;
-        if (produce && wv < 3) nxt = fetch_lr(i + 2);
+        const u4b nxt = fetch_lr(i + 2);   // (rows >= h read zeros)
         if (produce) phase1(i);          // writes ring slot i%3 (last read by phase3(i-1) as G(i-3))
         if (i >= r0 + 1) phase3(i);      // reads G(i-2), G(i-1)
-        if (produce && wv < 3 && lr_loader) *reinterpret_cast<uint4*>(lrr + lr_slot(i + 2) + lr_st) = nxt;
+        if (produce && wv < 3 && lr_loader) *reinterpret_cast<u4b*>(lrr + lr_slot(i + 2) + lr_st) = nxt;
         __syncthreads();
     }
 }
