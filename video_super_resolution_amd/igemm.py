@@ -39,6 +39,19 @@ def _cout_pad(c: int) -> int:
     return (c + 63) // 64 * 64
 
 
+def cached_zeros(owner, tag, shape, device) -> torch.Tensor:
+    """A zero-initialised fp16 buffer that belongs to `owner` (a layer / executor object) and is handed out again on the
+    next call with the same shape on the same stream.  The conv kernels write only the live channel slices, so the
+    padding channels stay zero without a fill launch per call (the trunks issued ~100 of those per frame).  Safe because
+    every owner produces one such tensor per executor call and its consumers run before the owner's next call."""
+    d = owner.__dict__.setdefault("_bufs", {})
+    k = (tag, tuple(shape), device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = d.get(k)
+    if t is None:
+        t = d[k] = torch.zeros(shape, dtype=torch.float16, device=device)
+    return t
+
+
 def to_nhwc_half(x_nchw: torch.Tensor, cp: int = None) -> torch.Tensor:
     """[N,C,H,W] any float -> [N,H,W,pad32(C)] float16, zero padded."""
     N, C, H, W = x_nchw.shape
@@ -87,8 +100,8 @@ class HConv:
         N, H, W, in_ld = x.shape
         Ho, Wo = out_hw or self.out_hw(H, W)
         if out is None:
-            out = torch.zeros((N, Ho * self.oy[0], Wo * self.ox[0], pad32(out_coff + self.cout)), dtype=torch.float16,
-                              device=x.device) if pad32(out_coff + self.cout) != out_coff + self.cout else \
+            out = cached_zeros(self, "out", (N, Ho * self.oy[0], Wo * self.ox[0], pad32(out_coff + self.cout)), x.device) \
+                if pad32(out_coff + self.cout) != out_coff + self.cout else \
                 torch.empty((N, Ho * self.oy[0], Wo * self.ox[0], out_coff + self.cout), dtype=torch.float16, device=x.device)
         tok = L.TIMER.start(f"conv N{N} {H}x{W} c{self.cin_pad}->{self.cout} k{self.kh}x{self.kw} s{self.stride}"
                             f"{' ph' if self.oy[0] > 1 else ''}") if L.TIMER.enabled else None
@@ -129,7 +142,8 @@ class HConvStem:
         Wo = (W + 2 * self.pad - self.kw) // self.stride + 1
         if out is None:
             cp = pad32(out_coff + self.cout)
-            out = (torch.zeros if cp != out_coff + self.cout else torch.empty)((N, Ho, Wo, cp), dtype=torch.float16, device=x4.device)
+            out = cached_zeros(self, "out", (N, Ho, Wo, cp), x4.device) if cp != out_coff + self.cout else \
+                torch.empty((N, Ho, Wo, cp), dtype=torch.float16, device=x4.device)
         tok = L.TIMER.start(f"conv N{N} {H}x{W} c4->{self.cout} k{self.kh}x{self.kw} s{self.stride} stem") if L.TIMER.enabled else None
         L.check(L.load().vsr_conv2d_stem_f16(L.dptr(x4, torch.float16), L.dptr(self.w, torch.float16), L.optr(self.b),
                                              L.dptr(out, torch.float16), out.shape[3], out_coff, N, H, W, Ho, Wo, self.cout,
@@ -161,7 +175,7 @@ class HDeconv4s2:
         N, H, W, in_ld = x.shape
         if out is None:
             cp = pad32(out_coff + self.cout)
-            out = torch.zeros((N, 2 * H, 2 * W, cp), dtype=torch.float16, device=x.device)
+            out = cached_zeros(self, "out", (N, 2 * H, 2 * W, cp), x.device)
         c0 = self.phases[0]
         tok = L.TIMER.start(f"deconv4s2 N{N} {H}x{W} c{c0.cin_pad}->{self.cout}") if L.TIMER.enabled else None
         wp = (ctypes.c_void_p * 4)(*[c.w.data_ptr() for c in self.phases])

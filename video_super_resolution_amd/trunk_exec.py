@@ -20,7 +20,8 @@ import torch.nn.functional as F
 from . import _lib as L
 from . import ops
 from .depth import HOURGLASS
-from .igemm import ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvStem, HDeconv4s2, pad32, pool2x2, resize_add, to_nhwc_half
+from .igemm import (ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvStem, HDeconv4s2, cached_zeros, pad32, pool2x2, resize_add,
+                    to_nhwc_half)
 
 
 def _fold(conv: nn.Conv2d, bn):
@@ -158,7 +159,7 @@ class HourglassExec:
         """[k,h,w,3] float frames -> [k,1,h,w] float depth predictions."""
         k, h, w, _ = frames_nhwc3.shape
         stem_first = self.prog[0] == "S" and isinstance(self.prog[1][0], tuple) and self.prog[1][0][0] == "stem"
-        x = torch.zeros((k, h, w, 4 if stem_first else 32), dtype=torch.float16, device=frames_nhwc3.device)
+        x = cached_zeros(self, "in", (k, h, w, 4 if stem_first else 32), frames_nhwc3.device)
         x[..., :3] = frames_nhwc3
         out, coff, c = self._run(self.prog, x, 0, 32)
         return out[..., coff:coff + 1].permute(0, 3, 1, 2).float()
@@ -193,7 +194,7 @@ class _Refine:
 
     def alloc_cat(self, idx, N, H, W, dev):
         """Concat buffer of decoder level idx (0 -> level 5 ...) at its resolution; the encoder writes slice 0."""
-        return torch.zeros((N, H, W, self.levels[idx]["cat"]), dtype=torch.float16, device=dev)
+        return cached_zeros(self, f"cat{idx}", (N, H, W, self.levels[idx]["cat"]), dev)
 
     def __call__(self, c6, cats, enc_c):
         """c6: coarsest features; cats[i]: concat buffer of level 5-i already holding the encoder features in
@@ -247,7 +248,7 @@ class _FlowNetCExec:
         """x6: [B,H,W,32] with the two normalised frames in channels 0-2 and 3-5."""
         B, H, W, _ = x6.shape
         dev = x6.device
-        both = torch.zeros((2 * B, H, W, 4), dtype=torch.float16, device=dev)   # 4-channel pixels for the dense-K stem
+        both = cached_zeros(self, "both", (2 * B, H, W, 4), dev)   # 4-channel pixels for the dense-K stem
         both[:B, ..., :3] = x6[..., 0:3]
         both[B:, ..., :3] = x6[..., 3:6]
         c2 = self.conv2(self.conv1(both))           # [2B,H/4,W/4,128]
@@ -256,7 +257,7 @@ class _FlowNetCExec:
         corr = ops.correlation(a3.permute(0, 3, 1, 2).float().contiguous(), b3.permute(0, 3, 1, 2).float().contiguous(),
                                20, 1, 20, 1, 2)     # fp32 NCHW cost volume kernel
         h8, w8 = H // 8, W // 8
-        cat31 = torch.zeros((B, h8, w8, pad32(473)), dtype=torch.float16, device=dev)
+        cat31 = cached_zeros(self, "cat31", (B, h8, w8, pad32(473)), dev)
         self.redir(a3.contiguous(), out=cat31, out_coff=0)
         cat31[..., 32:473] = F.leaky_relu(corr, 0.1).permute(0, 2, 3, 1)
         cats = [self.refine.alloc_cat(i, B, H >> (5 - i), W >> (5 - i), dev) for i in range(4)]
@@ -309,8 +310,8 @@ class _FusionExec:
     def __call__(self, x11):
         N, H, W, _ = x11.shape
         dev = x11.device
-        cat0 = torch.zeros((N, H, W, pad32(82)), dtype=torch.float16, device=dev)
-        cat1 = torch.zeros((N, H // 2, W // 2, pad32(162)), dtype=torch.float16, device=dev)
+        cat0 = cached_zeros(self, "cat0", (N, H, W, pad32(82)), dev)
+        cat1 = cached_zeros(self, "cat1", (N, H // 2, W // 2, pad32(162)), dev)
         self.conv0(x11, out=cat0, out_coff=0)                                             # 64
         self.conv1_1(self.conv1(cat0), out=cat1, out_coff=0)                              # 128
         c2 = self.conv2_1(self.conv2(cat1))
