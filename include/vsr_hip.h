@@ -200,6 +200,13 @@ int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out
                     const float* x, float* prefc, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                     vsr_stream_t stream);
 
+/* The same tail evaluated only at the output pixels (4i, 4j): prefc_dec [N,3,h,w] fp32.  Pass 1 of VSR.forward hands its
+ * frame to a nearest-neighbour x1/4 resize and nothing else (video_super_resolution.py:41-44), so only these pixels of
+ * it are ever read. */
+int vsr_sr_tail_dec_f16(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,
+                        const float* x, float* prefc_dec, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                        vsr_stream_t stream);
+
 /* The fusion MLP (vsr_sr_fc_fuse_f32) specialised and unrolled for the reference's 8 planes x 32 hidden units. */
 int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,
                          int nplanes, int hidden, float* out, int P, int out_nhwc, vsr_stream_t stream);

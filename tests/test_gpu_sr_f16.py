@@ -132,3 +132,17 @@ def test_sr_fp16_vs_fp32_path_full_width_strip(gpu_vsr, gpu_vsr_f16):
     ref = gpu_vsr.model(x)
     mse = ((a - ref) ** 2).mean().item()
     assert 10 * np.log10(255.0 ** 2 / mse) > 55.0
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (9, 40), (37, 33)])
+def test_decimated_output_is_a_subset_of_the_full_frame(gpu_vsr_f16, shape):
+    """decimate=True (the pixels a nearest x1/4 resize reads: pass 1 of VSR.forward) returns exactly the values of the
+    full frame at (4i, 4j)."""
+    m = gpu_vsr_f16.model
+    h, w = shape
+    x = torch.from_numpy(np.random.RandomState(h + w).randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        full = m(x)
+        dec = m(x, decimate=True)
+    assert dec.shape == (1, 3, h, w)
+    assert torch.equal(dec, full[..., ::4, ::4])

@@ -23,9 +23,8 @@ for it in range(4):
     else:
         est = F.interpolate(est_img.permute(0, 3, 1, 2), (h, w)); est_hw3 = est[0].permute(1, 2, 0).contiguous()
     pics, depth, _ = tick("guidance 1", lambda: m._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,)))
-    out1 = tick("SR 1", lambda: m.model(torch.cat((frames, pics, depth, est), 0)))
+    mid = tick("SR 1", lambda: m.model(torch.cat((frames, pics, depth, est), 0), decimate=True))[0]
     def g2():
-        mid = F.interpolate(out1, (h, w))[0]
         mid_hw3 = mid.permute(1, 2, 0).contiguous()
         pics2, depth2, mask = m._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3))
         masked = torch.where(maskprocess(mask) != 0, torch.zeros_like(mid), mid).unsqueeze(0)

@@ -822,7 +822,9 @@ k_utd2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
 //   P3: wave w -> output row 4i-5+(w>>1), column half w&1 of the strip's own 124 HR columns, 4 tiles of 16 pixels:
 //       M = 16 rows of which rows 0, 4, 8 carry the 3 output channels (so lane groups g = 0,1,2 each finish one
 //       channel), N = 16 pixels, K = 9 taps x 32 ch, B straight from the ring.
-template <bool ALLMAX>
+// DEC: only the output pixels (4i, 4j) are wanted (pass 1 of VSR.forward feeds its frame to a nearest x1/4 resize,
+// video_super_resolution.py:44): 3x3 rows with R % 4 != 0 are skipped and `prefc` is [N,3,h,w].
+template <bool ALLMAX, bool DEC = false>
 __global__ void __launch_bounds__(512, 2)
 k_tail(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, const unsigned char* __restrict__ acv,
        const float* __restrict__ tpar, const float* __restrict__ x, float* __restrict__ prefc, int h, int w, int rows_per_seg) {
@@ -941,6 +943,7 @@ k_tail(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     auto phase3 = [&](int i) __attribute__((always_inline)) {
         const int R = 4 * i - 5 + (wv >> 1);
         if (R < 4 * r0 || R >= 4 * r1) return;  // wave-uniform: row of another segment / outside the image
+        if (DEC && (R & 3) != 0) return;
         const int half = wv & 1;
         f4 acc[4];
 #pragma unroll
@@ -975,7 +978,9 @@ k_tail(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
                 const float v00 = xp[(size_t)y0 * w + x0i] * sub_s + sub_b, v01 = xp[(size_t)y0 * w + x1i] * sub_s + sub_b;
                 const float v10 = xp[(size_t)y1 * w + x0i] * sub_s + sub_b, v11 = xp[(size_t)y1 * w + x1i] * sub_s + sub_b;
                 const float skip = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
-                prefc[(((size_t)n * 3 + ch) * H + R) * W + c] = (skip + acc[t][0] + b_out) * add_s + add_b;
+                const float v = (skip + acc[t][0] + b_out) * add_s + add_b;
+                if (!DEC) prefc[(((size_t)n * 3 + ch) * H + R) * W + c] = v;
+                else if ((c & 3) == 0) prefc[(((size_t)n * 3 + ch) * h + (R >> 2)) * w + (c >> 2)] = v;
             }
         }
     };
@@ -1159,29 +1164,40 @@ int vsr_sr_utd2_f16(const void* in, const void* blob_v2, void* out, int N, int h
     return vsr::launched("sr_utd2");
 }
 
-int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,
-                    const float* x, float* prefc, int N, int h, int w, int rows_per_seg, int slopes_le_one,
-                    vsr_stream_t stream) {
+static int tail_launch(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,
+                       const float* x, float* prefc, int N, int h, int w, int rows_per_seg, int slopes_le_one, bool dec,
+                       vsr_stream_t stream) {
     VSR_REQUIRE(hid_nhwc && blob && conv_out_frags && tail_params && x && prefc, "sr_tail_f16: null pointer");
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_tail_f16: bad shape");
     constexpr int LDS = 3 * SLOT_PITCH + LR_BYTES + 256;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
     VSR_REQUIRE(segs <= 65535, "sr_tail_f16: too many row segments");
+    typedef void (*kern_t)(const _Float16*, const unsigned char*, const unsigned char*, const float*, const float*, float*, int, int, int);
+    static const kern_t kerns[4] = {k_tail<false, false>, k_tail<true, false>, k_tail<false, true>, k_tail<true, true>};
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return vsr::fail(VSR_E_LAUNCH, "sr_tail_f16: cannot reserve %d bytes of LDS", LDS);
+        for (kern_t k : kerns)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+                return vsr::fail(VSR_E_LAUNCH, "sr_tail_f16: cannot reserve %d bytes of LDS", LDS);
         attr_done = true;
     }
-    if (slopes_le_one)
-        hipLaunchKernelGGL(k_tail<true>, dim3(strips, segs, N), dim3(512), LDS, vsr::S(stream), (const _Float16*)hid_nhwc,
-                           (const unsigned char*)blob, (const unsigned char*)conv_out_frags, tail_params, x, prefc, h, w, rows_per_seg);
-    else
-        hipLaunchKernelGGL(k_tail<false>, dim3(strips, segs, N), dim3(512), LDS, vsr::S(stream), (const _Float16*)hid_nhwc,
-                           (const unsigned char*)blob, (const unsigned char*)conv_out_frags, tail_params, x, prefc, h, w, rows_per_seg);
+    hipLaunchKernelGGL(kerns[(dec ? 2 : 0) + (slopes_le_one ? 1 : 0)], dim3(strips, segs, N), dim3(512), LDS, vsr::S(stream),
+                       (const _Float16*)hid_nhwc, (const unsigned char*)blob, (const unsigned char*)conv_out_frags, tail_params, x,
+                       prefc, h, w, rows_per_seg);
     return vsr::launched("sr_tail_f16");
+}
+
+int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,
+                    const float* x, float* prefc, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                    vsr_stream_t stream) {
+    return tail_launch(hid_nhwc, blob, conv_out_frags, tail_params, x, prefc, N, h, w, rows_per_seg, slopes_le_one, false, stream);
+}
+
+int vsr_sr_tail_dec_f16(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,
+                        const float* x, float* prefc_dec, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                        vsr_stream_t stream) {
+    return tail_launch(hid_nhwc, blob, conv_out_frags, tail_params, x, prefc_dec, N, h, w, rows_per_seg, slopes_le_one, true, stream);
 }
 
 int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -254,7 +254,10 @@ class SRProjectionModule(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, taps: Optional[dict] = None, decimate: bool = False) -> torch.Tensor:
+        """[8,3,h,w] planes -> [1,3,4h,4w].  decimate=True returns only the pixels (4i, 4j) as [1,3,h,w] -- what a
+        nearest x1/4 resize of the full frame reads (pass 1 of VSR.forward, video_super_resolution.py:41-44); identical
+        values, the tail and the fusion MLP are evaluated at 1/16 of the pixels."""
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected [planes,3,h,w], got {tuple(x.shape)}")
         N, _, h, w = x.shape
@@ -267,7 +270,7 @@ class SRProjectionModule(nn.Module):
         G = self.block.num_groups
         cmap = self._const_map(P, h, w, dev)
         if self.precision == "fp16":
-            return self._forward_f16(x, P, cmap, taps)
+            return self._forward_f16(x, P, cmap, taps, decimate)
         if self.precision != "fp32":
             raise ValueError(f"precision must be 'fp16' or 'fp32', got {self.precision!r}")
         nmid = P["w_in"].shape[0]
@@ -312,7 +315,7 @@ class SRProjectionModule(nn.Module):
         L.check(lib.vsr_sr_fc_fuse_f32(L.dptr(prefc), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]), L.dptr(P["fc_w2"]),
                                        L.dptr(P["fc_b2"]), N, P["fc_w1"].shape[0], L.dptr(out), 16 * h * w, 0, L.stream()),
                 "sr_fc_fuse")
-        return out
+        return out[..., ::4, ::4].contiguous() if decimate else out
 
     # ------------------------------------------------------------------ MFMA path (fp16 storage, NHWC)
     @staticmethod
@@ -395,7 +398,7 @@ class SRProjectionModule(nn.Module):
         L.TIMER.stop(tok)
         return out
 
-    def _forward_f16(self, x, P, cmap, taps):
+    def _forward_f16(self, x, P, cmap, taps, decimate=False):
         lib = L.load()
         N, _, h, w = x.shape
         dev = x.device
@@ -449,15 +452,17 @@ class SRProjectionModule(nn.Module):
             self._c1h(co(live)["ins"], P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
         if taps is not None:
             taps[f"block{self.num_steps - 1}"] = nchw(hid)
-        prefc = torch.empty((N, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev)
-        tok = L.TIMER.start("sr_tail_f16")
-        L.check(lib.vsr_sr_tail_f16(L.dptr(hid, torch.float16), L.dptr(P["utd_out"], torch.uint8), L.dptr(P["cv_frags"], torch.float16),
-                                    L.dptr(P["tail_par"]), L.dptr(x), L.dptr(prefc), N, h, w, self._rows_per_segment(N, h, w),
-                                    int(P["slopes_le_one"]), L.stream()), "sr_tail_f16")
+        ho, wo = (h, w) if decimate else (4 * h, 4 * w)
+        prefc = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
+        tok = L.TIMER.start("sr_tail_dec_f16" if decimate else "sr_tail_f16")
+        tail = lib.vsr_sr_tail_dec_f16 if decimate else lib.vsr_sr_tail_f16
+        L.check(tail(L.dptr(hid, torch.float16), L.dptr(P["utd_out"], torch.uint8), L.dptr(P["cv_frags"], torch.float16),
+                     L.dptr(P["tail_par"]), L.dptr(x), L.dptr(prefc), N, h, w, self._rows_per_segment(N, h, w),
+                     int(P["slopes_le_one"]), L.stream()), "sr_tail_f16")
         L.TIMER.stop(tok)
-        out = torch.empty((1, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev)
+        out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=dev)
         L.check(lib.vsr_sr_fc_planes_f32(L.dptr(prefc), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]), L.dptr(P["fc_w2"]), L.dptr(P["fc_b2"]),
-                                         N, P["fc_w1"].shape[0], L.dptr(out), 16 * h * w, 0, L.stream()), "sr_fc_planes")
+                                         N, P["fc_w1"].shape[0], L.dptr(out), ho * wo, 0, L.stream()), "sr_fc_planes")
         if taps is not None:
             taps[f"prefc{self.num_steps - 1}"] = prefc
         return out

@@ -148,10 +148,11 @@ class VSR(nn.Module):
             # (the estimate's depth is only used in pass 2 but is already known: batched with the three frames)
             pics, depth, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,))
             self.model.precision = self.precision
-            out1 = self.model(torch.cat((frames, pics, depth, est), 0))  # [1,3,4h,4w]
+            # pass 1's frame is only ever read through the nearest x1/4 resize of :44, i.e. at its pixels (4i,4j): the SR
+            # stack evaluates its tail and fusion MLP at exactly those (identical values, 1/16 of the tail work)
+            mid = self.model(torch.cat((frames, pics, depth, est), 0), decimate=True)[0]  # [3,h,w] = F.interpolate(out1,(h,w))[0]
 
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
-            mid = F.interpolate(out1, (h, w))[0]  # nearest: HR pixel (4i,4j)
             mid_hw3 = mid.permute(1, 2, 0).contiguous()
             pics2, depth2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3))
             masked = torch.where(maskprocess(mask) != 0, torch.zeros_like(mid), mid).unsqueeze(0)  # :58-60
