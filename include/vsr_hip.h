@@ -200,6 +200,22 @@ int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out
                     const float* x, float* prefc, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                     vsr_stream_t stream);
 
+/* The tail in the structure of the fused stage (k_tail3, csrc/sr_tail3.hip): one wave per SIMD, the x4 map in registers,
+ * the 3x3 turned around so that the wave holding an HR row forms that row's contribution to its three output rows (M row
+ * 4 dy + co) and only fp32 partial sums cross waves.  Writes the RAW planes raw [N,3,4h,4w] fp32 = conv_out(PReLU(out
+ * deconv)) + bias; the bilinear skip and add_mean are applied by vsr_sr_fc_planes_skip_f32, which reads the planes next.
+ * conv3_frags: [dx 3][lane 64][8] fp16 (sr.py:pack_conv_out_frags3); tail_params as vsr_sr_tail_f16.  decimate != 0:
+ * raw is [N,3,h,w], the pixels (4i,4j).  The pair the forward runs; vsr_sr_tail_f16 + vsr_sr_fc_planes_f32 are the
+ * LDS-ring build with the skip inside the tail (agree up to fp32 summation order). */
+int vsr_sr_tail3_f16(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* raw,
+                     int N, int h, int w, int rows_per_seg, int slopes_le_one, int decimate, vsr_stream_t stream);
+/* Fusion MLP over the 8 planes (vsr_sr_fc_planes_f32) reading RAW planes and finishing them on the fly:
+ * plane = (bilinear x4 of (x * sub_scale + sub_bias) + raw) * add_scale + add_bias; x [8,3,h,w] fp32; out [3,4h,4w] (or
+ * [3,h,w] with decimate != 0) fp32. */
+int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tail_params, const float* w1, const float* b1,
+                              const float* w2, const float* b2, int nplanes, int hidden, float* out, int h, int w, int decimate,
+                              vsr_stream_t stream);
+
 /* The same tail evaluated only at the output pixels (4i, 4j): prefc_dec [N,3,h,w] fp32.  Pass 1 of VSR.forward hands its
  * frame to a nearest-neighbour x1/4 resize and nothing else (video_super_resolution.py:41-44), so only these pixels of
  * it are ever read. */

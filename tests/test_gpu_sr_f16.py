@@ -146,3 +146,24 @@ def test_decimated_output_is_a_subset_of_the_full_frame(gpu_vsr_f16, shape):
         dec = m(x, decimate=True)
     assert dec.shape == (1, 3, h, w)
     assert torch.equal(dec, full[..., ::4, ::4])
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (9, 40), (37, 33), (2, 2)])
+@pytest.mark.parametrize("decimate", [False, True])
+def test_tail_builds_agree(gpu_vsr_f16, shape, decimate):
+    """k_tail3 + fusion MLP with the skip (one wave per SIMD, registers, 3x3 turned around; the forward's pair) against
+    k_tail + plain fusion MLP (LDS ring, skip inside the tail): same operands and roundings, only the order of the fp32
+    sums differs."""
+    m = gpu_vsr_f16.model
+    h, w = shape
+    x = torch.from_numpy(np.random.RandomState(h * 7 + w).randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    try:
+        with torch.no_grad():
+            m.tail_build = 1
+            ref = m(x, decimate=decimate)
+            m.tail_build = 3
+            got = m(x, decimate=decimate)
+    finally:
+        m.tail_build = 3
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())

@@ -594,14 +594,6 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
     }
 }
 
-// bilinear x4, align_corners=False, as ATen's upsample_bilinear2d: src = (dst+0.5)/4-0.5 clamped at 0
-__device__ __forceinline__ void bil4(int dst, int n, int& i0, int& i1, float& l1) {
-    float src = ((float)dst + 0.5f) * 0.25f - 0.5f;
-    if (src < 0.0f) src = 0.0f;
-    i0 = (int)src;
-    i1 = i0 + (i0 < n - 1 ? 1 : 0);
-    l1 = src - (float)i0;
-}
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1027,6 +1019,45 @@ k_fc_planes(const float* __restrict__ prefc, const float* __restrict__ w1, const
     if (nhwc) out[p * 3 + c] = o; else out[(size_t)c * P + p] = o;
 }
 
+// ---- the same MLP reading the tail's RAW planes (conv_out 3x3 + bias, k_tail3) and finishing them on the fly:
+//      plane = (bilinear x4 of sub_mean(x) + raw) * add_scale + add_bias  (SRProjectionModule.py:136,142-143).
+//      dec != 0: the planes and the output hold only the pixels (4i, 4j).
+template <int NPL, int HID>
+__global__ void __launch_bounds__(256)
+k_fc_planes_skip(const float* __restrict__ raw, const float* __restrict__ x, const float* __restrict__ tpar,
+                 const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                 const float* __restrict__ b2, float* __restrict__ out, int h, int w, int dec) {
+    const int c = blockIdx.y;
+    const int Wo = dec ? w : 4 * w, Ho = dec ? h : 4 * h;
+    const size_t P = (size_t)Ho * Wo;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int yo = (int)(p / Wo), xo = (int)(p - (size_t)yo * Wo);
+    int y0, y1, x0i, x1i;
+    float ly, lx;
+    bil4(dec ? 4 * yo : yo, h, y0, y1, ly);
+    bil4(dec ? 4 * xo : xo, w, x0i, x1i, lx);
+    const float sub_s = tpar[3 + c], sub_b = tpar[6 + c], add_s = tpar[9 + c], add_b = tpar[12 + c];
+    float v[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const float* xp = x + ((size_t)i * 3 + c) * (size_t)h * w;
+        const float v00 = xp[(size_t)y0 * w + x0i] * sub_s + sub_b, v01 = xp[(size_t)y0 * w + x1i] * sub_s + sub_b;
+        const float v10 = xp[(size_t)y1 * w + x0i] * sub_s + sub_b, v11 = xp[(size_t)y1 * w + x1i] * sub_s + sub_b;
+        const float skip = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+        v[i] = (skip + raw[((size_t)i * 3 + c) * P + p]) * add_s + add_b;
+    }
+    float o = b2[0];
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+        float hs = b1[j];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) hs += w1[j * NPL + i] * v[i];
+        o += w2[j] * fmaxf(hs, 0.0f);
+    }
+    out[(size_t)c * P + p] = fmaxf(o, 0.0f);
+}
+
 }  // namespace
 
 static int g_utd_variant = 0;
@@ -1035,6 +1066,8 @@ namespace vsr {
 int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                 int diag, hipStream_t stream);
 int utd3_set_stamps(void* buf);
+int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* prefc, int N,
+                 int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream);
 }
 
 extern "C" {
@@ -1198,6 +1231,28 @@ int vsr_sr_tail_dec_f16(const void* hid_nhwc, const void* blob, const void* conv
                         const float* x, float* prefc_dec, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                         vsr_stream_t stream) {
     return tail_launch(hid_nhwc, blob, conv_out_frags, tail_params, x, prefc_dec, N, h, w, rows_per_seg, slopes_le_one, true, stream);
+}
+
+int vsr_sr_tail3_f16(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* raw,
+                     int N, int h, int w, int rows_per_seg, int slopes_le_one, int decimate, vsr_stream_t stream) {
+    VSR_REQUIRE(hid_nhwc && blob && conv3_frags && tail_params && raw, "sr_tail3_f16: null pointer");
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_tail3_f16: bad shape");
+    VSR_REQUIRE(vsr::cdiv(h, rows_per_seg) <= 65535, "sr_tail3_f16: too many row segments");
+    return vsr::launch_tail3(hid_nhwc, blob, conv3_frags, tail_params, raw, N, h, w, rows_per_seg, slopes_le_one, decimate,
+                             vsr::S(stream));
+}
+
+int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tail_params, const float* w1, const float* b1,
+                              const float* w2, const float* b2, int nplanes, int hidden, float* out, int h, int w, int decimate,
+                              vsr_stream_t stream) {
+    VSR_REQUIRE(raw && x && tail_params && w1 && b1 && w2 && b2 && out, "sr_fc_planes_skip: null pointer");
+    VSR_REQUIRE(h > 0 && w > 0, "sr_fc_planes_skip: bad shape");
+    if (nplanes != 8 || hidden != 32)
+        return vsr::fail(VSR_E_UNSUPPORTED, "sr_fc_planes_skip: %d planes / %d hidden units (the reference fuses 8 through 32)", nplanes, hidden);
+    const size_t P = decimate ? (size_t)h * w : (size_t)16 * h * w;
+    hipLaunchKernelGGL((k_fc_planes_skip<8, 32>), dim3(vsr::cdiv(P, 256), 3), dim3(256), 0, vsr::S(stream), raw, x, tail_params, w1, b1,
+                       w2, b2, out, h, w, decimate);
+    return vsr::launched("sr_fc_planes_skip");
 }
 
 int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -65,6 +65,15 @@ __device__ __forceinline__ int ring_off(int cc, int chunk) { return cc * COL_PIT
 // byte offset of (pixel p, 16-byte chunk) inside an LR ring slot (64-byte pitch, chunk XOR pixel bits 1-2)
 __device__ __forceinline__ int lr_off(int p, int chunk) { return p * 64 + ((chunk ^ ((p >> 1) & 3)) << 4); }
 
+// bilinear x4, align_corners=False, as ATen's upsample_bilinear2d: src = (dst+0.5)/4-0.5 clamped at 0
+__device__ __forceinline__ void bil4(int dst, int n, int& i0, int& i1, float& l1) {
+    float src = ((float)dst + 0.5f) * 0.25f - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    i0 = (int)src;
+    i1 = i0 + (i0 < n - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
 template <bool B>
 struct BoolC { static constexpr bool value = B; };
 

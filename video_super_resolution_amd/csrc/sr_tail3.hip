@@ -1,0 +1,282 @@
+// sr_tail3.hip -- k_tail3: the fused tail of SRProjectionModule (reference SRProjectionModule.py:118-123,136,142-143)
+//   hid -> `out` DeconvBlock (ConvTranspose k8 s4 p2 + PReLU) -> conv_out 3x3 (32 -> 3) + bilinear x4 skip of sub_mean(x)
+//   + add_mean  ->  pre-fusion planes [N,3,4h,4w] fp32   (this kernel: everything up to the 3x3 + bias; skip and add_mean
+//   are applied by the fusion-MLP kernel that reads the planes next)
+// in the structure of k_utd3 (sr_utd3.hip): one wave per SIMD, wave `wv` owns HR row 4i+2+wv of every group, the x4
+// feature map stays in registers.  The 3x3 convolution is turned around: instead of gathering three HR rows per output
+// row (k_tail: an LDS ring of 12 rows, 36 ring reads and 36 MFMAs per wave and step with 3 of 16 MFMA rows useful), the
+// wave that holds an HR row forms that row's contribution to the THREE output rows it touches in one MFMA tile -- M
+// row 4 dy + co (9 of 16 rows useful), one MFMA per (output column phase, dx, pixel tile) = 24 per step, B operands
+// straight from the deconv's operand tiles (a one-lane DPP shift where dx crosses a position boundary).  Only the
+// fp32 partial sums cross waves: 16 bytes per (output row, dy, HR pixel) in a 16-row LDS window; the wave that owns
+// output row R sums its three partials two steps later, adds bias and the bilinear skip and stores.
+//   step i = [deconv phases 0,1 of G(i); finish output rows 4i-7 .. 4i-4] BARRIER [deconv phases 2,3, PReLU, the 24
+//   conv MFMAs, partial stores, LR row i+3]
+#include "sr_f16_common.h"
+
+namespace {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+#define VSR_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+constexpr int T3_ROWS = 16;                              // output-row window of the partial sums
+constexpr int T3_PLANE = 128 * 16;                       // one (row, dy) plane: 128 HR columns x 16 B
+constexpr int T3_PART = (T3_ROWS * 3 + 1) * T3_PLANE;    // + one dump plane for the idle lane group
+constexpr int T3_LDS = T3_PART + LR_BYTES + 256;
+
+// DEC: only output pixels (4i, 4j) are wanted (pass 1 of VSR.forward): prefc is [N,3,h,w]
+template <bool ALLMAX, bool DEC>
+__global__ void __launch_bounds__(256)
+k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, const unsigned char* __restrict__ acv3,
+        const float* __restrict__ tpar, float* __restrict__ prefc, int h, int w, int rows_per_seg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const pb = smem;
+    unsigned char* const lrr = smem + T3_PART;
+    float* const bias_s = reinterpret_cast<float*>(smem + T3_PART + LR_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int x0 = blockIdx.x * TX;
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_seg;
+    const int r1 = min(h, r0 + rows_per_seg);
+    if (r0 >= r1) return;
+    const int H = 4 * h, W = 4 * w;
+
+    // deconv weights of HR row phase wv: the slices of k_utd's waves (2wv, 2wv+1); conv fragments per dx
+    h8 Aup[4][4][2];
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                Aup[px][t][mt] = *reinterpret_cast<const h8*>(
+                    blob + BLOB_UP + (((((2 * wv + (px >> 1)) * 2 + (px & 1)) * 4 + t) * 2 + mt) * 64 + lane) * 16);
+    h8 Ac[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) Ac[dx] = *reinterpret_cast<const h8*>(acv3 + (dx * 64 + lane) * 16);
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) asm volatile("" : "+a"(Aup[px][t][mt]));
+    const float* fpar = reinterpret_cast<const float*>(blob + BLOB_F32);
+    if (tid < 32) bias_s[tid] = fpar[tid];
+    f4 bup[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) bup[mt] = *reinterpret_cast<const f4*>(fpar + 16 * mt + 4 * g);
+    const float a_up = fpar[96];
+    const h2 a_up2 = {(_Float16)a_up, (_Float16)a_up};
+    const bool up_max = ALLMAX || a_up <= 1.0f;
+
+    int lr_b[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = 16 * nt + l15;
+        lr_b[0][nt] = lr_off(j + 1, g);
+        lr_b[1][nt] = lr_off(j, g);
+    }
+    const bool lr_loader = tid < LR_COLS * 4;
+    const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 1 + lr_px;
+    const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
+    const int lr_st = lr_off(lr_px, lr_ch);
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    auto fetch_lr = [&](int r) __attribute__((always_inline)) -> u4 {
+        const unsigned off = (lr_col_ok && r >= 0 && r < h) ? (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
+        return __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+    };
+    auto lr_slot = [&](int r) __attribute__((always_inline)) { return ((r + 1) % 3) * LR_SLOT; };
+    auto load_lr_frags = [&](int s_i, int s_i1, h8 (&Bf)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int dy = t >> 1, dx = t & 1;
+            const unsigned char* base = lrr + (dy ? s_i : s_i1);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) Bf[t][nt] = *reinterpret_cast<const h8*>(base + lr_b[dx][nt]);
+        }
+    };
+
+    // ---- P1: deconv + PReLU of HR row 4i+2+wv -> operand tiles ob[column phase][pixel tile] (zeros outside the image)
+    auto deconv_row = [&](int i, const h8 (&Bf)[4][2], h8 (&ob)[4][2]) __attribute__((always_inline)) {
+        const int r_hr = 4 * i + 2 + wv;
+        if (r_hr < 0 || r_hr >= H) {
+            h8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) ob[px][nt] = z;
+            return;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f4 acc[2][2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[c][mt][nt] = mfma16(Aup[2 * half + c][t][mt], Bf[t][nt], t == 0 ? bup[mt] : acc[c][mt][nt]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int px = 2 * half + c;
+                    h8 hb = act_pack(acc[c][0][nt], acc[c][1][nt], a_up2, up_max);
+                    const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
+                    const bool col_ok = (c_hr >= 0) && (c_hr < W);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hb[e] = col_ok ? hb[e] : (_Float16)0.0f;
+                    ob[px][nt] = hb;
+                }
+        }
+    };
+
+    // ---- P3: contributions of this HR row to output rows R'+1 (dy 0), R' (dy 1), R'-1 (dy 2) -> partial planes
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    auto ror1 = [&](const h8& src) __attribute__((always_inline)) -> u4v {    // row_ror:1: lane i <- src[(i-1)%16]
+        const u4v s = __builtin_bit_cast(u4v, src);
+        u4v d;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = __builtin_amdgcn_mov_dpp(s[q], 0x121, 0xF, 0xF, true);
+        return d;
+    };
+    auto ror15 = [&](const h8& src) __attribute__((always_inline)) -> u4v {   // row_ror:15: lane i <- src[(i+1)%16]
+        const u4v s = __builtin_bit_cast(u4v, src);
+        u4v d;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = __builtin_amdgcn_mov_dpp(s[q], 0x12F, 0xF, 0xF, true);
+        return d;
+    };
+    auto conv_row = [&](int i, const h8 (&ob)[4][2]) __attribute__((always_inline)) {
+        // phase 3 one position to the left (lane j reads j-1; lane 0 of tile 1 takes lane 15 of tile 0) for (pxo 0, dx 0);
+        // phase 0 one position to the right for (pxo 3, dx 2)
+        h8 shr[2], shl[2];
+        {
+            const u4v t0 = ror1(ob[3][0]);
+            u4v t1;
+            const u4v s1 = __builtin_bit_cast(u4v, ob[3][1]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t1[q] = __builtin_amdgcn_update_dpp(t0[q], s1[q], 0x111, 0xF, 0xF, false);   // row_shr:1, lane 0 keeps tile0[15]
+            shr[0] = __builtin_bit_cast(h8, t0);                      // lane 0 = tile0[15]: feeds only u = 0 (not an output)
+            shr[1] = __builtin_bit_cast(h8, t1);
+            const u4v r1 = ror15(ob[0][1]);
+            u4v r0v;
+            const u4v s0 = __builtin_bit_cast(u4v, ob[0][0]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r0v[q] = __builtin_amdgcn_update_dpp(r1[q], s0[q], 0x101, 0xF, 0xF, false);  // row_shl:1, lane 15 keeps tile1[0]
+            shl[0] = __builtin_bit_cast(h8, r0v);
+            shl[1] = __builtin_bit_cast(h8, r1);                      // lane 15 = tile1[0]: feeds only u = 127
+        }
+        const int Rp = 4 * i + 2 + wv;
+        // lane group g = dy: partial plane of output row Rp + 1 - g (idle group 3 -> dump plane)
+        const int plane = g < 3 ? ((Rp + 1 - g) & (T3_ROWS - 1)) * 3 + g : T3_ROWS * 3;
+        unsigned char* const dst = pb + plane * T3_PLANE + l15 * 64;   // + (16 nt) * 64 + pxo * 16:  u = 4 (16 nt + l15) + pxo
+#pragma unroll
+        for (int pxo = 0; pxo < 4; ++pxo)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int ps = pxo + dx - 1;
+                    const h8 b = ps < 0 ? shr[nt] : (ps > 3 ? shl[nt] : ob[ps][nt]);
+                    acc = mfma16(Ac[dx], b, acc);
+                }
+                *reinterpret_cast<f4*>(dst + nt * 1024 + pxo * 16) = acc;
+            }
+    };
+
+    // ---- finish output row R (all three partials visible): sum + conv bias -> raw[N,3,(4)h,(4)w] fp32.  Lane handles
+    //      u = lane and lane + 64.  The bilinear skip and add_mean are applied where the planes are read next, in the
+    //      fusion-MLP kernel (k_fc_planes_skip): there they cost HBM-bound elementwise time instead of ~0.45 ms of
+    //      dependent gathers inside this MFMA kernel.
+    int cq[2];
+    bool okq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int u = lane + 64 * q;
+        cq[q] = 4 * x0 + u - 2;
+        okq[q] = u >= 2 && u < 126 && cq[q] < W && (!DEC || (cq[q] & 3) == 0);
+    }
+    const float bo[3] = {tpar[0], tpar[1], tpar[2]};
+    auto finish_row = [&](int R) __attribute__((always_inline)) {
+        if (R < 4 * r0 || R >= 4 * r1) return;   // wave-uniform
+        if (DEC && (R & 3) != 0) return;
+        const unsigned char* const src = pb + ((R & (T3_ROWS - 1)) * 3) * T3_PLANE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!okq[q]) continue;
+            const int u = lane + 64 * q;
+            f4 s = *reinterpret_cast<const f4*>(src + u * 16);
+            s += *reinterpret_cast<const f4*>(src + T3_PLANE + u * 16);
+            s += *reinterpret_cast<const f4*>(src + 2 * T3_PLANE + u * 16);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float v = s[ch] + bo[ch];
+                if (!DEC) prefc[(((size_t)n * 3 + ch) * H + R) * W + cq[q]] = v;
+                else prefc[(((size_t)n * 3 + ch) * h + (R >> 2)) * w + (cq[q] >> 2)] = v;
+            }
+        }
+    };
+
+    // ---- march: groups G(r0-1) .. G(r1-1), then two more steps that only finish rows
+    if (lr_loader) {
+        *reinterpret_cast<u4*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
+        *reinterpret_cast<u4*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
+        *reinterpret_cast<u4*>(lrr + lr_slot(r0 + 1) + lr_st) = fetch_lr(r0 + 1);
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int i = r0 - 1; i <= r1 + 1; ++i) {
+        const bool produce = i <= r1 - 1;
+        const u4 nxt = fetch_lr(i + 3);
+        h8 Bf[4][2], ob[4][2];
+        if (produce) load_lr_frags(lr_slot(i), lr_slot(i + 1), Bf);
+        __syncthreads();
+        // rows whose last contribution was stored two steps ago (visible since the previous barrier; their planes are
+        // not rewritten before step i+2): anywhere in this step, so beside the MFMAs
+        finish_row(4 * i - 7 + wv);
+        if (produce) {
+            deconv_row(i, Bf, ob);
+            conv_row(i, ob);
+            if (wv < 3 && lr_loader) *reinterpret_cast<u4*>(lrr + lr_slot(i + 3) + lr_st) = nxt;   // over row i: read above the barrier
+        }
+    }
+}
+
+}  // namespace
+
+namespace vsr {
+
+int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* prefc, int N,
+                 int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream) {
+    typedef void (*kern_t)(const _Float16*, const unsigned char*, const unsigned char*, const float*, float*, int, int, int);
+    static const kern_t kerns[4] = {k_tail3<false, false>, k_tail3<true, false>, k_tail3<false, true>, k_tail3<true, true>};
+    static bool attr_done = false;
+    if (!attr_done) {
+        for (kern_t k : kerns)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS) != hipSuccess)
+                return vsr::fail(VSR_E_LAUNCH, "sr_tail3: cannot reserve %d bytes of LDS", T3_LDS);
+        attr_done = true;
+    }
+    if ((size_t)N * h * w * NF * 2 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail3: input beyond 2 GiB");
+    const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
+    hipLaunchKernelGGL(kerns[(dec ? 2 : 0) + (slopes_le_one ? 1 : 0)], dim3(strips, segs, N), dim3(256), T3_LDS, stream,
+                       (const _Float16*)hid_nhwc, (const unsigned char*)blob, (const unsigned char*)conv3_frags, tail_params,
+                       prefc, h, w, rows_per_seg);
+    return vsr::launched("sr_tail3");
+}
+
+}  // namespace vsr

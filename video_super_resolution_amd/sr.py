@@ -106,6 +106,7 @@ class SRProjectionModule(nn.Module):
         # "fp16": fp16 storage / fp32 accumulate on the MFMA path (the headline configuration);
         # "fp32": every product and sum in float32 (the parity configuration, ~60x slower).
         self.precision = "fp16"
+        self.tail_build = 3   # 3: k_tail3 (csrc/sr_tail3.hip); 1: k_tail (LDS ring; kept as the cross-check)
         self._pack: Optional[dict] = None
         self._pack_key = None
         self._const: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -167,6 +168,7 @@ class SRProjectionModule(nn.Module):
             P["utd2"][j] = pack_utd_blob(*args, layout=2)  # k_utd2 (producer / consumer waves)
         P["utd_out"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0)
         P["cv_frags"] = pack_conv_out_frags(self.conv_out[0].weight)
+        P["cv_frags3"] = pack_conv_out_frags3(self.conv_out[0].weight)
         P["tail_par"] = torch.cat((P["cv_b"], P["sub_s"], P["sub_b"], P["add_s"], P["add_b"])).contiguous()
         P["slopes_le_one"] = all(a <= 1.0 for a in P["up_a"] + P["dn_a"] + P["dt_a"] + [P["out_a"]])
         self._pack, self._pack_key = P, key
@@ -455,12 +457,23 @@ class SRProjectionModule(nn.Module):
         ho, wo = (h, w) if decimate else (4 * h, 4 * w)
         prefc = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
         tok = L.TIMER.start("sr_tail_dec_f16" if decimate else "sr_tail_f16")
+        out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=dev)
+        if self.tail_build == 3 and taps is None:
+            # k_tail3 (one wave per SIMD, registers) writes the raw planes; skip + add_mean ride on the fusion MLP's read
+            L.check(lib.vsr_sr_tail3_f16(L.dptr(hid, torch.float16), L.dptr(P["utd_out"], torch.uint8), L.dptr(P["cv_frags3"], torch.float16),
+                                         L.dptr(P["tail_par"]), L.dptr(prefc), N, h, w, self._rows_per_segment(N, h, w),
+                                         int(P["slopes_le_one"]), int(decimate), L.stream()), "sr_tail3_f16")
+            L.TIMER.stop(tok)
+            L.check(lib.vsr_sr_fc_planes_skip_f32(L.dptr(prefc), L.dptr(x), L.dptr(P["tail_par"]), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]),
+                                                  L.dptr(P["fc_w2"]), L.dptr(P["fc_b2"]), N, P["fc_w1"].shape[0], L.dptr(out), h, w,
+                                                  int(decimate), L.stream()), "sr_fc_planes_skip")
+            return out
+        # k_tail: two waves per SIMD, LDS ring, skip inside the tail (cross-check build; also serves the prefc tap)
         tail = lib.vsr_sr_tail_dec_f16 if decimate else lib.vsr_sr_tail_f16
         L.check(tail(L.dptr(hid, torch.float16), L.dptr(P["utd_out"], torch.uint8), L.dptr(P["cv_frags"], torch.float16),
                      L.dptr(P["tail_par"]), L.dptr(x), L.dptr(prefc), N, h, w, self._rows_per_segment(N, h, w),
                      int(P["slopes_le_one"]), L.stream()), "sr_tail_f16")
         L.TIMER.stop(tok)
-        out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=dev)
         L.check(lib.vsr_sr_fc_planes_f32(L.dptr(prefc), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]), L.dptr(P["fc_w2"]), L.dptr(P["fc_b2"]),
                                          N, P["fc_w1"].shape[0], L.dptr(out), ho * wo, 0, L.stream()), "sr_fc_planes")
         if taps is not None:
@@ -559,6 +572,24 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a,
         fpar[98] = float(dn_a)
     blob[off_f:off_f + 512] = fpar.view(torch.uint8)
     return blob
+
+
+def pack_conv_out_frags3(weight) -> torch.Tensor:
+    """conv_out weight [3,32,3,3] -> the 3 MFMA A-fragments (one per dx) of csrc/sr_tail3.hip:k_tail3, [dx][lane 64][8]
+    fp16: accumulator row m = 4 dy + co holds the contribution of an HR row to output row (HR row + 1 - dy), channel co;
+    k index (g, j) follows the operand tiles' channel order."""
+    dev = weight.device
+    w = weight.detach().float()
+    lane = torch.arange(64, device=dev)
+    m, g = lane & 15, lane >> 4
+    dy, co = m >> 2, m & 3
+    live = (dy < 3) & (co < 3)
+    perm = _chunk_channel_order(dev)  # [4,8]
+    frags = torch.zeros((3, 64, 8), dtype=torch.float32, device=dev)
+    ci = perm[g[live]]  # [n_live, 8]
+    for dx in range(3):
+        frags[dx, live] = w[co[live].unsqueeze(1), ci, dy[live].unsqueeze(1), dx]
+    return frags.to(torch.float16).contiguous()
 
 
 def pack_conv_out_frags(weight) -> torch.Tensor:
