@@ -234,7 +234,13 @@ __global__ void __launch_bounds__(kBlock) k_flow_maxrad(const float* __restrict_
         m = fmaxf(m, __shfl_down(m, off));
         nanflag |= __shfl_down(nanflag, off);
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one atomic per workgroup (thousands of same-address atomics serialised: 89 us for a 512x960 field)
+    __shared__ float sm[kBlock / 64];
+    __shared__ unsigned sn[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = m; sn[threadIdx.x >> 6] = nanflag; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / 64; ++k) { m = fmaxf(m, sm[k]); nanflag |= sn[k]; }
         atomicMax(ws, __float_as_uint(m));
         if (nanflag) atomicOr(ws + 1, 1u);
     }
@@ -393,7 +399,8 @@ int vsr_flow2img_f32(const float* flow, float* out_hwc, void* workspace, int H, 
     if (rc) return rc;
     const size_t hw = (size_t)H * W;
     if (hipMemsetAsync(workspace, 0, 16, vsr::S(stream)) != hipSuccess) return vsr::fail(VSR_E_LAUNCH, "flow2img: memset");
-    hipLaunchKernelGGL(k_flow_maxrad, dim3(grid_for(hw)), dim3(kBlock), 0, vsr::S(stream), flow, (unsigned*)workspace, hw);
+    const unsigned g_max = grid_for(hw) < 256u ? grid_for(hw) : 256u;   // grid-stride: few workgroups, few atomics
+    hipLaunchKernelGGL(k_flow_maxrad, dim3(g_max), dim3(kBlock), 0, vsr::S(stream), flow, (unsigned*)workspace, hw);
     rc = vsr::launched("flow2img/maxrad");
     if (rc) return rc;
     hipLaunchKernelGGL(k_flow_color, dim3(grid_for(hw)), dim3(kBlock), 0, vsr::S(stream), flow,

@@ -183,19 +183,21 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
         // lane group g = dy: partial plane of output row Rp + 1 - g (idle group 3 -> dump plane)
         const int plane = g < 3 ? ((Rp + 1 - g) & (T3_ROWS - 1)) * 3 + g : T3_ROWS * 3;
         unsigned char* const dst = pb + plane * T3_PLANE + l15 * 64;   // + (16 nt) * 64 + pxo * 16:  u = 4 (16 nt + l15) + pxo
+        f4 acc[4][2];   // dx outermost: 8 independent accumulator chains between two MFMAs on the same tile
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int pxo = 0; pxo < 4; ++pxo)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int ps = pxo + dx - 1;
+                    const h8 b = ps < 0 ? shr[nt] : (ps > 3 ? shl[nt] : ob[ps][nt]);
+                    acc[pxo][nt] = mfma16(Ac[dx], b, dx == 0 ? f4{0.0f, 0.0f, 0.0f, 0.0f} : acc[pxo][nt]);
+                }
 #pragma unroll
         for (int pxo = 0; pxo < 4; ++pxo)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int ps = pxo + dx - 1;
-                    const h8 b = ps < 0 ? shr[nt] : (ps > 3 ? shl[nt] : ob[ps][nt]);
-                    acc = mfma16(Ac[dx], b, acc);
-                }
-                *reinterpret_cast<f4*>(dst + nt * 1024 + pxo * 16) = acc;
-            }
+            for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f4*>(dst + nt * 1024 + pxo * 16) = acc[pxo][nt];
     };
 
     // ---- finish output row R (all three partials visible): sum + conv bias -> raw[N,3,(4)h,(4)w] fp32.  Lane handles
