@@ -258,6 +258,12 @@ int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int 
 int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,
                             void* out, int N, int H, int W, int C, vsr_stream_t stream);
 
+/* FlowNetC cost volume + LeakyReLU(0.1) on MFMA (reference networks/FlowNetC.py: Correlation(pad_size=20, kernel_size=1,
+ * max_displacement=20, stride1=1, stride2=2), correlation_cuda_kernel.cu:74-147): feat_a, feat_b [B,H,W,C] fp16 ->
+ * out[b][y][x][out_coff + tj*21 + ti] fp16 (441 channels of an [B,H,W,out_ld] concat buffer), 1/C normalisation. */
+int vsr_flownetc_corr_nhwc_f16(const void* feat_a, const void* feat_b, void* out, int out_ld, int out_coff, int B, int H, int W, int C,
+                               vsr_stream_t stream);
+
 /* ConvTranspose2d(k=4, s=2, p=1) (+bias +activation) as its four 2x2-tap phase convolutions in ONE launch (grid.z walks
  * phase and split-K slice).  w_packed4[py*2+px]: the phase's taps packed like vsr_conv2d_nhwc_f16 weights (kernel rows
  * (3,1) for py = 0, (2,0) for py = 1; same along x).  in [N,H,W,in_ld] -> out [N,2H,2W,out_ld], slice [out_coff,+cout). */

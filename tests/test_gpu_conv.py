@@ -98,3 +98,23 @@ def test_transposed_conv_k4s2(shape):
     got = igemm.to_nchw_float(dc(igemm.to_nhwc_half(x)), cout)
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 120, 256), (1, 13, 37, 256), (1, 8, 15, 64)])
+def test_flownetc_cost_volume_mfma(shape):
+    """MFMA cost volume + LeakyReLU written into a concat-buffer slice, against the float32 Correlation kernel (itself
+    pinned to the reference's CUDA kernel by tests/test_gpu_flow_ops.py) on the same fp16-rounded features."""
+    import ctypes
+    from video_super_resolution_amd import _lib as L, ops
+    B, H, W, C = shape
+    rs = np.random.RandomState(H * W)
+    a = torch.from_numpy(rs.randn(B, H, W, C).astype(np.float32)).cuda().half()
+    b = torch.from_numpy(rs.randn(B, H, W, C).astype(np.float32)).cuda().half()
+    ref = F.leaky_relu(ops.correlation(a.permute(0, 3, 1, 2).float().contiguous(), b.permute(0, 3, 1, 2).float().contiguous(),
+                                       20, 1, 20, 1, 2), 0.1)                       # [B,441,H,W]
+    out = torch.full((B, H, W, 480), 7.0, dtype=torch.float16, device="cuda")
+    L.check(L.load().vsr_flownetc_corr_nhwc_f16(L.dptr(a, torch.float16), L.dptr(b, torch.float16), L.dptr(out, torch.float16), 480, 32,
+                                                B, H, W, C, L.stream()))
+    got = out[..., 32:473].permute(0, 3, 1, 2).float()
+    assert (got - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    assert float((out[..., :32] - 7.0).abs().max()) == 0.0 and float((out[..., 473:] - 7.0).abs().max()) == 0.0   # slice only

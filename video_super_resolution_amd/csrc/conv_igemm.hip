@@ -554,6 +554,83 @@ __global__ void __launch_bounds__(256) k_osvos_fuse(const OsvosP p) {
     p.out[i] = acc;
 }
 
+// ---- FlowNetC cost volume on MFMA, NHWC fp16 in, straight into the concat buffer (reference FlowNetC.py: Correlation(pad 20,
+//      kernel 1, max_disp 20, stride1 1, stride2 2) + LeakyReLU(0.1); correlation_cuda_kernel.cu:74-147).
+//      out[b][y][x][coff + (tj*21 + ti)] = lrelu( 1/C * sum_c a[b][y][x][c] * bb[b][y + 2(tj-10)][x + 2(ti-10)][c] ).
+//      Workgroup = 32 pixels of one row; wave w takes the vertical displacements tj = w, w+4, ...  For one tj the full
+//      product G = A^T B of the 32 pixels against the 72-column window of row y2 is 80 MFMAs (M = pixels, N = window
+//      columns, K = C = 256) -- 3.4x more products than the band the volume keeps, but ~10 us of MFMA time for the whole
+//      map against 350 us of LDS-bound scalar FMAs in k_correlation; the band (column - pixel even, 0..40) is picked out
+//      of the accumulator tiles into an LDS image [32][441] and written as contiguous 882-byte pixel vectors.
+constexpr int CORR_D = 21, CORR_OC = CORR_D * CORR_D;
+__global__ void __launch_bounds__(256) k_corr_mfma(const _Float16* __restrict__ a, const _Float16* __restrict__ bb,
+                                                   _Float16* __restrict__ out, int out_ld, int out_coff, int H, int W, int C) {
+    __shared__ _Float16 stage[32 * CORR_OC];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int x0 = blockIdx.x * 32, y = blockIdx.y, b = blockIdx.z;
+    const int nks = C >> 5;   // 8 for C = 256
+    const size_t img = (size_t)b * H * W;
+    h8 Af[2][8];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int px = x0 + 16 * mt + l15;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            h8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.0f;
+            if (px < W && ks < nks) v = *reinterpret_cast<const h8*>(a + (img + (size_t)y * W + px) * C + 32 * ks + 8 * g);
+            Af[mt][ks] = v;
+        }
+    }
+    const float inv = 1.0f / (float)C;
+    for (int tj = wv; tj < CORR_D; tj += 4) {
+        const int y2 = y + 2 * (tj - 10);
+        f4 acc[2][5];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (y2 >= 0 && y2 < H) {   // wave-uniform; a row outside the image contributes zeros (the padding)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                const int col = x0 - 20 + 16 * nt + l15;
+                const bool ok = col >= 0 && col < W;
+                const _Float16* src = bb + (img + (size_t)y2 * W + (ok ? col : 0)) * C + 8 * g;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    h8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.0f;
+                    if (ok && ks < nks) v = *reinterpret_cast<const h8*>(src + 32 * ks);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[mt][ks], v, acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        // band: window column cl = 16 nt + l15, pixel pl = 16 mt + 4 g + r; cl - pl = 2 ti
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pl = 16 * mt + 4 * g + r, d = 16 * nt + l15 - pl;
+                    if (d >= 0 && d <= 40 && (d & 1) == 0) {
+                        float v = acc[mt][nt][r] * inv;
+                        v = v >= 0.0f ? v : 0.1f * v;
+                        stage[pl * CORR_OC + tj * CORR_D + (d >> 1)] = (_Float16)v;
+                    }
+                }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * CORR_OC; idx += 256) {
+        const int pl = idx / CORR_OC, tc = idx - pl * CORR_OC;
+        if (x0 + pl < W) out[(img + (size_t)y * W + x0 + pl) * out_ld + out_coff + tc] = stage[idx];
+    }
+}
+
 static int g_splitk_fill = 256;   // split K when a launch has fewer workgroups than this (measured: tools/probe_splitk.py)
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal (tuning hook)
 
@@ -610,6 +687,16 @@ int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, in
     p.ld = ld; p.bias = bias; p.out = out; p.N = N; p.h = h; p.w = w; p.nb = nbranch;
     hipLaunchKernelGGL(k_osvos_fuse, dim3(vsr::cdiv((long long)N * h * w, 256)), dim3(256), 0, vsr::S(stream), p);
     return vsr::launched("osvos_fuse");
+}
+
+int vsr_flownetc_corr_nhwc_f16(const void* feat_a, const void* feat_b, void* out, int out_ld, int out_coff, int B, int H, int W, int C,
+                               vsr_stream_t stream) {
+    VSR_REQUIRE(feat_a && feat_b && out, "flownetc_corr: null pointer");
+    VSR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && (C & 31) == 0 && C <= 256, "flownetc_corr: C must be a multiple of 32 up to 256");
+    VSR_REQUIRE(out_coff >= 0 && out_coff + CORR_OC <= out_ld && B <= 65535 && H <= 65535, "flownetc_corr: output slice / grid");
+    hipLaunchKernelGGL(k_corr_mfma, dim3(vsr::cdiv(W, 32), H, B), dim3(256), 0, vsr::S(stream), (const _Float16*)feat_a,
+                       (const _Float16*)feat_b, (_Float16*)out, out_ld, out_coff, H, W, C);
+    return vsr::launched("flownetc_corr");
 }
 
 int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* const* w_packed4, const float* bias, void* out,

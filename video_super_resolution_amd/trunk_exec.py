@@ -253,13 +253,13 @@ class _FlowNetCExec:
         both[B:, ..., :3] = x6[..., 3:6]
         c2 = self.conv2(self.conv1(both))           # [2B,H/4,W/4,128]
         c3 = self.conv3(c2)                         # [2B,H/8,W/8,256]
-        a3, b3 = c3[:B], c3[B:]
-        corr = ops.correlation(a3.permute(0, 3, 1, 2).float().contiguous(), b3.permute(0, 3, 1, 2).float().contiguous(),
-                               20, 1, 20, 1, 2)     # fp32 NCHW cost volume kernel
+        a3, b3 = c3[:B], c3[B:]                     # contiguous halves of the batched encoder output
         h8, w8 = H // 8, W // 8
         cat31 = cached_zeros(self, "cat31", (B, h8, w8, pad32(473)), dev)
-        self.redir(a3.contiguous(), out=cat31, out_coff=0)
-        cat31[..., 32:473] = F.leaky_relu(corr, 0.1).permute(0, 2, 3, 1)
+        self.redir(a3, out=cat31, out_coff=0)
+        # cost volume + LeakyReLU straight into channels [32, 473) of the concat buffer (MFMA, fp16 NHWC)
+        L.check(L.load().vsr_flownetc_corr_nhwc_f16(L.dptr(a3, torch.float16), L.dptr(b3, torch.float16), L.dptr(cat31, torch.float16),
+                                                    cat31.shape[3], 32, B, h8, w8, c3.shape[3], L.stream()), "flownetc_corr")
         cats = [self.refine.alloc_cat(i, B, H >> (5 - i), W >> (5 - i), dev) for i in range(4)]
         cats[3][..., :128] = c2[:B]                 # out_conv2a
         self.conv3_1(cat31, out=cats[2], out_coff=0)
