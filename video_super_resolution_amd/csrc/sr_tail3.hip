@@ -120,6 +120,7 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
             f4 acc[2][2][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+                if (DEC && half == 0 && c == 0) continue;   // column phase 0 is not read when only pixels (4i,4j) are kept
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -133,6 +134,7 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const int px = 2 * half + c;
+                    if (DEC && px == 0) { ob[0][nt] = Bf[0][nt]; continue; }   // (never read; any defined value)
                     h8 hb = act_pack(acc[c][0][nt], acc[c][1][nt], a_up2, up_max);
                     const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
                     const bool col_ok = (c_hr >= 0) && (c_hr < W);
@@ -163,7 +165,8 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
         // phase 3 one position to the left (lane j reads j-1; lane 0 of tile 1 takes lane 15 of tile 0) for (pxo 0, dx 0);
         // phase 0 one position to the right for (pxo 3, dx 2)
         h8 shr[2], shl[2];
-        {
+        if (DEC) { shr[0] = shr[1] = shl[0] = shl[1] = ob[1][0]; }   // unused in DEC mode (phase 2 needs no shifted tile)
+        else {
             const u4v t0 = ror1(ob[3][0]);
             u4v t1;
             const u4v s1 = __builtin_bit_cast(u4v, ob[3][1]);
@@ -190,6 +193,7 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
             for (int pxo = 0; pxo < 4; ++pxo)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
+                    if (DEC && pxo != 2) continue;   // kept pixels have C = 0 (mod 4), i.e. u = 2 (mod 4)
                     const int ps = pxo + dx - 1;
                     const h8 b = ps < 0 ? shr[nt] : (ps > 3 ? shl[nt] : ob[ps][nt]);
                     acc[pxo][nt] = mfma16(Ac[dx], b, dx == 0 ? f4{0.0f, 0.0f, 0.0f, 0.0f} : acc[pxo][nt]);
@@ -197,7 +201,10 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
 #pragma unroll
         for (int pxo = 0; pxo < 4; ++pxo)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f4*>(dst + nt * 1024 + pxo * 16) = acc[pxo][nt];
+            for (int nt = 0; nt < 2; ++nt) {
+                if (DEC && pxo != 2) continue;
+                *reinterpret_cast<f4*>(dst + nt * 1024 + pxo * 16) = acc[pxo][nt];
+            }
     };
 
     // ---- finish output row R (all three partials visible): sum + conv bias -> raw[N,3,(4)h,(4)w] fp32.  Lane handles
@@ -250,9 +257,11 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
         // rows whose last contribution was stored two steps ago (visible since the previous barrier; their planes are
         // not rewritten before step i+2): anywhere in this step, so beside the MFMAs
         finish_row(4 * i - 7 + wv);
-        if (produce) {
+        if (produce && !(DEC && wv == 0)) {   // DEC: HR row 4i+2 feeds output rows 4i+1..4i+3 only, none of them kept
             deconv_row(i, Bf, ob);
             conv_row(i, ob);
+        }
+        if (produce) {
             if (wv < 3 && lr_loader) *reinterpret_cast<u4*>(lrr + lr_slot(i + 3) + lr_st) = nxt;   // over row i: read above the barrier
         }
     }
