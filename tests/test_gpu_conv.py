@@ -52,6 +52,33 @@ def test_conv_matches_torch(case):
         assert float(out[..., cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", [  # (N, Cin, H, W, Cout, k, act): the LDS-patch builds, forced (the heuristic wants >= 8192 pixels)
+    (1, 64, 37, 61, 16, 11, igemm.ACT_RELU), (2, 64, 20, 50, 16, 7, igemm.ACT_RELU), (1, 32, 9, 40, 16, 5, igemm.ACT_RELU),
+    (1, 96, 33, 47, 16, 3, igemm.ACT_LEAKY), (2, 64, 37, 61, 1, 3, igemm.ACT_NONE), (1, 194, 33, 47, 2, 3, igemm.ACT_NONE),
+    (1, 64, 41, 77, 32, 7, igemm.ACT_RELU), (1, 64, 19, 33, 64, 5, igemm.ACT_RELU), (1, 32, 130, 70, 13, 11, igemm.ACT_RELU)])
+@pytest.mark.parametrize("mode", [2, 1])
+def test_patch_kernels_match_torch(case, mode):
+    """mode 2: every legal layer through k_conv_patch / k_conv_patch_rows; mode 1: the same layers through the gather kernel."""
+    from video_super_resolution_amd import _lib as L
+    N, cin, H, W, cout, k, act = case
+    rs = np.random.RandomState(cin + 31 * cout + k)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.conv2d(x.float(), w, b, stride=1, padding=k // 2)
+    ref = F.relu(ref) if act == igemm.ACT_RELU else (F.leaky_relu(ref, 0.1) if act == igemm.ACT_LEAKY else ref)
+    conv = igemm.HConv(w, b, stride=1, pad=k // 2, act=act)
+    old = L.load().vsr_conv2d_tuning(mode)
+    try:
+        out = conv(igemm.to_nhwc_half(x))
+        torch.cuda.synchronize()
+    finally:
+        L.load().vsr_conv2d_tuning(old)
+    got = igemm.to_nchw_float(out, cout)
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("case", [(2, 3, 37, 45, 128, 7, 1, 3, igemm.ACT_RELU), (4, 3, 64, 96, 64, 7, 2, 3, igemm.ACT_LEAKY),
                                   (1, 3, 33, 29, 64, 3, 1, 1, igemm.ACT_RELU), (1, 4, 20, 20, 16, 5, 1, 2, igemm.ACT_NONE)])
 def test_stem_conv_matches_torch(case):

@@ -1,0 +1,27 @@
+"""A/B in one process: hourglass (x4 batch and x1) with and without the row-reuse build of the 16-out-channel patch kernel."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from video_super_resolution_amd import VSR, _lib as L
+from video_super_resolution_amd.weights import fill_module_
+torch.set_grad_enabled(False)
+h, w = 540, 960
+m = fill_module_(VSR().eval(), 0).cuda()
+fr = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (4, h, w, 3)).astype(np.float32)).cuda()
+hx = m._depth_exec.get()
+def t(fn, reps=6):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+outs = {}
+for rnd in range(2):
+    for mode in (3, 0):
+        L.load().vsr_conv2d_tuning(mode)
+        outs[mode] = hx(fr).clone()
+        print(f"mode {mode} ({'row-reuse' if mode == 0 else 'k_conv_patch<1>'}): depth x4 {t(lambda: hx(fr)):.3f} ms   x1 {t(lambda: hx(fr[:1])):.3f} ms")
+L.load().vsr_conv2d_tuning(0)
+d = (outs[0].float() - outs[3].float()).abs().max().item()
+print(f"max |difference| of the depth maps {d:.4g} of range {outs[3].float().abs().max().item():.4g}")

@@ -426,6 +426,98 @@ __global__ void __launch_bounds__(256) k_conv_patch(const ConvP p) {
     }
 }
 
+// The 16-out-channel case of the patch kernel (the hourglass's 16-wide 3x3..11x11 inception branches and its final
+// conv): with one out-channel tile every pixel operand read from LDS feeds a single MFMA, and four waves issuing one
+// ds_read_b128 per MFMA ask the LDS for twice what it delivers.  The operand of (output row y, tap row ky) is the
+// operand of (y+1, ky-1): a wave therefore owns 4 rows x 16 columns of the tile, reads each patch row once per tap
+// column and feeds it to the (up to) four output rows it belongs to -- KH+3 reads for 4 KH MFMAs.  The KH weight
+// fragments of the current tap column stay in registers (fetched one tap column ahead from L2).
+template <int KH>
+__global__ void __launch_bounds__(256) k_conv_patch_rows(const ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    const int PH = PT_H + KH - 1, PW = PT_W + p.kw - 1;
+    unsigned char* const patch = psm;                      // [PH][PW] pixels of 64 B (chunk XOR pixel-column bits 1-2)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tiles_x = (p.Wo + PT_W - 1) / PT_W;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int n = blockIdx.y;
+    const int oy0 = ty * PT_H, ox0 = tx * PT_W;
+    const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+    const int nchunk = p.cin >> 5;
+    const int ry0 = 4 * (wv >> 1), cx0 = 16 * (wv & 1);    // this wave's 4 x 16 pixels of the 8 x 32 tile
+
+    f4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    auto wfrag = [&](int ky, int kx, int ch) __attribute__((always_inline)) {
+        return *reinterpret_cast<const h8*>(p.wpk + ((size_t)((ky * p.kw + kx) * nchunk + ch) * 16 + l15) * 32 + 8 * g);
+    };
+    auto column = [&](int kx, const h8 (&af)[KH]) __attribute__((always_inline)) {
+        const int px = cx0 + l15 + kx;
+        const unsigned char* src = patch + (ry0 * PW + px) * 64 + ((g ^ ((px >> 1) & 3)) << 4);
+#pragma unroll
+        for (int pr = 0; pr < KH + 3; ++pr) {
+            const h8 bf = *reinterpret_cast<const h8*>(src + pr * PW * 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ky = pr - r;
+                if (ky >= 0 && ky < KH) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ky], bf, acc[r], 0, 0, 0);
+            }
+        }
+    };
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();
+        for (int q = tid; q < PH * PW * 4; q += 256) {
+            const int pix = q >> 2, c4 = q & 3;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                v = *reinterpret_cast<const uint4*>(p.in + (((size_t)n * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + ch * 32 + c4 * 8);
+            *reinterpret_cast<uint4*>(patch + pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4)) = v;
+        }
+        h8 a0[KH], a1[KH];
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) a0[ky] = wfrag(ky, 0, ch);
+        __syncthreads();
+        for (int kx = 0; kx < p.kw; kx += 2) {   // two tap columns per trip: the weight sets swap roles without copies
+            const int k1 = kx + 1 < p.kw ? kx + 1 : kx, k2 = kx + 2 < p.kw ? kx + 2 : kx;
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) a1[ky] = wfrag(ky, k1, ch);
+            column(kx, a0);
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) a0[ky] = wfrag(ky, k2, ch);
+            if (kx + 1 < p.kw) column(kx + 1, a1);
+        }
+    }
+    // lane holds channels 4g .. 4g+3 of pixels (ry0 + r, cx0 + l15)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oy = oy0 + ry0 + r, ox = ox0 + cx0 + l15;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
+                        p.out_coff;
+        const int c = 4 * g;
+        if (c >= p.cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float tt = acc[r][e] + (p.bias ? p.bias[c + e] : 0.0f);
+            if (p.act == 1) tt = fmaxf(tt, 0.0f);
+            else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
+            v[e] = tt;
+        }
+        if (c + 4 <= p.cout && ((p.out_coff + c) & 3) == 0 && (p.out_ld & 3) == 0) {
+            *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < p.cout) dst[c + e] = (_Float16)v[e];
+        }
+    }
+}
+
 // sums the split-K partials in a fixed order, + bias, activation, fp16 store (4 channels per thread)
 __global__ void __launch_bounds__(256) k_splitk_finish(const ConvP p) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
@@ -632,7 +724,7 @@ __global__ void __launch_bounds__(256) k_corr_mfma(const _Float16* __restrict__ 
 }
 
 static int g_splitk_fill = 256;   // split K when a launch has fewer workgroups than this (measured: tools/probe_splitk.py)
-static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal (tuning hook)
+static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse build (tuning hook)
 
 extern "C" {
 
@@ -807,6 +899,14 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
             hipLaunchKernelGGL(k_conv_patch<4>, dim3(tiles, N, cout_pad / 64), dim3(256), patch_lds, vsr::S(stream), p);
         else if ((cout_pad & 31) == 0)
             hipLaunchKernelGGL(k_conv_patch<2>, dim3(tiles, N, cout_pad / 32), dim3(256), patch_lds, vsr::S(stream), p);
+        else if (cout_pad == 16 && kh == 3 && g_patch_mode != 3)
+            hipLaunchKernelGGL(k_conv_patch_rows<3>, dim3(tiles, N, 1), dim3(256), patch_lds, vsr::S(stream), p);
+        else if (cout_pad == 16 && kh == 5 && g_patch_mode != 3)
+            hipLaunchKernelGGL(k_conv_patch_rows<5>, dim3(tiles, N, 1), dim3(256), patch_lds, vsr::S(stream), p);
+        else if (cout_pad == 16 && kh == 7 && g_patch_mode != 3)
+            hipLaunchKernelGGL(k_conv_patch_rows<7>, dim3(tiles, N, 1), dim3(256), patch_lds, vsr::S(stream), p);
+        else if (cout_pad == 16 && kh == 11 && g_patch_mode != 3)
+            hipLaunchKernelGGL(k_conv_patch_rows<11>, dim3(tiles, N, 1), dim3(256), patch_lds, vsr::S(stream), p);
         else
             hipLaunchKernelGGL(k_conv_patch<1>, dim3(tiles, N, cout_pad / 16), dim3(256), patch_lds, vsr::S(stream), p);
         return vsr::launched("conv2d_nhwc_f16/patch");

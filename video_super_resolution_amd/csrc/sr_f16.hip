@@ -499,39 +499,46 @@ k_chain1x1_h(const ChainP cp, size_t P, size_t total_px) {
 //      (8 tiles), K = 27 taps padded to 32, B = the mean-shifted 3x3x3 neighbourhood gathered by the lanes (zero
 //      padding applies after the mean shift).  Its accumulator tiles are PReLU'd, packed and used in place as the B
 //      operand of the 1x1 (K = 128 in four steps; weight K order permuted to the accumulator's channel order).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const float* __restrict__ sub_bias,
          const float* __restrict__ w_in, const float* __restrict__ b_in, float slope_in, int nmid,
          const float* __restrict__ w_feat, const float* __restrict__ b_feat, float slope_feat, _Float16* __restrict__ out,
          int N, int h, int w) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, g = lane >> 4;
-    const size_t hw = (size_t)h * w, total = (size_t)N * hw;
-    // A1[mt]: conv_in weights, row = mid channel 16 mt + l15, k = 8 g + j -> (c, dy, dx) = (k / 9, (k % 9) / 3, k % 3)
-    h8 A1[8], A2[4][2];
+    const size_t hw = (size_t)h * w;
+    __shared__ __attribute__((aligned(16))) float bias_in[128];   // conv_in bias: accumulator seeds, one ds_read_b128 per tile
+    if (threadIdx.x < 128) bias_in[threadIdx.x] = b_in[threadIdx.x];
+    // weight fragments live in LDS in lane order (conflict-free ds_read_b128 at the point of use: 16 per tile), which
+    // leaves the registers to four resident waves per SIMD -- the gather's load latency is what this kernel has to hide.
+    // A1[mt]: conv_in, row = mid channel 16 mt + l15, k = 8 g + j -> (c, dy, dx) = (k / 9, (k % 9) / 3, k % 3)
+    // A2[s][mt2]: feat_in, row = out channel 16 mt2 + l15, k step s covers mids 32 s + {4g+j | 16+4g+j-4}
+    __shared__ __attribute__((aligned(16))) h8 A1s[8][64], A2s[4][2][64];
+    {
+        const int wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        h8 a;
+        for (int q = 0; q < 2; ++q) {
+            const int mt = 2 * wv + q;
+            h8 a;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 8 * g + j;
-            a[j] = k < 27 ? (_Float16)w_in[(16 * mt + l15) * 27 + k] : (_Float16)0.0f;
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * g + j;
+                a[j] = k < 27 ? (_Float16)w_in[(16 * mt + l15) * 27 + k] : (_Float16)0.0f;
+            }
+            A1s[mt][lane] = a;
         }
-        A1[mt] = a;
-    }
-    // A2[s][mt2]: feat_in weights, row = out channel 16 mt2 + l15, k step s covers mids 32 s + {4g+j | 16+4g+j-4}
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
         for (int mt2 = 0; mt2 < 2; ++mt2) {
             h8 a;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int mid = 32 * s4 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+                const int mid = 32 * wv + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
                 a[j] = (_Float16)w_feat[(16 * mt2 + l15) * nmid + mid];
             }
-            A2[s4][mt2] = a;
+            A2s[wv][mt2][lane] = a;
         }
+    }
+    __syncthreads();
     const h2 a1 = {(_Float16)slope_in, (_Float16)slope_in}, a2 = {(_Float16)slope_feat, (_Float16)slope_feat};
     const bool max1 = slope_in <= 1.0f, max2 = slope_feat <= 1.0f;
     // this lane's 8 taps of the 27 (k = 8g + j): channel and offsets are lane constants
@@ -546,30 +553,56 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
         ts[j] = k < 27 ? sub_scale[tc[j]] : 0.0f;
         tb[j] = k < 27 ? sub_bias[tc[j]] : 0.0f;
     }
-    const size_t ntiles = (total + 15) / 16;
-    const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
-    for (size_t tile = wave0; tile < ntiles; tile += nwaves) {
-        const size_t px = tile * 16 + l15;
-        const size_t pc = px < total ? px : total - 1;
-        const int n = (int)(pc / hw);
-        const int rem = (int)(pc - (size_t)n * hw);
-        const int y = rem / w, xx = rem - y * w;
-        h8 bfrag;
+    // tiles are 16 pixels of one image row (wave-uniform row decode, 32-bit); the eight taps of a lane are loaded from
+    // clamped coordinates with no branch (all in flight together, padding selected afterwards), one tile ahead of the
+    // MFMAs that use them
+    const unsigned tpr = (unsigned)(w + 15) >> 4;
+    const unsigned ntiles = (unsigned)N * (unsigned)h * tpr;
+    const unsigned wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
+    auto gather = [&](unsigned tile, float (&raw)[8], unsigned& okmask, unsigned& row_out) __attribute__((always_inline)) {
+        const unsigned row = tile / tpr, xt = tile - row * tpr;   // row = n * h + y
+        const unsigned n = row / (unsigned)h;
+        const int y = (int)(row - n * (unsigned)h), xx = (int)(16 * xt) + l15;
+        const float* const img = x + (size_t)n * 3 * hw;
+        unsigned m = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int yy = y + tdy[j], xc = xx + tdx[j];
-            float t = 0.0f;
-            if (yy >= 0 && yy < h && xc >= 0 && xc < w) t = x[((size_t)n * 3 + tc[j]) * hw + (size_t)yy * w + xc] * ts[j] + tb[j];
-            bfrag[j] = (_Float16)t;
+            const bool ok = yy >= 0 && yy < h && xc >= 0 && xc < w;
+            const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy), xl = xc < 0 ? 0 : (xc >= w ? w - 1 : xc);
+            raw[j] = img[(size_t)tc[j] * hw + (size_t)yc * w + xl];
+            m |= ok ? (1u << j) : 0u;
         }
+        okmask = m;
+        row_out = row;
+    };
+    float cur[8];
+    unsigned curm = 0, cur_row = 0;
+    if (wave0 < ntiles) gather(wave0, cur, curm, cur_row);
+    for (unsigned tile = wave0; tile < ntiles; tile += nwaves) {
+        float nxr[8];
+        unsigned nxm, nx_row;
+        const unsigned tnext = tile + nwaves < ntiles ? tile + nwaves : tile;
+        gather(tnext, nxr, nxm, nx_row);
+        const unsigned xt = tile - cur_row * tpr;
+        const int xx = (int)(16 * xt) + l15;
+        const size_t px = (size_t)cur_row * w + (xx < w ? xx : w - 1);
+        const bool px_ok = xx < w;
+        h8 bfrag;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = cur[j] * ts[j] + tb[j];
+            bfrag[j] = (curm >> j) & 1u ? (_Float16)t : (_Float16)0.0f;
+        }
+        unsigned loff = lane * 16, boff = g * 16;
+        asm volatile("" : "+v"(loff), "+v"(boff));   // opaque per trip: the weight reads stay in the loop (hoisted they cost the occupancy)
+        const unsigned char* const a1p = reinterpret_cast<const unsigned char*>(&A1s[0][0]) + loff;
+        const unsigned char* const a2p = reinterpret_cast<const unsigned char*>(&A2s[0][0][0]) + loff;
+        const unsigned char* const bp = reinterpret_cast<const unsigned char*>(&bias_in[0]) + boff;
         f4 acc1[8];
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            f4 bz;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bz[r] = b_in[16 * mt + 4 * g + r];
-            acc1[mt] = mfma16(A1[mt], bfrag, bz);
-        }
+        for (int mt = 0; mt < 8; ++mt)
+            acc1[mt] = mfma16(*reinterpret_cast<const h8*>(a1p + mt * 1024), bfrag, *reinterpret_cast<const f4*>(bp + mt * 64));
         f4 acc2[2];
 #pragma unroll
         for (int mt2 = 0; mt2 < 2; ++mt2)
@@ -579,9 +612,9 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
         for (int s4 = 0; s4 < 4; ++s4) {
             const h8 mid = act_pack(acc1[2 * s4], acc1[2 * s4 + 1], a1, max1);
 #pragma unroll
-            for (int mt2 = 0; mt2 < 2; ++mt2) acc2[mt2] = mfma16(A2[s4][mt2], mid, acc2[mt2]);
+            for (int mt2 = 0; mt2 < 2; ++mt2) acc2[mt2] = mfma16(*reinterpret_cast<const h8*>(a2p + (2 * s4 + mt2) * 1024), mid, acc2[mt2]);
         }
-        if (px < total) {
+        if (px_ok) {
             typedef float f2v __attribute__((ext_vector_type(2)));
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -591,6 +624,10 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
                 *reinterpret_cast<h4*>(out + px * NF + 16 * mt2 + 4 * g) = h4{p0[0], p0[1], p1[0], p1[1]};
             }
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cur[j] = nxr[j];
+        curm = nxm;
+        cur_row = nx_row;
     }
 }
 
@@ -1166,7 +1203,8 @@ int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bi
     VSR_REQUIRE(x && sub_scale3 && sub_bias3 && w_in && b_in && w_feat && b_feat && out_nhwc, "sr_head_f16: null pointer");
     VSR_REQUIRE(N > 0 && h > 0 && w > 0, "sr_head_f16: bad shape");
     if (nmid != 128) return vsr::fail(VSR_E_UNSUPPORTED, "sr_head_f16: %d mid channels (the reference has 4 x 32)", nmid);
-    const size_t tiles = ((size_t)N * h * w + 15) / 16;
+    VSR_REQUIRE((long long)N * h * ((w + 15) / 16) < (1ll << 31), "sr_head_f16: too many pixels");
+    const size_t tiles = (size_t)N * h * ((w + 15) / 16);   // 16 pixels of one row each
     const unsigned grid = (unsigned)(tiles / 4 + 1 < 2048 ? tiles / 4 + 1 : 2048);  // 4 waves per block, grid-stride
     hipLaunchKernelGGL(k_head_h, dim3(grid), dim3(256), 0, vsr::S(stream), x, sub_scale3, sub_bias3, w_in, b_in, slope_in,
                        nmid, w_feat, b_feat, slope_feat, (_Float16*)out_nhwc, N, h, w);

@@ -369,7 +369,9 @@ class SRProjectionModule(nn.Module):
             o = torch.empty((N, P, _NF), dtype=torch.float16, device=dev) if keep[s] else None
             d.out = L.dptr(o, torch.float16).value if o is not None else None
             outs.append(o)
+        tok = L.TIMER.start(f"sr_chain1x1_f16 x{len(stages)}") if L.TIMER.enabled else None
         L.check(L.load().vsr_sr_chain1x1_f16(ctypes.byref(c), N, P, L.stream()), "sr_chain1x1_f16")
+        L.TIMER.stop(tok)
         return outs
 
     @staticmethod
@@ -410,9 +412,11 @@ class SRProjectionModule(nn.Module):
             self._const_nhwc[(h, w)] = cmap.t().contiguous()  # [h*w, 32] fp32, added before the activation
         cmap_nhwc = self._const_nhwc[(h, w)]
         feat = torch.empty((N, hp, _NF), dtype=torch.float16, device=dev)
+        tok = L.TIMER.start("sr_head_f16") if L.TIMER.enabled else None
         L.check(lib.vsr_sr_head_f16(L.dptr(x), L.dptr(P["sub_s"]), L.dptr(P["sub_b"]), L.dptr(P["w_in"]), L.dptr(P["b_in"]),
                                     L.cf(P["a_in"]), P["w_in"].shape[0], L.dptr(P["w_feat"]), L.dptr(P["b_feat"]),
                                     L.cf(P["a_feat"]), L.dptr(feat, torch.float16), N, h, w, L.stream()), "sr_head_f16")
+        L.TIMER.stop(tok)
         nchw = lambda t: t.view(N, h, w, _NF).permute(0, 3, 1, 2).float()
         if taps is not None:
             taps["feat_in"] = nchw(feat)
@@ -464,9 +468,11 @@ class SRProjectionModule(nn.Module):
                                          L.dptr(P["tail_par"]), L.dptr(prefc), N, h, w, self._rows_per_segment(N, h, w),
                                          int(P["slopes_le_one"]), int(decimate), L.stream()), "sr_tail3_f16")
             L.TIMER.stop(tok)
+            tok = L.TIMER.start("sr_fc_planes_skip_dec" if decimate else "sr_fc_planes_skip") if L.TIMER.enabled else None
             L.check(lib.vsr_sr_fc_planes_skip_f32(L.dptr(prefc), L.dptr(x), L.dptr(P["tail_par"]), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]),
                                                   L.dptr(P["fc_w2"]), L.dptr(P["fc_b2"]), N, P["fc_w1"].shape[0], L.dptr(out), h, w,
                                                   int(decimate), L.stream()), "sr_fc_planes_skip")
+            L.TIMER.stop(tok)
             return out
         # k_tail: two waves per SIMD, LDS ring, skip inside the tail (cross-check build; also serves the prefc tap)
         tail = lib.vsr_sr_tail_dec_f16 if decimate else lib.vsr_sr_tail_f16
