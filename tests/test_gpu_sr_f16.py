@@ -167,3 +167,24 @@ def test_tail_builds_agree(gpu_vsr_f16, shape, decimate):
         m.tail_build = 3
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (9, 40), (37, 33), (2, 2), (1, 7)])
+def test_chain_builds_bit_identical(gpu_vsr_f16, shape):
+    """The 1x1 glue through the streaming builds (specialised on the launch shape, operands requested one tile ahead,
+    weights in LDS) against the generic chain kernel: the same MFMAs in the same order, so the frames are equal bit for bit."""
+    from video_super_resolution_amd import _lib as L
+    m = gpu_vsr_f16.model
+    h, w = shape
+    x = torch.from_numpy(np.random.RandomState(h * 11 + w).randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    lib = L.load()
+    try:
+        with torch.no_grad():
+            lib.vsr_sr_chain_variant(1)
+            ref = m(x).clone()
+            lib.vsr_sr_chain_variant(0)
+            got = m(x)
+    finally:
+        lib.vsr_sr_chain_variant(0)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref)

@@ -494,6 +494,104 @@ k_chain1x1_h(const ChainP cp, size_t P, size_t total_px) {
     }
 }
 
+// The same chain, specialised at compile time on the stage count, on which stages read memory (bit 2s+t of MIN: stage s
+// reads in[t]) and on whether stage 0 adds the constant map: the shapes the FeedbackBlock glue actually launches.  These
+// launches are pure HBM streams (one to four 265 MB tensors in, one out), so the kernel is built around the loads:
+// every memory operand of the NEXT tile is requested before the current tile's MFMAs (no branch between a load and its
+// use), weight fragments and biases sit in LDS (read at the point of use, so five waves per SIMD stay resident) and
+// offsets are 32-bit.
+template <int NS, int MIN, bool CMAP0>
+__global__ void __launch_bounds__(256)
+k_chain1x1_s(const ChainP cp, unsigned P, unsigned total_px) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    __shared__ __attribute__((aligned(16))) h8 As[NS][3][2][64];
+    __shared__ __attribute__((aligned(16))) float bs[NS][32];
+    for (int q = wv; q < NS * 6; q += 4) {   // fragment q = (stage, operand, out-channel tile)
+        const int s = q / 6, t = (q % 6) >> 1, mt = q & 1;
+        const ChainStage& st = cp.st[s];
+        h8 a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (_Float16)0.0f;
+        const float* wp = t < 2 ? (st.in[t] ? st.w[t] : nullptr) : st.w_prev;
+        if (wp) {
+            const int ld = t < 2 ? st.ld[t] : st.ld_prev;
+            const float* wr = wp + (size_t)(16 * mt + l15) * ld;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)   // memory inputs: k = 8g + e; chained input: the accumulator's channel order
+                a[e] = (_Float16)wr[t < 2 ? 8 * g + e : (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
+        }
+        As[s][t][mt][lane] = a;
+    }
+    if (threadIdx.x < NS * 32) bs[threadIdx.x >> 5][threadIdx.x & 31] = cp.st[threadIdx.x >> 5].bias[threadIdx.x & 31];
+    __syncthreads();
+    h2 a2[NS];
+    bool use_max[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        a2[s] = h2{(_Float16)cp.st[s].slope, (_Float16)cp.st[s].slope};
+        use_max[s] = cp.st[s].slope <= 1.0f;
+    }
+    constexpr int NIN = ((MIN >> 0) & 1) + ((MIN >> 1) & 1) + ((MIN >> 2) & 1) + ((MIN >> 3) & 1) + ((MIN >> 4) & 1) + ((MIN >> 5) & 1);
+    struct Ops { h8 in[NIN > 0 ? NIN : 1]; f4 cm[2]; };
+    auto fetch = [&](unsigned tile, Ops& o) __attribute__((always_inline)) {
+        const unsigned px = tile * 16 + l15;
+        const unsigned pc = px < total_px ? px : total_px - 1;
+        int k = 0;
+#pragma unroll
+        for (int q = 0; q < 2 * NS; ++q)
+            if ((MIN >> q) & 1) o.in[k++] = *reinterpret_cast<const h8*>(cp.st[q >> 1].in[q & 1] + (size_t)pc * NF + 8 * g);
+        if (CMAP0) {
+            const unsigned pp = pc - (pc / P) * P;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) o.cm[mt] = *reinterpret_cast<const f4*>(cp.st[0].cmap + (size_t)pp * NF + 16 * mt + 4 * g);
+        }
+    };
+    const unsigned ntiles = (total_px + 15) / 16;
+    const unsigned wave0 = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    if (wave0 >= ntiles) return;
+    Ops cur;
+    fetch(wave0, cur);
+    for (unsigned tile = wave0; tile < ntiles; tile += nwaves) {
+        Ops nxt;
+        fetch(tile + nwaves < ntiles ? tile + nwaves : tile, nxt);
+        unsigned loff = lane * 16, boff = g * 16;
+        asm volatile("" : "+v"(loff), "+v"(boff));   // opaque per trip: fragment reads stay inside the loop
+        const unsigned char* const ap = reinterpret_cast<const unsigned char*>(&As[0][0][0][0]) + loff;
+        const unsigned char* const bp = reinterpret_cast<const unsigned char*>(&bs[0][0]) + boff;
+        const unsigned px = tile * 16 + l15;
+        h8 prev = cur.in[0];
+        int k = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            f4 acc[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[mt] = *reinterpret_cast<const f4*>(bp + s * 128 + mt * 64);
+            if (CMAP0 && s == 0) { acc[0] += cur.cm[0]; acc[1] += cur.cm[1]; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (!((MIN >> (2 * s + t)) & 1)) continue;
+                const h8 bfrag = cur.in[k++];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt] = mfma16(*reinterpret_cast<const h8*>(ap + ((s * 3 + t) * 2 + mt) * 1024), bfrag, acc[mt]);
+            }
+            if (s > 0) {   // (an absent chained weight is a zero fragment)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt] = mfma16(*reinterpret_cast<const h8*>(ap + ((s * 3 + 2) * 2 + mt) * 1024), prev, acc[mt]);
+            }
+            prev = act_pack(acc[0], acc[1], a2[s], use_max[s]);   // channels {4g..4g+3, 16+4g..16+4g+3} of pixel l15
+            if (cp.st[s].out && px < total_px) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<h4*>(cp.st[s].out + (size_t)px * NF + 4 * g) = h4{prev[0], prev[1], prev[2], prev[3]};
+                *reinterpret_cast<h4*>(cp.st[s].out + (size_t)px * NF + 16 + 4 * g) = h4{prev[4], prev[5], prev[6], prev[7]};
+            }
+        }
+        cur = nxt;
+    }
+}
+
 // ---- head on MFMA: sub_mean -> conv_in 3x3 (3->128) + PReLU -> feat_in 1x1 (128->32) + PReLU -> NHWC fp16
 //      (SRProjectionModule.py:135,137-138).  One wave = 16 pixels per trip.  First product: M = 128 mid channels
 //      (8 tiles), K = 27 taps padded to 32, B = the mean-shifted 3x3x3 neighbourhood gathered by the lanes (zero
@@ -1107,7 +1205,16 @@ int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags
                  int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream);
 }
 
+static int g_chain_generic = 0;   // 1: every chain through the generic build (cross-check / A-B)
+
 extern "C" {
+
+int vsr_sr_chain_variant(int generic) {
+    const int old = g_chain_generic;
+    g_chain_generic = generic;
+    return old;
+}
+
 
 int vsr_sr_utd_variant(int v) {
     VSR_REQUIRE(v >= 0 && v <= 4, "sr_utd_variant: 0 one wave per SIMD, 1 two waves per SIMD, 2 / 3 their stamped diagnostic builds, 4 build 0 with loop totals only");
@@ -1193,7 +1300,24 @@ int vsr_sr_chain1x1_f16(const vsr_chain1x1_t* chain, int N, int P, vsr_stream_t 
     const size_t total = (size_t)N * P;
     const size_t tiles = (total + 15) / 16;
     const unsigned grid = (unsigned)(tiles / 4 + 1 < 2048 ? tiles / 4 + 1 : 2048);  // 4 waves per block, grid-stride
-    hipLaunchKernelGGL(k_chain1x1_h, dim3(grid), dim3(256), 0, vsr::S(stream), cp, (size_t)P, total);
+    // the shapes the FeedbackBlock glue launches go through the streaming build; anything else through the generic one
+    int min_mask = 0, cmap_late = 0, cmap0 = cp.st[0].cmap != nullptr;
+    for (int s = 0; s < chain->nstages; ++s) {
+        for (int t = 0; t < 2; ++t) min_mask |= cp.st[s].in[t] ? 1 << (2 * s + t) : 0;
+        if (s > 0 && cp.st[s].cmap) cmap_late = 1;
+    }
+    const int key = g_chain_generic || cmap_late || total >= (1ull << 26) ? -1 : chain->nstages * 1000 + min_mask * 10 + cmap0;
+#define VSR_CHAIN_CASE(NS_, MIN_, CM_)                                                                                   \
+    case NS_ * 1000 + MIN_ * 10 + CM_:                                                                                   \
+        hipLaunchKernelGGL((k_chain1x1_s<NS_, MIN_, (CM_ != 0)>), dim3(grid), dim3(256), 0, vsr::S(stream), cp, (unsigned)P, \
+                           (unsigned)total);                                                                             \
+        break;
+    switch (key) {
+        VSR_CHAIN_CASE(1, 1, 0) VSR_CHAIN_CASE(1, 3, 0) VSR_CHAIN_CASE(1, 1, 1) VSR_CHAIN_CASE(1, 3, 1)
+        VSR_CHAIN_CASE(2, 3, 0) VSR_CHAIN_CASE(2, 1, 0) VSR_CHAIN_CASE(3, 7, 1) VSR_CHAIN_CASE(3, 5, 1) VSR_CHAIN_CASE(3, 7, 0)
+        default: hipLaunchKernelGGL(k_chain1x1_h, dim3(grid), dim3(256), 0, vsr::S(stream), cp, (size_t)P, total);
+    }
+#undef VSR_CHAIN_CASE
     return vsr::launched("sr_chain1x1_f16");
 }
 
