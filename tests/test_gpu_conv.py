@@ -55,10 +55,12 @@ def test_conv_matches_torch(case):
 @pytest.mark.parametrize("case", [  # (N, Cin, H, W, Cout, k, act): the LDS-patch builds, forced (the heuristic wants >= 8192 pixels)
     (1, 64, 37, 61, 16, 11, igemm.ACT_RELU), (2, 64, 20, 50, 16, 7, igemm.ACT_RELU), (1, 32, 9, 40, 16, 5, igemm.ACT_RELU),
     (1, 96, 33, 47, 16, 3, igemm.ACT_LEAKY), (2, 64, 37, 61, 1, 3, igemm.ACT_NONE), (1, 194, 33, 47, 2, 3, igemm.ACT_NONE),
-    (1, 64, 41, 77, 32, 7, igemm.ACT_RELU), (1, 64, 19, 33, 64, 5, igemm.ACT_RELU), (1, 32, 130, 70, 13, 11, igemm.ACT_RELU)])
-@pytest.mark.parametrize("mode", [2, 1])
+    (1, 64, 41, 77, 32, 7, igemm.ACT_RELU), (1, 64, 19, 33, 64, 5, igemm.ACT_RELU), (1, 32, 130, 70, 13, 11, igemm.ACT_RELU),
+    (2, 64, 33, 50, 128, 3, igemm.ACT_LEAKY), (1, 64, 30, 40, 64, 11, igemm.ACT_RELU), (1, 96, 12, 16, 48, 3, igemm.ACT_RELU)])
+@pytest.mark.parametrize("mode", [2, 6, 7, 1])
 def test_patch_kernels_match_torch(case, mode):
-    """mode 2: every legal layer through k_conv_patch / k_conv_patch_rows; mode 1: the same layers through the gather kernel."""
+    """mode 2: every legal layer through the LDS-patch builds (k_conv_patch_r8 where one exists); 6: without r8
+    (k_conv_patch_rows / k_conv_patch); 7: k_conv_patch only; 1: the same layers through the gather kernel."""
     from video_super_resolution_amd import _lib as L
     N, cin, H, W, cout, k, act = case
     rs = np.random.RandomState(cin + 31 * cout + k)

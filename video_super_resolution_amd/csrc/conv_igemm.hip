@@ -331,6 +331,95 @@ __global__ void __launch_bounds__(512) k_conv1x1_stream(const ConvP p) {
 // M = 16*MT out-channels, N = pixels (wave w: tile rows 2w, 2w+1), K = taps x channels.
 constexpr int PT_H = 8, PT_W = 32;
 
+// Epilogue of the patch kernels: bias + activation + fp16, then out through LDS so that a pixel's 16 MT channels leave
+// as whole 16-byte pieces from adjacent lanes (a full 128-byte line per pixel at MT = 4).  Straight from the MFMA
+// layout a store instruction writes 8 bytes per lane, 32 bytes per pixel per out-channel tile; measured on the 3x3
+// FlowNet layers those partial-line writes were half of the kernel's time (tools/patch_exp2.py).  Wave-local: each
+// wave transposes its own NT x 16 pixels in its own LDS slice (the caller has synchronised after the last patch read).
+// acc(ti, mt) -> f4 of pixel-tile ti; pix(ti, li, oy, ox) -> output coordinates of pixel li of tile ti.
+template <int MT, int NT, class GetAcc, class PixOf>
+__device__ __forceinline__ void patch_epilogue(const ConvP& p, unsigned char* wave_lds, int n, int co0, int lane, GetAcc acc, PixOf pix) {
+    constexpr int RB = 32 * MT, LPP = 2 * MT, PPI = 64 / LPP;
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int c = co0 + 16 * mt + 4 * g;
+        float bz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bz[e] = (p.bias && c + e < p.cout) ? p.bias[c + e] : 0.0f;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const f4 a = acc(ti, mt);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float tt = a[e] + bz[e];
+                if (p.act == 1) tt = fmaxf(tt, 0.0f);
+                else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
+                v[e] = tt;
+            }
+            *reinterpret_cast<h4*>(wave_lds + (ti * 16 + l15) * RB + (((2 * mt + (g >> 1)) ^ (l15 & (LPP - 1))) << 4) + ((g & 1) << 3)) =
+                h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+    }
+    asm volatile("" ::: "memory");   // (same wave, in-order LDS: the reads below see the writes above)
+    const bool vec_ok = ((p.out_coff + co0) & 7) == 0 && (p.out_ld & 7) == 0;
+    const int k = lane % LPP;
+    const int c = co0 + 8 * k;
+#pragma unroll
+    for (int it = 0; it < NT * 16 / PPI; ++it) {
+        const int pl = it * PPI + lane / LPP;
+        const int ti = pl >> 4, li = pl & 15;
+        int oy, ox;
+        pix(ti, li, oy, ox);
+        const h8 v = *reinterpret_cast<const h8*>(wave_lds + pl * RB + ((k ^ (li & (LPP - 1))) << 4));
+        if (oy >= p.Ho || ox >= p.Wo || c >= p.cout) continue;
+        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
+                        p.out_coff + c;
+        if (vec_ok && c + 8 <= p.cout) {
+            *reinterpret_cast<h8*>(dst) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c + e < p.cout) dst[e] = v[e];
+        }
+    }
+}
+
+// Stages the [PH][PW] x 32-channel input patch of image n, chunk ch into LDS (pixel = 64 B, 16-byte pieces XOR-swizzled
+// by pixel-column bits 1-2).  Six pieces per thread are requested back to back with no branch in between (buffer loads:
+// positions outside the image or past the patch carry an out-of-range offset and read zeros) and only then written to
+// LDS -- a conditional load per piece serialises one memory latency per piece, which was most of the 3x3 layers' time.
+__device__ __forceinline__ void stage_patch(const ConvP& p, unsigned char* patch, int n, int ch, int iy0, int ix0, int PH, int PW, int tid) {
+    constexpr int U = 6;
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const size_t img_bytes = (size_t)p.H * p.W * p.in_ld * 2;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(p.in) + (size_t)n * p.H * p.W * p.in_ld, 0, (int)(unsigned)img_bytes, 0x00020000);
+    const int total = PH * PW * 4;
+    const unsigned coff = (unsigned)(p.in_coff + ch * 32) * 2;
+    for (int q0 = 0; q0 < total; q0 += 256 * U) {
+        u4v v[U];
+        int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * 256 + tid;
+            const int pix = q >> 2, c4 = q & 3;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool ok = q < total && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.in_ld * 2 + coff + c4 * 16) : 0xFFFFFFFFu;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            dst[u] = q < total ? pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<u4v*>(patch + dst[u]) = v[u];
+    }
+}
+
+
+
 // MT = out-channel tiles (16 each) per workgroup; blockIdx.z walks blocks of 16*MT out-channels.
 // Weights are not staged: each tap's A fragments are read straight from global memory (the packed slab of one
 // (tap, chunk) is [cout_pad][32] fp16, so a wave's 16 rows x 64 B are one contiguous 1 KiB read, L2-resident and
@@ -365,15 +454,7 @@ __global__ void __launch_bounds__(256) k_conv_patch(const ConvP p) {
     };
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();
-        for (int q = tid; q < PH * PW * 4; q += 256) {
-            const int pix = q >> 2, c4 = q & 3;
-            const int py = pix / PW, px = pix - py * PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = *reinterpret_cast<const uint4*>(p.in + (((size_t)n * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + ch * 32 + c4 * 8);
-            *reinterpret_cast<uint4*>(patch + pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4)) = v;
-        }
+        stage_patch(p, patch, n, ch, iy0, ix0, PH, PW, tid);
         h8 af[MT], afn[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = wfrag(0, ch, mt);
@@ -396,34 +477,10 @@ __global__ void __launch_bounds__(256) k_conv_patch(const ConvP p) {
                 for (int mt = 0; mt < MT; ++mt) af[mt] = afn[mt];
             }
     }
-    // lane holds channels co0 + 16 mt + 4g .. +3 of its four pixels
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int oy = oy0 + 2 * wv + (t >> 1), ox = ox0 + 16 * (t & 1) + l15;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
-                        p.out_coff;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int c = co0 + 16 * mt + 4 * g;
-            if (c >= p.cout) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float tt = acc[mt][t][r] + (p.bias ? p.bias[c + r] : 0.0f);
-                if (p.act == 1) tt = fmaxf(tt, 0.0f);
-                else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
-                v[r] = tt;
-            }
-            if (c + 4 <= p.cout && ((p.out_coff + c) & 3) == 0 && (p.out_ld & 3) == 0) {
-                *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c + r < p.cout) dst[c + r] = (_Float16)v[r];
-            }
-        }
-    }
+    __syncthreads();   // every wave is done with the patch: its memory carries the output tile now
+    patch_epilogue<MT, 4>(p, psm + wv * (4 * 16 * 32 * MT), n, co0, lane,
+                          [&](int t, int mt) { return acc[mt][t]; },
+                          [&](int t, int li, int& oy, int& ox) { oy = oy0 + 2 * wv + (t >> 1); ox = ox0 + 16 * (t & 1) + li; });
 }
 
 // The 16-out-channel case of the patch kernel (the hourglass's 16-wide 3x3..11x11 inception branches and its final
@@ -468,15 +525,7 @@ __global__ void __launch_bounds__(256) k_conv_patch_rows(const ConvP p) {
     };
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();
-        for (int q = tid; q < PH * PW * 4; q += 256) {
-            const int pix = q >> 2, c4 = q & 3;
-            const int py = pix / PW, px = pix - py * PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = *reinterpret_cast<const uint4*>(p.in + (((size_t)n * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + ch * 32 + c4 * 8);
-            *reinterpret_cast<uint4*>(patch + pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4)) = v;
-        }
+        stage_patch(p, patch, n, ch, iy0, ix0, PH, PW, tid);
         h8 a0[KH], a1[KH];
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) a0[ky] = wfrag(ky, 0, ch);
@@ -491,31 +540,92 @@ __global__ void __launch_bounds__(256) k_conv_patch_rows(const ConvP p) {
             if (kx + 1 < p.kw) column(kx + 1, a1);
         }
     }
-    // lane holds channels 4g .. 4g+3 of pixels (ry0 + r, cx0 + l15)
+    __syncthreads();
+    patch_epilogue<1, 4>(p, psm + wv * (4 * 16 * 32), n, 0, lane, [&](int r, int) { return acc[r]; },
+                         [&](int r, int li, int& oy, int& ox) { oy = oy0 + ry0 + r; ox = ox0 + cx0 + li; });
+}
+
+// The patch kernel with a 16 x 32 output tile and 8 rows x 16 columns x MT out-channel tiles per wave.  Measured on
+// MI355X (tools/patch_exp.py): k_conv_patch spends 15-33 % of its time on the per-tap weight fragments (every wave
+// fetches every fragment, 1 KiB per 4 MFMAs, which is the L1's whole bandwidth) and one ds_read per 1-4 MFMAs.  Here
+// a wave walks the patch one tap COLUMN at a time: the KH fragments of the column sit in registers, each patch row
+// is read once and feeds the up-to-eight output rows it belongs to (row y, tap row ky = row y+1, tap row ky-1), and a
+// fragment is replaced by the next column's as soon as its last row has used it.  Per column: 8 KH MT MFMAs for KH MT
+// fragment loads and KH+7 LDS reads -- half the L1 traffic and a third to a sixth of the LDS traffic per MFMA.
+constexpr int P8_H = 16, P8_W = 32, P8_R = 8;
+template <int KH, int MT>
+__global__ void __launch_bounds__(256, MT == 4 ? 2 : 1) k_conv_patch_r8(const ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    const int PH = P8_H + KH - 1, PW = P8_W + p.kw - 1;
+    unsigned char* const patch = psm;                      // [PH][PW] pixels of 64 B (chunk XOR pixel-column bits 1-2)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tiles_x = (p.Wo + P8_W - 1) / P8_W;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int n = blockIdx.y;
+    const int co0 = blockIdx.z * 16 * MT;
+    const int oy0 = ty * P8_H, ox0 = tx * P8_W;
+    const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+    const int nchunk = p.cin >> 5;
+    const int ry0 = P8_R * (wv >> 1), cx0 = 16 * (wv & 1);
+
+    f4 acc[P8_R][MT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int oy = oy0 + ry0 + r, ox = ox0 + cx0 + l15;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
-                        p.out_coff;
-        const int c = 4 * g;
-        if (c >= p.cout) continue;
-        float v[4];
+    for (int r = 0; r < P8_R; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float tt = acc[r][e] + (p.bias ? p.bias[c + e] : 0.0f);
-            if (p.act == 1) tt = fmaxf(tt, 0.0f);
-            else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
-            v[e] = tt;
-        }
-        if (c + 4 <= p.cout && ((p.out_coff + c) & 3) == 0 && (p.out_ld & 3) == 0) {
-            *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        } else {
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    auto wfrag = [&](int ky, int kx, int ch, int mt) __attribute__((always_inline)) {
+        return *reinterpret_cast<const h8*>(p.wpk + ((size_t)((ky * p.kw + kx) * nchunk + ch) * p.cout_pad + co0 + 16 * mt + l15) * 32 + 8 * g);
+    };
+    h8 A[KH][MT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (c + e < p.cout) dst[c + e] = (_Float16)v[e];
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) A[ky][mt] = wfrag(ky, 0, 0, mt);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();
+        stage_patch(p, patch, n, ch, iy0, ix0, PH, PW, tid);
+        __syncthreads();
+        for (int kx = 0; kx < p.kw; ++kx) {
+            // the column after this one (next chunk's first at the end; the very last refresh re-reads its own)
+            const bool last_col = kx + 1 == p.kw;
+            const int nkx = last_col ? (ch + 1 < nchunk ? 0 : kx) : kx + 1, nch = last_col && ch + 1 < nchunk ? ch + 1 : ch;
+            const int px = cx0 + l15 + kx;
+            const unsigned char* src = patch + (ry0 * PW + px) * 64 + ((g ^ ((px >> 1) & 3)) << 4);
+#pragma unroll
+            for (int pr = 0; pr < KH + P8_R - 1; ++pr) {
+                const h8 bf = *reinterpret_cast<const h8*>(src + pr * PW * 64);
+#pragma unroll
+                for (int r = 0; r < P8_R; ++r) {
+                    const int ky = pr - r;
+                    if (ky < 0 || ky >= KH) continue;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ky][mt], bf, acc[r][mt], 0, 0, 0);
+                }
+                const int kd = pr - (P8_R - 1);   // tap row whose last output row was just fed: its registers take the next column
+                if (kd >= 0 && kd < KH) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) A[kd][mt] = wfrag(kd, nkx, nch, mt);
+                }
+            }
         }
     }
+    __syncthreads();
+    patch_epilogue<MT, P8_R>(p, psm + wv * (P8_R * 16 * 32 * MT), n, co0, lane, [&](int r, int mt) { return acc[r][mt]; },
+                             [&](int r, int li, int& oy, int& ox) { oy = oy0 + ry0 + r; ox = ox0 + cx0 + li; });
+}
+
+template <int KH, int MT>
+static void launch_patch_r8(const ConvP& p, int N, hipStream_t stream) {
+    const int lds_patch = (P8_H + KH - 1) * (P8_W + p.kw - 1) * 64, lds_out = 4 * P8_R * 16 * 32 * MT;
+    const int lds = lds_patch > lds_out ? lds_patch : lds_out;
+    static bool raised = false;   // (per instantiation)
+    if (lds > 64 * 1024 && !raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch_r8<KH, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    const unsigned tiles = vsr::cdiv(p.Ho, P8_H) * vsr::cdiv(p.Wo, P8_W);
+    hipLaunchKernelGGL((k_conv_patch_r8<KH, MT>), dim3(tiles, N, p.cout_pad / (16 * MT)), dim3(256), lds, stream, p);
 }
 
 // sums the split-K partials in a fixed order, + bias, activation, fp16 store (4 channels per thread)
@@ -724,7 +834,7 @@ __global__ void __launch_bounds__(256) k_corr_mfma(const _Float16* __restrict__ 
 }
 
 static int g_splitk_fill = 256;   // split K when a launch has fewer workgroups than this (measured: tools/probe_splitk.py)
-static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse build (tuning hook)
+static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows (tuning hook)
 
 extern "C" {
 
@@ -889,26 +999,44 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
     // stride-1 layers with a real spatial kernel and enough pixels: the 2-D LDS patch kernel (stages the input once per
     // 32-channel chunk instead of gathering it kh*kw times from L2).  Measured on MI355X (tools/conv_microbench.py).
     const int patch_lds = (PT_H + kh - 1) * (PT_W + kw - 1) * 64;
-    const bool patch_legal = stride == 1 && Ho >= 4 && Wo >= 16 && patch_lds <= 64 * 1024 && N <= 65535 && (cout_pad & 15) == 0;
+    const bool patch_legal = stride == 1 && Ho >= 4 && Wo >= 16 && patch_lds <= 64 * 1024 && N <= 65535 && (cout_pad & 15) == 0 &&
+                             (unsigned long long)H * W * in_ld * 2 < (1ull << 31);   // (staging uses 32-bit byte offsets per image)
     const bool patch_pays = (long long)Ho * Wo >= 8192 && kh * kw >= 9 && ((cout_pad == 16 && (cin >> 5) <= 8) || cout_pad >= 32);
-    if (patch_legal && g_patch_mode != 1 && (patch_pays || g_patch_mode == 2)) {
+    const bool force = g_patch_mode == 2 || g_patch_mode == 6 || g_patch_mode == 7;
+    const bool no_r8 = g_patch_mode == 3 || g_patch_mode == 5 || g_patch_mode == 6 || g_patch_mode == 7, no_rows = g_patch_mode == 3 || g_patch_mode == 7;
+    if (patch_legal && g_patch_mode != 1 && (patch_pays || force)) {
         p.ws = nullptr;
         p.splits = 1;
         const unsigned tiles = vsr::cdiv(Ho, PT_H) * vsr::cdiv(Wo, PT_W);
+        // 16 x 32 tiles, 8 rows per wave (k_conv_patch_r8) where a build exists and the patch fits the LDS
+        const int r8_lds = (P8_H + kh - 1) * (P8_W + kw - 1) * 64;
+        const int r8_mt = (cout_pad & 63) == 0 && kh == 3 ? 4 : ((cout_pad & 31) == 0 ? 2 : (cout_pad == 16 ? 1 : 0));
+        // measured (tools/patch_exp.py): pays for 5x5 and larger kernels and for 16-channel outputs; 3x3 layers with 32+
+        // out-channels are staging-bound and keep the smaller tile's occupancy
+        const bool r8_pays = kh >= 5 || cout_pad == 16 || g_patch_mode == 2;
+        if (!no_r8 && r8_pays && r8_mt && r8_lds <= 80 * 1024 && Ho >= 12 && (kh == 3 || kh == 5 || kh == 7 || kh == 11)) {
+            hipStream_t st = vsr::S(stream);
+#define VSR_R8(KH_) \
+            if (kh == KH_) { if (r8_mt == 4 && KH_ == 3) launch_patch_r8<3, 4>(p, N, st); else if (r8_mt == 2) launch_patch_r8<KH_, 2>(p, N, st); else launch_patch_r8<KH_, 1>(p, N, st); }
+            VSR_R8(3) VSR_R8(5) VSR_R8(7) VSR_R8(11)
+#undef VSR_R8
+            return vsr::launched("conv2d_nhwc_f16/patch_r8");
+        }
+        const auto lds_for = [&](int mt) { const int o = 4 * 4 * 16 * 32 * mt; return patch_lds > o ? patch_lds : o; };   // patch, then the output tile
         if ((cout_pad & 63) == 0)
-            hipLaunchKernelGGL(k_conv_patch<4>, dim3(tiles, N, cout_pad / 64), dim3(256), patch_lds, vsr::S(stream), p);
+            hipLaunchKernelGGL(k_conv_patch<4>, dim3(tiles, N, cout_pad / 64), dim3(256), lds_for(4), vsr::S(stream), p);
         else if ((cout_pad & 31) == 0)
-            hipLaunchKernelGGL(k_conv_patch<2>, dim3(tiles, N, cout_pad / 32), dim3(256), patch_lds, vsr::S(stream), p);
-        else if (cout_pad == 16 && kh == 3 && g_patch_mode != 3)
-            hipLaunchKernelGGL(k_conv_patch_rows<3>, dim3(tiles, N, 1), dim3(256), patch_lds, vsr::S(stream), p);
-        else if (cout_pad == 16 && kh == 5 && g_patch_mode != 3)
-            hipLaunchKernelGGL(k_conv_patch_rows<5>, dim3(tiles, N, 1), dim3(256), patch_lds, vsr::S(stream), p);
-        else if (cout_pad == 16 && kh == 7 && g_patch_mode != 3)
-            hipLaunchKernelGGL(k_conv_patch_rows<7>, dim3(tiles, N, 1), dim3(256), patch_lds, vsr::S(stream), p);
-        else if (cout_pad == 16 && kh == 11 && g_patch_mode != 3)
-            hipLaunchKernelGGL(k_conv_patch_rows<11>, dim3(tiles, N, 1), dim3(256), patch_lds, vsr::S(stream), p);
+            hipLaunchKernelGGL(k_conv_patch<2>, dim3(tiles, N, cout_pad / 32), dim3(256), lds_for(2), vsr::S(stream), p);
+        else if (cout_pad == 16 && kh == 3 && !no_rows)
+            hipLaunchKernelGGL(k_conv_patch_rows<3>, dim3(tiles, N, 1), dim3(256), lds_for(1), vsr::S(stream), p);
+        else if (cout_pad == 16 && kh == 5 && !no_rows)
+            hipLaunchKernelGGL(k_conv_patch_rows<5>, dim3(tiles, N, 1), dim3(256), lds_for(1), vsr::S(stream), p);
+        else if (cout_pad == 16 && kh == 7 && !no_rows)
+            hipLaunchKernelGGL(k_conv_patch_rows<7>, dim3(tiles, N, 1), dim3(256), lds_for(1), vsr::S(stream), p);
+        else if (cout_pad == 16 && kh == 11 && !no_rows)
+            hipLaunchKernelGGL(k_conv_patch_rows<11>, dim3(tiles, N, 1), dim3(256), lds_for(1), vsr::S(stream), p);
         else
-            hipLaunchKernelGGL(k_conv_patch<1>, dim3(tiles, N, cout_pad / 16), dim3(256), patch_lds, vsr::S(stream), p);
+            hipLaunchKernelGGL(k_conv_patch<1>, dim3(tiles, N, cout_pad / 16), dim3(256), lds_for(1), vsr::S(stream), p);
         return vsr::launched("conv2d_nhwc_f16/patch");
     }
     // 1x1 over many pixels with more than one 64-channel block of outputs: the streaming kernel (input read once)
