@@ -47,6 +47,65 @@ struct C1 { static constexpr int value = 1; };
 
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
+// Epilogue of the convolution kernels: bias + activation + fp16, then out through LDS so that a pixel's 16 MT channels leave
+// as whole 16-byte pieces from adjacent lanes (a full 128-byte line per pixel at MT = 4).  Straight from the MFMA
+// layout a store instruction writes 8 bytes per lane, 32 bytes per pixel per out-channel tile; measured on the 3x3
+// FlowNet layers those partial-line writes were half of the kernel's time (tools/patch_exp2.py).  Wave-local: each
+// wave transposes its own NT x 16 pixels in its own LDS slice (the caller has synchronised after the last patch read).
+// acc(ti, mt) -> f4 of pixel-tile ti; pixoff(ti, li) -> element offset of pixel li of tile ti in the output tensor (its
+// channel 0), or -1 when the pixel does not exist.
+template <int MT, int NT, class GetAcc, class PixOf>
+__device__ __forceinline__ void patch_epilogue(const ConvP& p, unsigned char* wave_lds, int co0, int lane, GetAcc acc, PixOf pixoff) {
+    constexpr int RB = 32 * MT, LPP = 2 * MT, PPI = 64 / LPP;
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int c = co0 + 16 * mt + 4 * g;
+        float bz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bz[e] = (p.bias && c + e < p.cout) ? p.bias[c + e] : 0.0f;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const f4 a = acc(ti, mt);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float tt = a[e] + bz[e];
+                if (p.act == 1) tt = fmaxf(tt, 0.0f);
+                else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
+                v[e] = tt;
+            }
+            *reinterpret_cast<h4*>(wave_lds + (ti * 16 + l15) * RB + (((2 * mt + (g >> 1)) ^ (l15 & (LPP - 1))) << 4) + ((g & 1) << 3)) =
+                h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+    }
+    asm volatile("" ::: "memory");   // (same wave, in-order LDS: the reads below see the writes above)
+    const bool vec_ok = ((p.out_coff + co0) & 7) == 0 && (p.out_ld & 7) == 0;
+    const int k = lane % LPP;
+    const int c = co0 + 8 * k;
+#pragma unroll
+    for (int it = 0; it < NT * 16 / PPI; ++it) {
+        const int pl = it * PPI + lane / LPP;
+        const int ti = pl >> 4, li = pl & 15;
+        const long long po = pixoff(ti, li);
+        const h8 v = *reinterpret_cast<const h8*>(wave_lds + pl * RB + ((k ^ (li & (LPP - 1))) << 4));
+        if (po < 0 || c >= p.cout) continue;
+        _Float16* dst = p.out + po + p.out_coff + c;
+        if (vec_ok && c + 8 <= p.cout) {
+            *reinterpret_cast<h8*>(dst) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c + e < p.cout) dst[e] = v[e];
+        }
+    }
+}
+
+__device__ __forceinline__ long long patch_pixoff(const ConvP& p, int n, int oy, int ox) {
+    if (oy >= p.Ho || ox >= p.Wo) return -1;
+    return (long long)((((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld);
+}
+
 // STEM: the input has 4 channels per pixel ([N,H,W,4] fp16, 3 live) and one K chunk is a whole kernel ROW: k = 4 kx + c
 // for kx < 8 (packed weights [ky][cout_pad][32], zero where kx >= kw or c >= cin).  A 7x7 stem on an RGB image is 7 K
 // chunks instead of 49 chunks that are 29/32 zero padding.
@@ -189,6 +248,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     }
 
     // ---- epilogue: this lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15
+    //      (straight from the MFMA layout: the LDS-transposed epilogue of the patch kernels was measured here too and
+    //      loses 10-25 % on these shorter, lower-resolution launches)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const long long m = m0 + 32 * wv + 16 * nt + l15;
@@ -331,61 +392,6 @@ __global__ void __launch_bounds__(512) k_conv1x1_stream(const ConvP p) {
 // M = 16*MT out-channels, N = pixels (wave w: tile rows 2w, 2w+1), K = taps x channels.
 constexpr int PT_H = 8, PT_W = 32;
 
-// Epilogue of the patch kernels: bias + activation + fp16, then out through LDS so that a pixel's 16 MT channels leave
-// as whole 16-byte pieces from adjacent lanes (a full 128-byte line per pixel at MT = 4).  Straight from the MFMA
-// layout a store instruction writes 8 bytes per lane, 32 bytes per pixel per out-channel tile; measured on the 3x3
-// FlowNet layers those partial-line writes were half of the kernel's time (tools/patch_exp2.py).  Wave-local: each
-// wave transposes its own NT x 16 pixels in its own LDS slice (the caller has synchronised after the last patch read).
-// acc(ti, mt) -> f4 of pixel-tile ti; pix(ti, li, oy, ox) -> output coordinates of pixel li of tile ti.
-template <int MT, int NT, class GetAcc, class PixOf>
-__device__ __forceinline__ void patch_epilogue(const ConvP& p, unsigned char* wave_lds, int n, int co0, int lane, GetAcc acc, PixOf pix) {
-    constexpr int RB = 32 * MT, LPP = 2 * MT, PPI = 64 / LPP;
-    const int l15 = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int c = co0 + 16 * mt + 4 * g;
-        float bz[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bz[e] = (p.bias && c + e < p.cout) ? p.bias[c + e] : 0.0f;
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti) {
-            const f4 a = acc(ti, mt);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float tt = a[e] + bz[e];
-                if (p.act == 1) tt = fmaxf(tt, 0.0f);
-                else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
-                v[e] = tt;
-            }
-            *reinterpret_cast<h4*>(wave_lds + (ti * 16 + l15) * RB + (((2 * mt + (g >> 1)) ^ (l15 & (LPP - 1))) << 4) + ((g & 1) << 3)) =
-                h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        }
-    }
-    asm volatile("" ::: "memory");   // (same wave, in-order LDS: the reads below see the writes above)
-    const bool vec_ok = ((p.out_coff + co0) & 7) == 0 && (p.out_ld & 7) == 0;
-    const int k = lane % LPP;
-    const int c = co0 + 8 * k;
-#pragma unroll
-    for (int it = 0; it < NT * 16 / PPI; ++it) {
-        const int pl = it * PPI + lane / LPP;
-        const int ti = pl >> 4, li = pl & 15;
-        int oy, ox;
-        pix(ti, li, oy, ox);
-        const h8 v = *reinterpret_cast<const h8*>(wave_lds + pl * RB + ((k ^ (li & (LPP - 1))) << 4));
-        if (oy >= p.Ho || ox >= p.Wo || c >= p.cout) continue;
-        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld +
-                        p.out_coff + c;
-        if (vec_ok && c + 8 <= p.cout) {
-            *reinterpret_cast<h8*>(dst) = v;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (c + e < p.cout) dst[e] = v[e];
-        }
-    }
-}
-
 // Stages the [PH][PW] x 32-channel input patch of image n, chunk ch into LDS (pixel = 64 B, 16-byte pieces XOR-swizzled
 // by pixel-column bits 1-2).  Six pieces per thread are requested back to back with no branch in between (buffer loads:
 // positions outside the image or past the patch carry an out-of-range offset and read zeros) and only then written to
@@ -478,9 +484,8 @@ __global__ void __launch_bounds__(256) k_conv_patch(const ConvP p) {
             }
     }
     __syncthreads();   // every wave is done with the patch: its memory carries the output tile now
-    patch_epilogue<MT, 4>(p, psm + wv * (4 * 16 * 32 * MT), n, co0, lane,
-                          [&](int t, int mt) { return acc[mt][t]; },
-                          [&](int t, int li, int& oy, int& ox) { oy = oy0 + 2 * wv + (t >> 1); ox = ox0 + 16 * (t & 1) + li; });
+    patch_epilogue<MT, 4>(p, psm + wv * (4 * 16 * 32 * MT), co0, lane, [&](int t, int mt) { return acc[mt][t]; },
+                          [&](int t, int li) { return patch_pixoff(p, n, oy0 + 2 * wv + (t >> 1), ox0 + 16 * (t & 1) + li); });
 }
 
 // The 16-out-channel case of the patch kernel (the hourglass's 16-wide 3x3..11x11 inception branches and its final
@@ -541,8 +546,8 @@ __global__ void __launch_bounds__(256) k_conv_patch_rows(const ConvP p) {
         }
     }
     __syncthreads();
-    patch_epilogue<1, 4>(p, psm + wv * (4 * 16 * 32), n, 0, lane, [&](int r, int) { return acc[r]; },
-                         [&](int r, int li, int& oy, int& ox) { oy = oy0 + ry0 + r; ox = ox0 + cx0 + li; });
+    patch_epilogue<1, 4>(p, psm + wv * (4 * 16 * 32), 0, lane, [&](int r, int) { return acc[r]; },
+                         [&](int r, int li) { return patch_pixoff(p, n, oy0 + ry0 + r, ox0 + cx0 + li); });
 }
 
 // The patch kernel with a 16 x 32 output tile and 8 rows x 16 columns x MT out-channel tiles per wave.  Measured on
@@ -611,8 +616,8 @@ __global__ void __launch_bounds__(256, MT == 4 ? 2 : 1) k_conv_patch_r8(const Co
         }
     }
     __syncthreads();
-    patch_epilogue<MT, P8_R>(p, psm + wv * (P8_R * 16 * 32 * MT), n, co0, lane, [&](int r, int mt) { return acc[r][mt]; },
-                             [&](int r, int li, int& oy, int& ox) { oy = oy0 + ry0 + r; ox = ox0 + cx0 + li; });
+    patch_epilogue<MT, P8_R>(p, psm + wv * (P8_R * 16 * 32 * MT), co0, lane, [&](int r, int mt) { return acc[r][mt]; },
+                             [&](int r, int li) { return patch_pixoff(p, n, oy0 + ry0 + r, ox0 + cx0 + li); });
 }
 
 template <int KH, int MT>
