@@ -82,7 +82,9 @@ def test_patch_kernels_match_torch(case, mode):
 
 
 @pytest.mark.parametrize("case", [(2, 3, 37, 45, 128, 7, 1, 3, igemm.ACT_RELU), (4, 3, 64, 96, 64, 7, 2, 3, igemm.ACT_LEAKY),
-                                  (1, 3, 33, 29, 64, 3, 1, 1, igemm.ACT_RELU), (1, 4, 20, 20, 16, 5, 1, 2, igemm.ACT_NONE)])
+                                  (1, 3, 33, 29, 64, 3, 1, 1, igemm.ACT_RELU), (1, 4, 20, 20, 16, 5, 1, 2, igemm.ACT_NONE),
+                                  (1, 3, 270, 250, 128, 7, 1, 3, igemm.ACT_RELU),    # hourglass stem, >= 65536 pixels: k_stem7_rows (ragged tiles)
+                                  (3, 3, 161, 144, 128, 7, 1, 3, igemm.ACT_LEAKY)])  # the same across image boundaries
 def test_stem_conv_matches_torch(case):
     """Dense-K first convolution ([N,H,W,4] input, one K chunk per kernel row) of the hourglass / FlowNetC / VGG."""
     N, cin, H, W, cout, k, s, p, act = case

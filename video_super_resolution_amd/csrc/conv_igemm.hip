@@ -633,6 +633,118 @@ static void launch_patch_r8(const ConvP& p, int N, hipStream_t stream) {
     hipLaunchKernelGGL((k_conv_patch_r8<KH, MT>), dim3(tiles, N, p.cout_pad / (16 * MT)), dim3(256), lds, stream, p);
 }
 
+// The hourglass stem (7x7, 3 -> 128, stride 1, at full resolution): 531 MB of output per 4-frame batch against 0.12
+// TFLOP, i.e. a store-bound layer; through k_conv_igemm<.., STEM> it ran at 0.62 ms, gather-bound (49 x 8-byte pieces per
+// output pixel).  Here a persistent workgroup keeps ALL its weights in registers (wave w: out-channels 32w..32w+31, 7
+// tap rows x 2 tiles), stages the 14 x 22-pixel input patch of an 8 x 16 tile in LDS (8 bytes per pixel, next tile's
+// patch requested before this tile's MFMAs) and walks it row by row: the B operand of (pixel x, tap row ky) is the 64
+// bytes of pixels x-3 .. x+4 of one patch row (lane group g: pixels x-3+2g, +1), and each patch row feeds the up-to-
+// seven output rows it belongs to.  The tile leaves through LDS as whole 256-byte pixel rows.
+constexpr int ST_R = 8, ST_C = 16, ST_PH = ST_R + 6, ST_PW = ST_C + 8;   // (patch width: 16 + 6, padded to 24)
+constexpr int ST_PATCH = ST_PH * ST_PW * 8, ST_OUT = ST_R * ST_C * 256;
+__global__ void __launch_bounds__(256) k_stem7_rows(const ConvP p, int tiles_x, int tiles_y, int ntiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * ST_PATCH + ST_OUT];
+    unsigned char* const outs = sm + 2 * ST_PATCH;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(p.in), 0, (int)(unsigned)((size_t)p.N * p.H * p.W * 8), 0x00020000);
+    // weights: A[ky][mt] = rows 32 wv + 16 mt + l15 of tap row ky ([ky][cout_pad][32] fp16, k = 4 kx + c)
+    h8 A[7][2];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            A[ky][mt] = *reinterpret_cast<const h8*>(p.wpk + ((size_t)ky * p.cout_pad + 32 * wv + 16 * mt + l15) * 32 + 8 * g);
+    float bz[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bz[mt][e] = p.bias ? p.bias[32 * wv + 16 * mt + 4 * g + e] : 0.0f;
+    // patch pieces of this thread: q = tid, tid + 256 (< 14 x 24 = 336 pixels)
+    auto fetch = [&](int tile, u2v (&v)[2]) __attribute__((always_inline)) {
+        const int n = tile / (tiles_x * tiles_y), rem = tile - n * tiles_x * tiles_y;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + 256 * u;
+            const int py = q / ST_PW, px = q - py * ST_PW;
+            const int iy = ty * ST_R - 3 + py, ix = tx * ST_C - 3 + px;
+            const bool ok = q < ST_PH * ST_PW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const unsigned off = ok ? (unsigned)((((size_t)n * p.H + iy) * p.W + ix) * 8) : 0xFFFFFFFFu;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, off, 0, 0);
+        }
+    };
+    auto stash = [&](int buf, const u2v (&v)[2]) __attribute__((always_inline)) {
+        *reinterpret_cast<u2v*>(sm + buf * ST_PATCH + tid * 8) = v[0];
+        if (tid + 256 < ST_PH * ST_PW) *reinterpret_cast<u2v*>(sm + buf * ST_PATCH + (tid + 256) * 8) = v[1];
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    u2v nv[2];
+    fetch(tile, nv);
+    stash(0, nv);
+    __syncthreads();
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int tnext = tile + (int)gridDim.x;
+        fetch(tnext < ntiles ? tnext : tile, nv);
+        f4 acc[ST_R][2];
+#pragma unroll
+        for (int r = 0; r < ST_R; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[r][mt] = f4{bz[mt][0], bz[mt][1], bz[mt][2], bz[mt][3]};
+        const unsigned char* src = sm + buf * ST_PATCH + (l15 + 2 * g) * 8;
+#pragma unroll
+        for (int pr = 0; pr < ST_PH; ++pr) {
+            const u2v b0 = *reinterpret_cast<const u2v*>(src + pr * ST_PW * 8);
+            const u2v b1 = *reinterpret_cast<const u2v*>(src + pr * ST_PW * 8 + 8);
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const h8 bf = __builtin_bit_cast(h8, u4v{b0[0], b0[1], b1[0], b1[1]});
+#pragma unroll
+            for (int r = 0; r < ST_R; ++r) {
+                const int ky = pr - r;
+                if (ky < 0 || ky >= 7) continue;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ky][mt], bf, acc[r][mt], 0, 0, 0);
+            }
+        }
+        // activation, fp16, into the tile's LDS image: pixel q = 16 r + l15, 256 B per pixel, 16-byte pieces XOR (q & 15)
+#pragma unroll
+        for (int r = 0; r < ST_R; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float tt = acc[r][mt][e];
+                    if (p.act == 1) tt = fmaxf(tt, 0.0f);
+                    else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
+                    v[e] = tt;
+                }
+                *reinterpret_cast<h4*>(outs + (16 * r + l15) * 256 + (((4 * wv + 2 * mt + (g >> 1)) ^ l15) << 4) + ((g & 1) << 3)) =
+                    h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        stash(buf ^ 1, nv);
+        __syncthreads();
+        {
+            const int n = tile / (tiles_x * tiles_y), rem = tile - n * tiles_x * tiles_y;
+            const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+            const int j = lane & 15;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {   // wave: pixels 32 wv .. +31, four per instruction (16 lanes x 16 B each)
+                const int q = 32 * wv + 4 * it + (lane >> 4);
+                const int oy = ty * ST_R + (q >> 4), ox = tx * ST_C + (q & 15);
+                const h8 v = *reinterpret_cast<const h8*>(outs + q * 256 + ((j ^ (q & 15)) << 4));
+                if (oy < p.Ho && ox < p.Wo)
+                    *reinterpret_cast<h8*>(p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.out_ld + p.out_coff + 8 * j) = v;
+            }
+        }
+        __syncthreads();   // the tile image is rewritten by the next trip
+    }
+}
+
 // sums the split-K partials in a fixed order, + bias, activation, fp16 store (4 channels per thread)
 __global__ void __launch_bounds__(256) k_splitk_finish(const ConvP p) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
@@ -971,6 +1083,17 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
     p.outH = Ho; p.outW = Wo; p.oy_mul = 1; p.oy_off = 0; p.ox_mul = 1; p.ox_off = 0;
     p.act = act; p.slope = slope; p.ws = nullptr; p.splits = 1; p.nphase = 0;
     const long long M = (long long)N * Ho * Wo;
+    // the hourglass stem's shape: persistent row-walking kernel with register-resident weights and full-line stores
+    if (g_patch_mode != 1 && kh == 7 && kw == 7 && stride == 1 && pad_y == 3 && pad_x == 3 && cout == 128 && cout_pad == 128 && Ho == H &&
+        Wo == W && (out_ld & 7) == 0 && (out_coff & 7) == 0 && (unsigned long long)N * H * W * 8 < (1ull << 31) && M >= 65536) {
+        const int tiles_x = (int)vsr::cdiv(Wo, ST_C), tiles_y = (int)vsr::cdiv(Ho, ST_R);
+        const long long ntiles = (long long)N * tiles_x * tiles_y;
+        if (ntiles < (1ll << 30)) {
+            const unsigned grid1 = (unsigned)(ntiles < 256 * 2 ? ntiles : 256 * 2);   // two 4-wave workgroups resident per CU (registers)
+            hipLaunchKernelGGL(k_stem7_rows, dim3(grid1), dim3(256), 0, vsr::S(stream), p, tiles_x, tiles_y, (int)ntiles);
+            return vsr::launched("conv2d_stem_f16/rows");
+        }
+    }
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const dim3 grid(vsr::cdiv(M, BM), cout_pad / bn, 1);
     if (bn == 64) hipLaunchKernelGGL((k_conv_igemm<64, true>), grid, dim3(256), 0, vsr::S(stream), p);
