@@ -255,7 +255,7 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
 
 /* NHWC fp16 glue of the hourglass (pytorch_DIW_scratch.py: MaxPool2d/AvgPool2d((2,2),(2,2)), UpsamplingNearest2d(2),
  * coolAddTensors :29-31).  Inputs may be channel slices of wider buffers; outputs are dense [N,.,.,C].
- * pool: mode 0 max, 1 average.  resize_add: out = nearest_resize(a -> HxW) (+ b if given). */
+ * pool: mode 0 max, 1 average (out H/2 x W/2), 2 max with ceil_mode (out ceil(H/2) x ceil(W/2): OSVOS's VGG pools).  resize_add: out = nearest_resize(a -> HxW) (+ b if given). */
 int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int N, int H, int W, int C, int mode,
                          vsr_stream_t stream);
 int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,

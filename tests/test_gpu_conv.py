@@ -149,3 +149,20 @@ def test_flownetc_cost_volume_mfma(shape):
     got = out[..., 32:473].permute(0, 3, 1, 2).float()
     assert (got - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
     assert float((out[..., :32] - 7.0).abs().max()) == 0.0 and float((out[..., 473:] - 7.0).abs().max()) == 0.0   # slice only
+
+
+@pytest.mark.parametrize("shape", [(2, 135, 68, 64), (1, 7, 9, 16), (1, 34, 60, 128)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_pool2x2(shape, mode):
+    """2x2 stride-2 pools on NHWC fp16: max, average (floor) and max with ceil_mode (OSVOS's VGG pools)."""
+    N, H, W, C = shape
+    x = torch.from_numpy(np.random.RandomState(H + W + mode).randn(N, H, W, C).astype(np.float32)).cuda().half()
+    got = igemm.pool2x2(x, 0, C, mode)
+    xn = x.permute(0, 3, 1, 2).float()
+    ref = F.avg_pool2d(xn, 2, 2) if mode == 1 else F.max_pool2d(xn, 2, 2, ceil_mode=(mode == 2))
+    ref = ref.permute(0, 2, 3, 1)
+    assert got.shape == ref.shape
+    if mode == 1:
+        assert (got.float() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    else:
+        assert torch.equal(got.float(), ref)

@@ -780,10 +780,11 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const ConvP p) {
 //      coolAddTensors = nearest-resize + add): 16 bytes (8 channels) per thread, channel-slice aware on the input side.
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
-// mode 0: 2x2 max pool, 1: 2x2 average pool.  in [N,H,W,in_ld] slice [in_coff, +C) -> out [N,H/2,W/2,C]
+// mode 0: 2x2 max pool, 1: 2x2 average pool (both floor: out H/2 x W/2), 2: 2x2 max pool with ceil_mode (out ceil(H/2) x
+// ceil(W/2); the last window of an odd side holds one row / column).  in [N,H,W,in_ld] slice [in_coff, +C) -> out [N,Ho,Wo,C]
 __global__ void __launch_bounds__(256) k_pool2(const _Float16* __restrict__ in, int in_ld, int in_coff, _Float16* __restrict__ out,
                                                int N, int H, int W, int C, int mode) {
-    const int Ho = H >> 1, Wo = W >> 1, c8n = C >> 3;
+    const int Ho = mode == 2 ? (H + 1) >> 1 : H >> 1, Wo = mode == 2 ? (W + 1) >> 1 : W >> 1, c8n = C >> 3;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)N * Ho * Wo * c8n) return;
     const int c8 = (int)(idx % c8n);
@@ -791,11 +792,12 @@ __global__ void __launch_bounds__(256) k_pool2(const _Float16* __restrict__ in, 
     const int ox = (int)(r % Wo); r /= Wo;
     const int oy = (int)(r % Ho);
     const int n = (int)(r / Ho);
+    const int dy = 2 * oy + 1 < H ? 1 : 0, dx = 2 * ox + 1 < W ? 1 : 0;   // (ceil mode: a clamped window re-reads its own row / column)
     const _Float16* p00 = in + (((size_t)n * H + 2 * oy) * W + 2 * ox) * in_ld + in_coff + 8 * c8;
-    const h8v a = *reinterpret_cast<const h8v*>(p00), b = *reinterpret_cast<const h8v*>(p00 + in_ld);
-    const h8v c = *reinterpret_cast<const h8v*>(p00 + (size_t)W * in_ld), d = *reinterpret_cast<const h8v*>(p00 + (size_t)W * in_ld + in_ld);
+    const h8v a = *reinterpret_cast<const h8v*>(p00), b = *reinterpret_cast<const h8v*>(p00 + (size_t)dx * in_ld);
+    const h8v c = *reinterpret_cast<const h8v*>(p00 + (size_t)dy * W * in_ld), d = *reinterpret_cast<const h8v*>(p00 + ((size_t)dy * W + dx) * in_ld);
     h8v o;
-    if (mode == 0) {
+    if (mode != 1) {
         o = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
     } else {
 #pragma unroll
@@ -969,8 +971,8 @@ int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int 
                          vsr_stream_t stream) {
     VSR_REQUIRE(in && out, "pool2x2: null pointer");
     VSR_REQUIRE(N > 0 && H >= 2 && W >= 2 && C > 0 && (C & 7) == 0 && (in_ld & 7) == 0 && (in_coff & 7) == 0 && in_coff + C <= in_ld &&
-                    (mode == 0 || mode == 1), "pool2x2: bad arguments");
-    const long long total = (long long)N * (H >> 1) * (W >> 1) * (C >> 3);
+                    (mode >= 0 && mode <= 2), "pool2x2: bad arguments");
+    const long long total = (long long)N * (mode == 2 ? (H + 1) >> 1 : H >> 1) * (mode == 2 ? (W + 1) >> 1 : W >> 1) * (C >> 3);
     hipLaunchKernelGGL(k_pool2, dim3(vsr::cdiv(total, 256)), dim3(256), 0, vsr::S(stream), (const _Float16*)in, in_ld, in_coff,
                        (_Float16*)out, N, H, W, C, mode);
     return vsr::launched("pool2x2");

@@ -188,9 +188,11 @@ class HDeconv4s2:
 
 
 def pool2x2(x, coff, c, mode):
-    """2x2 stride-2 max (mode 0) / average (mode 1) pool of channel slice [coff, coff+c) -> dense [N,H/2,W/2,c]."""
+    """2x2 stride-2 max (mode 0) / average (mode 1) pool of channel slice [coff, coff+c) -> dense [N,H/2,W/2,c];
+    mode 2: max with ceil_mode -> [N,ceil(H/2),ceil(W/2),c]."""
     N, H, W, ld = x.shape
-    out = torch.empty((N, H // 2, W // 2, c), dtype=torch.float16, device=x.device)
+    ho, wo = ((H + 1) // 2, (W + 1) // 2) if mode == 2 else (H // 2, W // 2)
+    out = torch.empty((N, ho, wo, c), dtype=torch.float16, device=x.device)
     L.check(L.load().vsr_pool2x2_nhwc_f16(L.dptr(x, torch.float16), ld, coff, L.dptr(out, torch.float16), N, H, W, c, mode, L.stream()),
             "pool2x2")
     return out

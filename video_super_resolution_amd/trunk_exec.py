@@ -341,7 +341,13 @@ class FlowNet2Exec:
     def __call__(self, inputs):
         """inputs [B,3,2,H,W] (0..255) -> flow [B,2,H,W] float32; mirrors flownet.FlowNet2.forward."""
         inputs = inputs.float()
-        mean = inputs.contiguous().view(inputs.shape[:2] + (-1,)).mean(dim=-1).view(inputs.shape[:2] + (1, 1, 1))
+        # per-(pair, colour) mean over both frames (FlowNet2.forward's rgb_mean).  Six rows of ~10^6 elements leave a
+        # row-wise reduction on six workgroups (0.2 ms); split every row into 256 segments first.
+        flat = inputs.contiguous().view(inputs.shape[0] * inputs.shape[1], -1)
+        if flat.shape[1] % 256 == 0:
+            mean = (flat.view(flat.shape[0], 256, -1).sum(dim=-1).sum(dim=-1) / flat.shape[1]).view(inputs.shape[:2] + (1, 1, 1))
+        else:
+            mean = flat.mean(dim=-1).view(inputs.shape[:2] + (1, 1, 1))
         x = (inputs - mean) / 255.0
         x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1).contiguous()  # [B,6,H,W] float32
         x6 = to_nhwc_half(x)
@@ -390,7 +396,7 @@ class OSVOSExec:
         sides = []
         for si, items in enumerate(self.stages):
             for it in items:
-                x = _nhwc(F.max_pool2d(_nchw(x), 2, 2, ceil_mode=True)) if it == "M" else it(x)
+                x = pool2x2(x, 0, x.shape[3], 2) if it == "M" else it(x)   # MaxPool2d(2, 2, ceil_mode=True)
             if si > 0:
                 sides.append(self.side[si - 1](x))  # [N,h',w',32] (16 live)
         nb = len(sides)
