@@ -50,6 +50,15 @@ def test_conv_matches_torch(case):
     assert err <= 2e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
     if out.shape[3] > cout:  # padding channels stay zero so the tensor can feed the next layer
         assert float(out[..., cout:].abs().max()) == 0.0
+    # the first gather build (pixel operand through LDS) runs the same MFMAs in the same order: equal bit for bit
+    from video_super_resolution_amd import _lib as L
+    old = L.load().vsr_conv2d_tuning(8)
+    try:
+        out8 = conv(igemm.to_nhwc_half(x))
+        torch.cuda.synchronize()
+    finally:
+        L.load().vsr_conv2d_tuning(old)
+    assert torch.equal(out8, out)
 
 
 @pytest.mark.parametrize("case", [  # (N, Cin, H, W, Cout, k, act): the LDS-patch builds, forced (the heuristic wants >= 8192 pixels)

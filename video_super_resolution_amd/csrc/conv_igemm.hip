@@ -44,6 +44,7 @@ struct ConvP {
 
 struct C0 { static constexpr int value = 0; };
 struct C1 { static constexpr int value = 1; };
+struct C2 { static constexpr int value = 2; };
 
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
@@ -245,6 +246,192 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     for (int ks = ks0; ks < nk; ks += 2) {
         body(ks, C0{}, C1{});
         if (ks + 1 < nk) body(ks + 1, C1{}, C0{});
+    }
+
+    // ---- epilogue: this lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15
+    //      (straight from the MFMA layout: the LDS-transposed epilogue of the patch kernels was measured here too and
+    //      loses 10-25 % on these shorter, lower-resolution launches)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const long long m = m0 + 32 * wv + 16 * nt + l15;
+        if (m >= M) continue;
+        if (p.splits > 1) {
+            float* wsp = p.ws + (((size_t)zsplit * (p.nphase > 1 ? 4 : 1) + ph) * M + m) * p.cout_pad + co0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4*>(wsp + 16 * mt + 4 * g) = acc[mt][nt];
+            continue;
+        }
+        const int n = (int)(m / ((long long)p.Ho * p.Wo));
+        const int rem = (int)(m - (long long)n * p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + oy_off) * p.outW + ox * p.ox_mul + ox_off) * p.out_ld +
+                        p.out_coff;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c = co0 + 16 * mt + 4 * g;
+            if (c >= p.cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[mt][nt][r] + (p.bias ? p.bias[c + r] : 0.0f);
+                if (p.act == 1) t = fmaxf(t, 0.0f);
+                else if (p.act == 2) t = t >= 0.0f ? t : t * p.slope;
+                v[r] = t;
+            }
+            if (c + 4 <= p.cout && ((p.out_coff + c) & 3) == 0 && (p.out_ld & 3) == 0) {
+                *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < p.cout) dst[c + r] = (_Float16)v[r];
+            }
+        }
+    }
+}
+
+
+// k_conv_igemm with the PIXEL operand kept out of LDS.  A wave's MFMA B fragments are its own 32 pixels (lane: pixel
+// l15 of tile nt, 16-byte channel piece g) and no other wave reads them, so the lanes load them from global memory
+// straight in fragment layout -- the same 16-byte pieces the staging threads fetched -- three K steps deep in registers.
+// Only the weight tile, shared by the four waves, still goes through LDS.  Per K step the LDS moves 40 KB instead of
+// 72 KB against 256 MFMA cycles per wave, which is what bounded the gather kernel (LDS busy ~2x the MFMA time).
+template <int BN, bool STEM = false>
+__global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
+    constexpr int MT = BN / 16;                 // out-channel tiles per wave
+    constexpr int A_HALF = BN * 64;             // weight tile of one (tap, chunk)
+    constexpr int STAGE = 2 * A_HALF;           // one K step = two (tap, chunk) pairs = 64 K elements
+    constexpr int A_PIECES = A_HALF / 16;       // 16-byte pieces per half (<= 256)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    auto As = [&](int b, int hf) __attribute__((always_inline)) { return smem + b * STAGE + hf * A_HALF; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int co0 = blockIdx.y * BN;
+    const int nchunk = STEM ? 1 : p.cin >> 5;
+    const int npair = STEM ? p.kh : p.kh * p.kw * nchunk;     // (tap, chunk) pairs; STEM: one per kernel row
+    const int nk_all = (npair + 1) >> 1;        // K steps of two pairs (the odd tail pair is zero-filled)
+    // split-K (small pixel counts with long K, e.g. the 1/32 and 1/64-resolution FlowNet layers): blockIdx.z owns a
+    // contiguous range of K steps and writes an fp32 partial tile; k_splitk_finish sums them in a fixed order
+    const int ph = p.nphase > 1 ? (int)(blockIdx.z & 3) : 0;
+    const int zsplit = p.nphase > 1 ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
+    const _Float16* const wpk = p.nphase > 1 ? p.wpk_ph[ph] : p.wpk;
+    const int pad_y = p.nphase > 1 ? p.pad_y_ph[ph] : p.pad_y, pad_x = p.nphase > 1 ? p.pad_x_ph[ph] : p.pad_x;
+    const int oy_off = p.nphase > 1 ? p.oy_off_ph[ph] : p.oy_off, ox_off = p.nphase > 1 ? p.ox_off_ph[ph] : p.ox_off;
+    const int ks_per = (nk_all + p.splits - 1) / p.splits;
+    const int ks0 = zsplit * ks_per;
+    const int nk = min(nk_all, ks0 + ks_per);
+
+    // ---- this lane's two pixels (tile r: row 32 wv + 16 r + l15 of the workgroup's 128) and its channel piece g
+    int pn[2], piy0[2], pix0[2];
+    bool pok[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = 32 * wv + 16 * r + l15;
+        const long long m = m0 + row;
+        pok[r] = m < M;
+        const long long mm = pok[r] ? m : 0;
+        const int n = (int)(mm / ((long long)p.Ho * p.Wo));
+        const int rem = (int)(mm - (long long)n * p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        pn[r] = n;
+        piy0[r] = oy * p.stride - pad_y;
+        pix0[r] = ox * p.stride - pad_x;
+    }
+    const int bchunk = g;
+
+    // Global -> register staging, two K steps deep: the loads of step ks+2 are issued at the top of step ks and stored to
+    // LDS at the end of step ks+1.  Every load is a buffer load whose offset is out of range when the piece does not
+    // exist (padding, tail, idle thread) -- the hardware returns zeros -- so a step issues a FIXED number of loads and
+    // hipcc can wait with vmcnt(6) for the older set only (conditional loads forced vmcnt(0): one step of cover).
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(wpk), 0, (int)((size_t)(STEM ? p.kh : p.kh * p.kw * nchunk) * p.cout_pad * 64), 0x00020000);
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.in_ld * 2), 0x00020000);
+    u4 ra[2][2], rb[3][2][2];
+    auto gload = [&](int ks, auto setc, auto setb) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value, SB = decltype(setb)::value;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int pr = 2 * ks + hf;
+            const bool live = pr < npair;
+            const int prc = live ? pr : 0;
+            const int tap = prc / nchunk, ch = prc - tap * nchunk;
+            const int ky = STEM ? tap : tap / p.kw, kx = STEM ? 2 * bchunk : tap - ky * p.kw;
+            // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0.. contiguous
+            const unsigned woff = (live && tid < A_PIECES) ? (unsigned)((((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8) * 2) : 0xFFFFFFFFu;
+            ra[S][hf] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, woff, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int iy = piy0[r] + ky, ix = pix0[r] + kx;
+                const bool rowok = live && pok[r] && iy >= 0 && iy < p.H;
+                if (STEM) {   // this 16-byte piece = taps kx, kx+1 of kernel row ky: two 8-byte pixels
+                    const size_t rowb = ((size_t)pn[r] * p.H + iy) * p.W * 8;
+                    const unsigned o0 = (rowok && ix >= 0 && ix < p.W) ? (unsigned)(rowb + (size_t)ix * 8) : 0xFFFFFFFFu;
+                    const unsigned o1 = (rowok && ix + 1 >= 0 && ix + 1 < p.W) ? (unsigned)(rowb + (size_t)(ix + 1) * 8) : 0xFFFFFFFFu;
+                    const u2 t0 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, o0, 0, 0);
+                    const u2 t1 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, o1, 0, 0);
+                    rb[SB][hf][r] = u4{t0[0], t0[1], t1[0], t1[1]};
+                } else {
+                    const unsigned off = (rowok && ix >= 0 && ix < p.W)
+                        ? (unsigned)(((((size_t)pn[r] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + ch * 32 + bchunk * 8) * 2) : 0xFFFFFFFFu;
+                    rb[SB][hf][r] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+                }
+            }
+        }
+    };
+    auto lstore = [&](int buf, auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (tid < A_PIECES) *reinterpret_cast<u4*>(As(buf, hf) + sw_off(tid >> 2, tid & 3)) = ra[S][hf];
+        }
+    };
+
+    f4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (ks0 < nk) {
+        gload(ks0, C0{}, C0{});
+        lstore(ks0 & 1, C0{});
+        if (ks0 + 1 < nk) gload(ks0 + 1, C1{}, C1{});
+    }
+    __syncthreads();
+    // step ks (i = ks - ks0): weights in LDS buffer ks&1, pixels in register set i%3; step ks+1 is in flight (weights in
+    // set (i+1)&1, pixels in set (i+1)%3); step ks+2 is requested at the top of the step into the sets step ks-1 used
+    auto body = [&](int ks, auto amine, auto aother, auto bcur, auto bnew) __attribute__((always_inline)) {
+        constexpr int BC = decltype(bcur)::value;
+        const int buf = ks & 1;
+        if (ks + 2 < nk) gload(ks + 2, amine, bnew);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            h8 bf[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bf[nt] = __builtin_bit_cast(h8, rb[BC][hf][nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h8 af = *reinterpret_cast<const h8*>(As(buf, hf) + sw_off(16 * mt + l15, g));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        if (ks + 1 < nk) lstore(buf ^ 1, aother);
+        __syncthreads();
+    };
+    for (int ks = ks0; ks < nk; ks += 6) {   // lcm of the two-deep weight sets and the three-deep pixel sets
+        body(ks, C0{}, C1{}, C0{}, C2{});
+        if (ks + 1 < nk) body(ks + 1, C1{}, C0{}, C1{}, C0{});
+        if (ks + 2 < nk) body(ks + 2, C0{}, C1{}, C2{}, C1{});
+        if (ks + 3 < nk) body(ks + 3, C1{}, C0{}, C0{}, C2{});
+        if (ks + 4 < nk) body(ks + 4, C0{}, C1{}, C1{}, C0{});
+        if (ks + 5 < nk) body(ks + 5, C1{}, C0{}, C2{}, C1{});
     }
 
     // ---- epilogue: this lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15
@@ -953,7 +1140,7 @@ __global__ void __launch_bounds__(256) k_corr_mfma(const _Float16* __restrict__ 
 }
 
 static int g_splitk_fill = 256;   // split K when a launch has fewer workgroups than this (measured: tools/probe_splitk.py)
-static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows (tuning hook)
+static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm (tuning hook)
 
 extern "C" {
 
@@ -1059,9 +1246,15 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
     p.ws = splits > 1 ? (float*)splitk_ws : nullptr;
     p.splits = splits;
     const dim3 grid(gx, gy, 4 * splits);
-    if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, vsr::S(stream), p);
-    else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, vsr::S(stream), p);
-    else hipLaunchKernelGGL(k_conv_igemm<16>, grid, dim3(256), 0, vsr::S(stream), p);
+    if (g_patch_mode == 8) {   // the first gather build (pixel operand through LDS): cross-check / A-B
+        if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, vsr::S(stream), p);
+        else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, vsr::S(stream), p);
+        else hipLaunchKernelGGL(k_conv_igemm<16>, grid, dim3(256), 0, vsr::S(stream), p);
+    } else {
+        if (bn == 64) hipLaunchKernelGGL(k_conv_igemm_d<64>, grid, dim3(256), 0, vsr::S(stream), p);
+        else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm_d<32>, grid, dim3(256), 0, vsr::S(stream), p);
+        else hipLaunchKernelGGL(k_conv_igemm_d<16>, grid, dim3(256), 0, vsr::S(stream), p);
+    }
     if (splits > 1) {
         int rc = vsr::launched("deconv4s2_nhwc_f16");
         if (rc) return rc;
@@ -1098,9 +1291,15 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
     }
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const dim3 grid(vsr::cdiv(M, BM), cout_pad / bn, 1);
-    if (bn == 64) hipLaunchKernelGGL((k_conv_igemm<64, true>), grid, dim3(256), 0, vsr::S(stream), p);
-    else if (bn == 32) hipLaunchKernelGGL((k_conv_igemm<32, true>), grid, dim3(256), 0, vsr::S(stream), p);
-    else hipLaunchKernelGGL((k_conv_igemm<16, true>), grid, dim3(256), 0, vsr::S(stream), p);
+    if (g_patch_mode == 8) {
+        if (bn == 64) hipLaunchKernelGGL((k_conv_igemm<64, true>), grid, dim3(256), 0, vsr::S(stream), p);
+        else if (bn == 32) hipLaunchKernelGGL((k_conv_igemm<32, true>), grid, dim3(256), 0, vsr::S(stream), p);
+        else hipLaunchKernelGGL((k_conv_igemm<16, true>), grid, dim3(256), 0, vsr::S(stream), p);
+    } else {
+        if (bn == 64) hipLaunchKernelGGL((k_conv_igemm_d<64, true>), grid, dim3(256), 0, vsr::S(stream), p);
+        else if (bn == 32) hipLaunchKernelGGL((k_conv_igemm_d<32, true>), grid, dim3(256), 0, vsr::S(stream), p);
+        else hipLaunchKernelGGL((k_conv_igemm_d<16, true>), grid, dim3(256), 0, vsr::S(stream), p);
+    }
     return vsr::launched("conv2d_stem_f16");
 }
 
@@ -1205,9 +1404,15 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
     p.ws = splits > 1 ? (float*)splitk_ws : nullptr;
     p.splits = splits;
     const dim3 grid(gx, gy, splits);
-    if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, vsr::S(stream), p);
-    else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, vsr::S(stream), p);
-    else hipLaunchKernelGGL(k_conv_igemm<16>, grid, dim3(256), 0, vsr::S(stream), p);
+    if (g_patch_mode == 8) {   // the first gather build (pixel operand through LDS): cross-check / A-B
+        if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, vsr::S(stream), p);
+        else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, vsr::S(stream), p);
+        else hipLaunchKernelGGL(k_conv_igemm<16>, grid, dim3(256), 0, vsr::S(stream), p);
+    } else {
+        if (bn == 64) hipLaunchKernelGGL(k_conv_igemm_d<64>, grid, dim3(256), 0, vsr::S(stream), p);
+        else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm_d<32>, grid, dim3(256), 0, vsr::S(stream), p);
+        else hipLaunchKernelGGL(k_conv_igemm_d<16>, grid, dim3(256), 0, vsr::S(stream), p);
+    }
     if (splits > 1) {
         int rc = vsr::launched("conv2d_nhwc_f16");
         if (rc) return rc;
