@@ -333,6 +333,12 @@ class FlowNet2Exec:
         self.sd = _FlowNetSDExec(net.flownets_d)
         self.fusion = _FusionExec(net.flownetfusion)
 
+    def _sd_stream(self, dev):
+        key = (dev.type, dev.index)
+        if getattr(self, "_sd_key", None) != key:
+            self._sd_side, self._sd_key = torch.cuda.Stream(device=dev), key
+        return self._sd_side
+
     @staticmethod
     def _flow_nchw(t):  # [B,h,w,>=2] half -> [B,2,h,w] float
         return t[..., :2].permute(0, 3, 1, 2).float()
@@ -353,14 +359,25 @@ class FlowNet2Exec:
         x6 = to_nhwc_half(x)
         up_bil = lambda t: F.interpolate(self._flow_nchw(t), scale_factor=4, mode="bilinear")
         up_nn = lambda t: F.interpolate(self._flow_nchw(t), scale_factor=4, mode="nearest")
+        # FlowNetSD depends only on the input pair: it runs on its own HIP stream beside the C -> S1 -> S2 chain (whose
+        # 1/16..1/64-resolution layers are latency-bound launches of a few hundred workgroups) and joins at the fusion
+        main = torch.cuda.current_stream(x.device)
+        side = self._sd_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            flow_sd = up_nn(self.sd(x6)) / self.div_flow
+            n_sd, d_sd = ops.warp_norms(x, flow_sd)
+            for t in (flow_sd, n_sd, d_sd):
+                t.record_stream(main)
+        x.record_stream(side)
+        x6.record_stream(side)
         flow_c = up_bil(self.c(x6)) * self.div_flow
         concat1 = ops.warp_concat(x, flow_c, self.div_flow)
         flow_s1 = up_bil(self.s1(to_nhwc_half(concat1))) * self.div_flow
         concat2 = ops.warp_concat(x, flow_s1, self.div_flow)
         flow_s2 = up_nn(self.s2(to_nhwc_half(concat2))) * self.div_flow
         n_s2, d_s2 = ops.warp_norms(x, flow_s2)
-        flow_sd = up_nn(self.sd(x6)) / self.div_flow
-        n_sd, d_sd = ops.warp_norms(x, flow_sd)
+        main.wait_stream(side)
         concat3 = torch.cat((x[:, :3], flow_sd, flow_s2, n_sd, n_s2, d_sd, d_s2), dim=1)
         return self._flow_nchw(self.fusion(to_nhwc_half(concat3)))
 
