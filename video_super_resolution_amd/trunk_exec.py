@@ -12,6 +12,7 @@ channel slices of the destination buffer.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -127,7 +128,36 @@ class HourglassExec:
             return ("I", _Inception(mod))
         raise ValueError(node)
 
-    def _run(self, node, x, coff, c):
+    def _side(self, dev, level):
+        key = (dev.type, dev.index)
+        if getattr(self, "_side_key", None) != key:
+            self._side_streams, self._side_key = {}, key
+        if level not in self._side_streams:
+            self._side_streams[level] = torch.cuda.Stream(device=dev)
+        return self._side_streams[level]
+
+    def _fan_out(self, subs, x, coff, c, level):
+        """The two arms of an hourglass level (the skip inceptions at this resolution / pool -> inner levels -> upsample)
+        are independent until their sum: the first runs on a side stream of its own (one per nesting level), so the
+        latency-bound low-resolution launches of the inner levels overlap the wide layers of the outer skips."""
+        if len(subs) != 2 or not self.concurrent:
+            return [self._run(sub, x, coff, c, level + 1) for sub in subs]
+        cur = torch.cuda.current_stream(x.device)
+        side = self._side(x.device, level)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            first = self._run(subs[0], x, coff, c, level + 1)
+            first[0].record_stream(cur)
+        x.record_stream(side)
+        second = self._run(subs[1], x, coff, c, level + 1)
+        cur.wait_stream(side)
+        return [first, second]
+
+    # Off by default: alone the trunk gains 8 % (5.5 -> 5.1 ms for four frames) but inside VSR.forward, where FlowNet2
+    # already runs beside it, the frame loses 1.8 ms (same-box A/B, tools/depth_ab.py and bench.py); results are identical.
+    concurrent = os.environ.get("VSR_HOURGLASS_STREAMS", "0") == "1"
+
+    def _run(self, node, x, coff, c, level=0):
         """x: NHWC buffer whose live channels are [coff, coff+c) -> (buffer, coff, c)."""
         if node == "max" or node == "avg":
             return pool2x2(x, coff, c, 0 if node == "max" else 1), 0, c
@@ -148,9 +178,9 @@ class HourglassExec:
                     (a, ca, na), (b, cb, nb) = x  # list from the preceding fan-out
                     x, coff, c = resize_add(a, ca, nb, (b.shape[1], b.shape[2]), b, cb), 0, nb
                 elif isinstance(ch, tuple) and ch[0] == "M":
-                    x = [self._run(sub, x, coff, c) for sub in ch[1]]
+                    x = self._fan_out(ch[1], x, coff, c, level)
                 else:
-                    x, coff, c = self._run(ch, x, coff, c)
+                    x, coff, c = self._run(ch, x, coff, c, level)
             return x, coff, c
         raise ValueError(node)
 
