@@ -392,7 +392,7 @@ class FlowNet2Exec:
         # FlowNetSD depends only on the input pair: it runs on its own HIP stream beside the C -> S1 -> S2 chain (whose
         # 1/16..1/64-resolution layers are latency-bound launches of a few hundred workgroups) and joins at the fusion
         main = torch.cuda.current_stream(x.device)
-        side = self._sd_stream(x.device)
+        side = self._sd_stream(x.device) if os.environ.get("VSR_FLOWSD_STREAM", "1") != "0" else main   # (A/B switch)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             flow_sd = up_nn(self.sd(x6)) / self.div_flow
