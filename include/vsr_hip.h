@@ -151,7 +151,8 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
  *   4  build 0 stamped around the whole march only (cycles and clock without perturbing the step). */
 int vsr_sr_utd_variant(int variant);
 /* Build vsr_sr_chain1x1_f16 launches (process-wide; returns the previous setting): 0 = the streaming builds specialised
- * on the glue's launch shapes where one exists (default), 1 = always the generic kernel (cross-check; same results). */
+ * on the glue's launch shapes where one exists (default), 1 = always the generic kernel (cross-check; same results).
+ * Bit 1 of the argument (value 2) sends full frames of vsr_sr_fc_planes_skip_f32 through its one-pixel build as well. */
 int vsr_sr_chain_variant(int generic);
 /* Device buffer the stamped builds write to: [workgroup][wave 8][8] uint64 (phase cycle sums, loop cycles, loop time in
  * 10 ns ticks).  NULL detaches. */

@@ -188,3 +188,24 @@ def test_chain_builds_bit_identical(gpu_vsr_f16, shape):
         lib.vsr_sr_chain_variant(0)
     assert torch.isfinite(got).all()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (9, 40), (37, 33), (2, 2), (1, 7)])
+def test_fusion_builds_bit_identical(gpu_vsr_f16, shape):
+    """Fusion MLP + skip over the raw planes: four pixels per thread on packed fp32 pairs (full frames) against one
+    pixel per thread (the decimated pass's build): every product-sum is an explicit fma in both, so they agree exactly."""
+    from video_super_resolution_amd import _lib as L
+    m = gpu_vsr_f16.model
+    h, w = shape
+    x = torch.from_numpy(np.random.RandomState(h * 13 + w).randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    lib = L.load()
+    try:
+        with torch.no_grad():
+            lib.vsr_sr_chain_variant(2)
+            ref = m(x).clone()
+            lib.vsr_sr_chain_variant(0)
+            got = m(x)
+    finally:
+        lib.vsr_sr_chain_variant(0)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref)

@@ -1157,6 +1157,14 @@ k_fc_planes(const float* __restrict__ prefc, const float* __restrict__ w1, const
 // ---- the same MLP reading the tail's RAW planes (conv_out 3x3 + bias, k_tail3) and finishing them on the fly:
 //      plane = (bilinear x4 of sub_mean(x) + raw) * add_scale + add_bias  (SRProjectionModule.py:136,142-143).
 //      dec != 0: the planes and the output hold only the pixels (4i, 4j).
+//      Every product-sum below is an explicit fma (contraction off), so the one-pixel build (decimated pass) and the
+//      four-pixel build (full frame) round identically: the decimated frame IS the full frame at (4i, 4j), bit for bit.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float fc_lerp4(float v00, float v01, float v10, float v11, float lx, float ly) {
+    const float top = __builtin_fmaf(lx, v01, (1.0f - lx) * v00), bot = __builtin_fmaf(lx, v11, (1.0f - lx) * v10);
+    return __builtin_fmaf(ly, bot, (1.0f - ly) * top);
+}
+
 template <int NPL, int HID>
 __global__ void __launch_bounds__(256)
 k_fc_planes_skip(const float* __restrict__ raw, const float* __restrict__ x, const float* __restrict__ tpar,
@@ -1177,21 +1185,79 @@ k_fc_planes_skip(const float* __restrict__ raw, const float* __restrict__ x, con
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const float* xp = x + ((size_t)i * 3 + c) * (size_t)h * w;
-        const float v00 = xp[(size_t)y0 * w + x0i] * sub_s + sub_b, v01 = xp[(size_t)y0 * w + x1i] * sub_s + sub_b;
-        const float v10 = xp[(size_t)y1 * w + x0i] * sub_s + sub_b, v11 = xp[(size_t)y1 * w + x1i] * sub_s + sub_b;
-        const float skip = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
-        v[i] = (skip + raw[((size_t)i * 3 + c) * P + p]) * add_s + add_b;
+        const float v00 = __builtin_fmaf(xp[(size_t)y0 * w + x0i], sub_s, sub_b), v01 = __builtin_fmaf(xp[(size_t)y0 * w + x1i], sub_s, sub_b);
+        const float v10 = __builtin_fmaf(xp[(size_t)y1 * w + x0i], sub_s, sub_b), v11 = __builtin_fmaf(xp[(size_t)y1 * w + x1i], sub_s, sub_b);
+        v[i] = __builtin_fmaf(fc_lerp4(v00, v01, v10, v11, lx, ly) + raw[((size_t)i * 3 + c) * P + p], add_s, add_b);
     }
     float o = b2[0];
 #pragma unroll
     for (int j = 0; j < HID; ++j) {
         float hs = b1[j];
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) hs += w1[j * NPL + i] * v[i];
-        o += w2[j] * fmaxf(hs, 0.0f);
+        for (int i = 0; i < NPL; ++i) hs = __builtin_fmaf(w1[j * NPL + i], v[i], hs);
+        o = __builtin_fmaf(w2[j], fmaxf(hs, 0.0f), o);
     }
     out[(size_t)c * P + p] = fmaxf(o, 0.0f);
 }
+
+// Full frame: four horizontally adjacent output pixels per thread (columns 4q..4q+3 read LR columns q-1, q, q+1 of
+// two rows: six loads per plane instead of sixteen; raw planes and output as 16-byte accesses) and the MLP on packed
+// fp32 pairs (v_pk_fma_f32).  The one-pixel build was VALU-bound at 0.33 ms.
+template <int NPL, int HID>
+__global__ void __launch_bounds__(256)
+k_fc_planes_skip4(const float* __restrict__ raw, const float* __restrict__ x, const float* __restrict__ tpar,
+                  const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                  const float* __restrict__ b2, float* __restrict__ out, int h, int w) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int c = blockIdx.y;
+    const int Ho = 4 * h;
+    const size_t P = (size_t)Ho * 4 * w;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;   // (row yo, column group q)
+    if (t >= (size_t)Ho * w) return;
+    const int yo = (int)(t / w), q = (int)(t - (size_t)yo * w);
+    int y0, y1;
+    float ly;
+    bil4(yo, h, y0, y1, ly);
+    int xa[4], xb[4];
+    float lx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bil4(4 * q + j, w, xa[j], xb[j], lx[j]);
+    const int cm = q > 0 ? q - 1 : 0, cp = q < w - 1 ? q + 1 : q;   // every xa / xb is one of cm, q, cp
+    const float sub_s = tpar[3 + c], sub_b = tpar[6 + c], add_s = tpar[9 + c], add_b = tpar[12 + c];
+    const size_t p = (size_t)yo * 4 * w + 4 * q;
+    float v[NPL][4];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const float* xp = x + ((size_t)i * 3 + c) * (size_t)h * w;
+        const float* r0 = xp + (size_t)y0 * w;
+        const float* r1 = xp + (size_t)y1 * w;
+        const float a0 = __builtin_fmaf(r0[cm], sub_s, sub_b), a1 = __builtin_fmaf(r0[q], sub_s, sub_b), a2 = __builtin_fmaf(r0[cp], sub_s, sub_b);
+        const float c0 = __builtin_fmaf(r1[cm], sub_s, sub_b), c1 = __builtin_fmaf(r1[q], sub_s, sub_b), c2 = __builtin_fmaf(r1[cp], sub_s, sub_b);
+        const f4 rw = *reinterpret_cast<const f4*>(raw + ((size_t)i * 3 + c) * P + p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v00 = xa[j] == q ? a1 : (xa[j] == cm ? a0 : a2), v01 = xb[j] == q ? a1 : (xb[j] == cm ? a0 : a2);
+            const float v10 = xa[j] == q ? c1 : (xa[j] == cm ? c0 : c2), v11 = xb[j] == q ? c1 : (xb[j] == cm ? c0 : c2);
+            v[i][j] = __builtin_fmaf(fc_lerp4(v00, v01, v10, v11, lx[j], ly) + rw[j], add_s, add_b);
+        }
+    }
+    f2 o[2] = {f2{b2[0], b2[0]}, f2{b2[0], b2[0]}};
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+        f2 hs[2] = {f2{b1[j], b1[j]}, f2{b1[j], b1[j]}};
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const float wv = w1[j * NPL + i];
+            hs[0] = __builtin_elementwise_fma(f2{wv, wv}, f2{v[i][0], v[i][1]}, hs[0]);
+            hs[1] = __builtin_elementwise_fma(f2{wv, wv}, f2{v[i][2], v[i][3]}, hs[1]);
+        }
+        const float w2j = w2[j];
+        o[0] = __builtin_elementwise_fma(f2{w2j, w2j}, __builtin_elementwise_max(hs[0], f2{0.0f, 0.0f}), o[0]);
+        o[1] = __builtin_elementwise_fma(f2{w2j, w2j}, __builtin_elementwise_max(hs[1], f2{0.0f, 0.0f}), o[1]);
+    }
+    *reinterpret_cast<f4*>(out + (size_t)c * P + p) = f4{fmaxf(o[0][0], 0.0f), fmaxf(o[0][1], 0.0f), fmaxf(o[1][0], 0.0f), fmaxf(o[1][1], 0.0f)};
+}
+#pragma clang fp contract(fast)
 
 }  // namespace
 
@@ -1205,13 +1271,15 @@ int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags
                  int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream);
 }
 
+static int g_fc_one_pixel = 0;     // 1: full frames through the one-pixel fusion build too (cross-check)
 static int g_chain_generic = 0;   // 1: every chain through the generic build (cross-check / A-B)
 
 extern "C" {
 
 int vsr_sr_chain_variant(int generic) {
-    const int old = g_chain_generic;
-    g_chain_generic = generic;
+    const int old = g_chain_generic | (g_fc_one_pixel << 1);
+    g_chain_generic = generic & 1;
+    g_fc_one_pixel = (generic >> 1) & 1;
     return old;
 }
 
@@ -1412,8 +1480,12 @@ int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tai
     if (nplanes != 8 || hidden != 32)
         return vsr::fail(VSR_E_UNSUPPORTED, "sr_fc_planes_skip: %d planes / %d hidden units (the reference fuses 8 through 32)", nplanes, hidden);
     const size_t P = decimate ? (size_t)h * w : (size_t)16 * h * w;
-    hipLaunchKernelGGL((k_fc_planes_skip<8, 32>), dim3(vsr::cdiv(P, 256), 3), dim3(256), 0, vsr::S(stream), raw, x, tail_params, w1, b1,
-                       w2, b2, out, h, w, decimate);
+    if (decimate || g_fc_one_pixel)
+        hipLaunchKernelGGL((k_fc_planes_skip<8, 32>), dim3(vsr::cdiv(P, 256), 3), dim3(256), 0, vsr::S(stream), raw, x, tail_params, w1, b1,
+                           w2, b2, out, h, w, decimate);
+    else
+        hipLaunchKernelGGL((k_fc_planes_skip4<8, 32>), dim3(vsr::cdiv(P / 4, 256), 3), dim3(256), 0, vsr::S(stream), raw, x, tail_params,
+                           w1, b1, w2, b2, out, h, w);
     return vsr::launched("sr_fc_planes_skip");
 }
 
