@@ -21,4 +21,8 @@ rows.sort(key=lambda r: -r[2])
 print(f"aten ops, self device time: total {sum(r[2] for r in rows):.3f} ms in {sum(r[1] for r in rows)} calls")
 for k, c, t in rows[:25]:
     print(f"   {k:40s} x{c:4d} {t:8.3f} ms")
-print(prof.key_averages(group_by_stack_n=4).table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=40, max_src_column_width=90))
+ev = [e for e in prof.key_averages(group_by_stack_n=6) if e.key.startswith("aten::") and e.self_device_time_total > 0]
+ev.sort(key=lambda e: -e.self_device_time_total)
+for e in ev[:45]:
+    st = [f for f in e.stack if "video_super_resolution_amd" in f]
+    print(f"{e.key:28s} x{e.count:3d} {e.self_device_time_total/1e3:7.3f} ms  <- " + " <- ".join(x.split("video_super_resolution_amd/")[-1] for x in st[:3]))

@@ -1,4 +1,4 @@
-"""EXPERIMENT (timing only): 1x1 streaming kernel with and without its stores."""
+"""Time of the 1x1 streaming kernel on the hourglass's fused inception reductions."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,12 +11,14 @@ def t(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for (N, cin, H, W, cout) in [(4, 128, 540, 960, 208), (4, 128, 270, 480, 224), (4, 128, 270, 480, 128)]:
+cases = [(4, 128, 540, 960, 208), (4, 128, 270, 480, 224), (4, 128, 270, 480, 128)]
+if len(sys.argv) > 1: cases = cases[:1]
+for (N, cin, H, W, cout) in cases:
     x = torch.randn(N, H, W, cin, device="cuda").half()
     w = torch.randn(cout, cin, 1, 1, device="cuda") / cin ** 0.5
     conv = igemm.HConv(w, torch.zeros(cout, device="cuda"), stride=1, pad=0, act=igemm.ACT_RELU)
     r = []
-    for mode, nm in ((0, "full"), (13, "no stores")):
+    for mode, nm in ((0, "stream"),) if len(sys.argv) > 1 else ((0, "stream"), (1, "gather")):
         L.load().vsr_conv2d_tuning(mode)
         ms = t(lambda: conv(x))
         r.append(f"{nm} {ms*1e3:7.1f} us")

@@ -493,6 +493,10 @@ __global__ void __launch_bounds__(512) k_conv1x1_stream(const ConvP p) {
     const int rows = NCH * p.cout_pad;
     for (int q = tid; q < rows * 4; q += 512)
         *reinterpret_cast<uint4*>(wsm + sw_off(q >> 2, q & 3)) = *reinterpret_cast<const uint4*>(p.wpk + (size_t)q * 8);
+    // bias beside the weights: a global load per out-channel block inside the persistent loop put one memory latency
+    // (microseconds under this kernel's own traffic) in front of every block's stores
+    float* const bsm = reinterpret_cast<float*>(wsm + (size_t)rows * 64);
+    for (int q = tid; q < p.cout_pad; q += 512) bsm[q] = (p.bias && q < p.cout) ? p.bias[q] : 0.0f;
     __syncthreads();
     const int ntile = p.cout_pad >> 4;
     const long long nblk = (M + 255) / 256;
@@ -544,7 +548,7 @@ __global__ void __launch_bounds__(512) k_conv1x1_stream(const ConvP p) {
             if (c0 >= p.cout) continue;
             float bz[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) bz[r] = (p.bias && r < nch && c0 + r < p.cout) ? p.bias[c0 + r] : 0.0f;
+            for (int r = 0; r < 8; ++r) bz[r] = (r < nch && c0 + r < p.cout_pad) ? bsm[c0 + r] : 0.0f;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const long long m = mbase + 16 * nt + l15;
@@ -1379,13 +1383,14 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
         static const k1_t k1[C1_MAX_CHUNKS] = {k_conv1x1_stream<1>, k_conv1x1_stream<2>, k_conv1x1_stream<3>, k_conv1x1_stream<4>,
                                                k_conv1x1_stream<5>, k_conv1x1_stream<6>, k_conv1x1_stream<7>, k_conv1x1_stream<8>};
         const k1_t k = k1[(cin >> 5) - 1];
-        if (w_lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w_lds) != hipSuccess)
-            return vsr::fail(VSR_E_LAUNCH, "conv2d/1x1: cannot reserve %zu bytes of LDS", w_lds);
-        const int per_cu = (int)((160 * 1024) / w_lds) < 2 ? 1 : 2;   // 512-thread workgroups resident per CU
+        const size_t k_lds = w_lds + (size_t)cout_pad * 4;   // weights + bias
+        if (k_lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k_lds) != hipSuccess)
+            return vsr::fail(VSR_E_LAUNCH, "conv2d/1x1: cannot reserve %zu bytes of LDS", k_lds);
+        const int per_cu = (int)((160 * 1024) / k_lds) < 2 ? 1 : 2;   // 512-thread workgroups resident per CU
         const long long nblk = (M + 255) / 256;
         const unsigned grid = (unsigned)(nblk < 256LL * per_cu ? nblk : 256LL * per_cu);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), w_lds, vsr::S(stream), p);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), k_lds, vsr::S(stream), p);
         return vsr::launched("conv2d_nhwc_f16/1x1");
     }
     const unsigned gx = vsr::cdiv(M, BM);
