@@ -20,6 +20,9 @@ CASES = [  # (N, Cin, H, W, Cout, k, stride, pad, act)
     (3, 64, 6, 5, 1, 3, 1, 1, igemm.ACT_NONE),         # single output channel
     (1, 256, 33, 47, 512, 3, 2, 1, igemm.ACT_LEAKY),   # stride 2
     (1, 96, 130, 3, 48, 3, 1, 1, igemm.ACT_RELU),      # narrow, more pixels than one tile
+    (1, 64, 92, 94, 256, 3, 2, 1, igemm.ACT_LEAKY),    # stride 2, 256 out-channels (128-channel tiles when forced below)
+    (2, 128, 131, 67, 128, 5, 2, 2, igemm.ACT_RELU),   # 5x5 stride 2, ragged
+    (4, 64, 128, 130, 128, 3, 2, 1, igemm.ACT_LEAKY),  # enough workgroups for the 128-channel gather tile by default
     (2, 64, 37, 61, 1, 3, 1, 1, igemm.ACT_NONE),       # hourglass final conv: LDS-patch path (cout <= 16, stride 1)
     (1, 64, 20, 50, 16, 11, 1, 5, igemm.ACT_RELU),     # 16-wide 11x11 inception branch: patch path
     (1, 194, 33, 47, 2, 3, 1, 1, igemm.ACT_NONE),      # predict_flow2: patch path over 7 channel chunks
@@ -50,7 +53,7 @@ def test_conv_matches_torch(case):
     assert err <= 2e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
     if out.shape[3] > cout:  # padding channels stay zero so the tensor can feed the next layer
         assert float(out[..., cout:].abs().max()) == 0.0
-    # the first gather build (pixel operand through LDS) runs the same MFMAs in the same order: equal bit for bit
+    # the first gather build (pixel operand through LDS, 64-channel tiles) runs the same MFMAs in the same order: equal bit for bit
     from video_super_resolution_amd import _lib as L
     old = L.load().vsr_conv2d_tuning(8)
     try:
@@ -58,7 +61,18 @@ def test_conv_matches_torch(case):
         torch.cuda.synchronize()
     finally:
         L.load().vsr_conv2d_tuning(old)
-    assert torch.equal(out8, out)
+    if cout <= 64 or (N * out.shape[1] * out.shape[2] + 127) // 128 * ((cout + 127) // 128) < 128:
+        assert torch.equal(out8, out)   # (128-channel tiles may split K differently: a different fp32 summation order)
+    else:
+        assert (igemm.to_nchw_float(out8, cout) - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    for mode in (10, 11):   # 128-channel gather tiles wherever the channel count allows / nowhere
+        old = L.load().vsr_conv2d_tuning(mode)
+        try:
+            outm = conv(igemm.to_nhwc_half(x))
+            torch.cuda.synchronize()
+        finally:
+            L.load().vsr_conv2d_tuning(old)
+        assert (igemm.to_nchw_float(outm, cout) - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), mode
 
 
 @pytest.mark.parametrize("case", [  # (N, Cin, H, W, Cout, k, act): the LDS-patch builds, forced (the heuristic wants >= 8192 pixels)

@@ -19,7 +19,7 @@ def t(fn, reps=6):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 for rnd in range(2):
-    for mode in (8, 0):
+    for mode in (11, 0):
         L.load().vsr_conv2d_tuning(mode)
-        print(f"mode {mode} ({'k_conv_igemm_d' if mode == 0 else 'k_conv_igemm  '}): " + "  ".join(f"{k} {t(fn):.3f} ms" for k, fn in stages.items()), flush=True)
+        print(f"mode {mode} ({'128-channel tiles where they pay' if mode == 0 else '64-channel tiles only            '}): " + "  ".join(f"{k} {t(fn):.3f} ms" for k, fn in stages.items()), flush=True)
 L.load().vsr_conv2d_tuning(0)

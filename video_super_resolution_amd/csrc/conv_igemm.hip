@@ -300,7 +300,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
     constexpr int MT = BN / 16;                 // out-channel tiles per wave
     constexpr int A_HALF = BN * 64;             // weight tile of one (tap, chunk)
     constexpr int STAGE = 2 * A_HALF;           // one K step = two (tap, chunk) pairs = 64 K elements
-    constexpr int A_PIECES = A_HALF / 16;       // 16-byte pieces per half (<= 256)
+    constexpr int A_PIECES = A_HALF / 16;       // 16-byte pieces per half
+    constexpr int AP = (A_PIECES + 255) / 256;  // ... per thread (2 for the 128-channel tile)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
     auto As = [&](int b, int hf) __attribute__((always_inline)) { return smem + b * STAGE + hf * A_HALF; };
 
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
         const_cast<_Float16*>(wpk), 0, (int)((size_t)(STEM ? p.kh : p.kh * p.kw * nchunk) * p.cout_pad * 64), 0x00020000);
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.in_ld * 2), 0x00020000);
-    u4 ra[2][2], rb[3][2][2];
+    u4 ra[2][2][AP], rb[3][2][2];
     auto gload = [&](int ks, auto setc, auto setb) __attribute__((always_inline)) {
         constexpr int S = decltype(setc)::value, SB = decltype(setb)::value;
 #pragma unroll
@@ -362,8 +363,12 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
             const int tap = prc / nchunk, ch = prc - tap * nchunk;
             const int ky = STEM ? tap : tap / p.kw, kx = STEM ? 2 * bchunk : tap - ky * p.kw;
             // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0.. contiguous
-            const unsigned woff = (live && tid < A_PIECES) ? (unsigned)((((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8) * 2) : 0xFFFFFFFFu;
-            ra[S][hf] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, woff, 0, 0);
+#pragma unroll
+            for (int ap = 0; ap < AP; ++ap) {
+                const int piece = tid + 256 * ap;
+                const unsigned woff = (live && piece < A_PIECES) ? (unsigned)((((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + piece * 8) * 2) : 0xFFFFFFFFu;
+                ra[S][hf][ap] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, woff, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int iy = piy0[r] + ky, ix = pix0[r] + kx;
@@ -387,7 +392,11 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
         constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            if (tid < A_PIECES) *reinterpret_cast<u4*>(As(buf, hf) + sw_off(tid >> 2, tid & 3)) = ra[S][hf];
+#pragma unroll
+            for (int ap = 0; ap < AP; ++ap) {
+                const int piece = tid + 256 * ap;
+                if (piece < A_PIECES) *reinterpret_cast<u4*>(As(buf, hf) + sw_off(piece >> 2, piece & 3)) = ra[S][hf][ap];
+            }
         }
     };
 
@@ -1144,7 +1153,7 @@ __global__ void __launch_bounds__(256) k_corr_mfma(const _Float16* __restrict__ 
 }
 
 static int g_splitk_fill = 256;   // split K when a launch has fewer workgroups than this (measured: tools/probe_splitk.py)
-static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm (tuning hook)
+static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
 
 extern "C" {
 
@@ -1394,7 +1403,12 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
         return vsr::launched("conv2d_nhwc_f16/1x1");
     }
     const unsigned gx = vsr::cdiv(M, BM);
-    const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);  // widest tile the padded count fills
+    // widest tile the padded count fills; 128 out-channels per workgroup (half the pixel-operand traffic per FLOP: these
+    // layers run at the L2's bandwidth, 43 FLOP per byte with the 128 x 64 tile) when that still leaves 128 workgroups
+    // before split-K (measured per layer, tools/probe_layers.py with VSR_TUNING=10 / 11)
+    const bool wide = (cout_pad & 127) == 0 && g_patch_mode != 8 && g_patch_mode != 11 &&
+                      (g_patch_mode == 10 || (long long)gx * (cout_pad / 128) >= 128);
+    const int bn = wide ? 128 : (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const unsigned gy = cout_pad / bn;
     // split-K when the launch cannot fill the chip and K is long
     const int nk_all = (kh * kw * (cin >> 5) + 1) >> 1;
@@ -1414,7 +1428,8 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
         else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, vsr::S(stream), p);
         else hipLaunchKernelGGL(k_conv_igemm<16>, grid, dim3(256), 0, vsr::S(stream), p);
     } else {
-        if (bn == 64) hipLaunchKernelGGL(k_conv_igemm_d<64>, grid, dim3(256), 0, vsr::S(stream), p);
+        if (bn == 128) hipLaunchKernelGGL(k_conv_igemm_d<128>, grid, dim3(256), 0, vsr::S(stream), p);
+        else if (bn == 64) hipLaunchKernelGGL(k_conv_igemm_d<64>, grid, dim3(256), 0, vsr::S(stream), p);
         else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm_d<32>, grid, dim3(256), 0, vsr::S(stream), p);
         else hipLaunchKernelGGL(k_conv_igemm_d<16>, grid, dim3(256), 0, vsr::S(stream), p);
     }
