@@ -507,6 +507,7 @@ k_chain1x1_s(const ChainP cp, unsigned P, unsigned total_px) {
     const int l15 = lane & 15, g = lane >> 4;
     __shared__ __attribute__((aligned(16))) h8 As[NS][3][2][64];
     __shared__ __attribute__((aligned(16))) float bs[NS][32];
+    __shared__ __attribute__((aligned(16))) unsigned char ost[4 * 1024];
     for (int q = wv; q < NS * 6; q += 4) {   // fragment q = (stage, operand, out-channel tile)
         const int s = q / 6, t = (q % 6) >> 1, mt = q & 1;
         const ChainStage& st = cp.st[s];
@@ -582,10 +583,21 @@ k_chain1x1_s(const ChainP cp, unsigned P, unsigned total_px) {
                     acc[mt] = mfma16(*reinterpret_cast<const h8*>(ap + ((s * 3 + 2) * 2 + mt) * 1024), prev, acc[mt]);
             }
             prev = act_pack(acc[0], acc[1], a2[s], use_max[s]);   // channels {4g..4g+3, 16+4g..16+4g+3} of pixel l15
-            if (cp.st[s].out && px < total_px) {
+            if (cp.st[s].out) {
+                // out through this wave's 1 KiB LDS slice so that the 16 pixels x 64 bytes leave as ONE store instruction
+                // over contiguous memory (16 bytes per lane); straight from the accumulator layout it took two
+                // instructions of 8 bytes per lane, 32 bytes per pixel each.  16-byte pieces XOR (pixel & 3).
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                *reinterpret_cast<h4*>(cp.st[s].out + (size_t)px * NF + 4 * g) = h4{prev[0], prev[1], prev[2], prev[3]};
-                *reinterpret_cast<h4*>(cp.st[s].out + (size_t)px * NF + 16 + 4 * g) = h4{prev[4], prev[5], prev[6], prev[7]};
+                unsigned char* const o = ost + wv * 1024;
+                const int sw = l15 & 3;
+                *reinterpret_cast<h4*>(o + l15 * 64 + (((g >> 1) ^ sw) << 4) + ((g & 1) << 3)) = h4{prev[0], prev[1], prev[2], prev[3]};
+                *reinterpret_cast<h4*>(o + l15 * 64 + (((2 + (g >> 1)) ^ sw) << 4) + ((g & 1) << 3)) = h4{prev[4], prev[5], prev[6], prev[7]};
+                asm volatile("" ::: "memory");
+                const int opx = lane >> 2, opc = (lane & 3) ^ (opx & 3);   // this lane's linear slot holds piece opc of pixel opx
+                const h8 ov = *reinterpret_cast<const h8*>(o + lane * 16);
+                asm volatile("" ::: "memory");
+                const unsigned gpx = tile * 16 + opx;
+                if (gpx < total_px) *reinterpret_cast<h8*>(cp.st[s].out + (size_t)gpx * NF + 8 * opc) = ov;
             }
         }
         cur = nxt;
