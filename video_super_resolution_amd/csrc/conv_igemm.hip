@@ -51,7 +51,7 @@ __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((
 // Epilogue of the convolution kernels: bias + activation + fp16, then out through LDS so that a pixel's 16 MT channels leave
 // as whole 16-byte pieces from adjacent lanes (a full 128-byte line per pixel at MT = 4).  Straight from the MFMA
 // layout a store instruction writes 8 bytes per lane, 32 bytes per pixel per out-channel tile; measured on the 3x3
-// FlowNet layers those partial-line writes were half of the kernel's time (tools/patch_exp2.py).  Wave-local: each
+// FlowNet layers those partial-line writes cost a third of the kernel (3x3 32->64 at 2x512x960: 121 -> 88 us).  Wave-local: each
 // wave transposes its own NT x 16 pixels in its own LDS slice (the caller has synchronised after the last patch read).
 // acc(ti, mt) -> f4 of pixel-tile ti; pixoff(ti, li) -> element offset of pixel li of tile ti in the output tensor (its
 // channel 0), or -1 when the pixel does not exist.
