@@ -254,6 +254,9 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
                         int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
                         vsr_stream_t stream);
 
+/* Trunk input conversion: [N,C,H,W] fp32 (contiguous) -> [N,H,W,cp] fp16, channels C..cp-1 zero (cp a multiple of 4, >= C);
+ * rounding as Tensor.half().  Replaces torch.zeros + a strided copy per trunk input (FlowNet2 alone converts four). */
+int vsr_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int cp, vsr_stream_t stream);
 /* NHWC fp16 glue of the hourglass (pytorch_DIW_scratch.py: MaxPool2d/AvgPool2d((2,2),(2,2)), UpsamplingNearest2d(2),
  * coolAddTensors :29-31).  Inputs may be channel slices of wider buffers; outputs are dense [N,.,.,C].
  * pool: mode 0 max, 1 average (out H/2 x W/2), 2 max with ceil_mode (out ceil(H/2) x ceil(W/2): OSVOS's VGG pools).  resize_add: out = nearest_resize(a -> HxW) (+ b if given). */

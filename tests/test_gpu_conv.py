@@ -189,3 +189,15 @@ def test_pool2x2(shape, mode):
         assert (got.float() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
     else:
         assert torch.equal(got.float(), ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 37, 45, None), (1, 12, 64, 96, None), (2, 3, 19, 21, 4), (1, 11, 8, 8, 32), (1, 40, 5, 7, None)])
+def test_nchw_f32_to_nhwc_f16(shape):
+    """Trunk input conversion in one pass: same values as zero fill + strided copy (Tensor.half() rounding), padding zero."""
+    N, C, H, W, cp = shape
+    x = torch.from_numpy((np.random.RandomState(C + H).randn(N, C, H, W) * 100).astype(np.float32)).cuda()
+    got = igemm.to_nhwc_half(x, cp)
+    cpp = cp or igemm.pad32(C)
+    ref = torch.zeros((N, H, W, cpp), dtype=torch.float16, device="cuda")
+    ref[..., :C] = x.permute(0, 2, 3, 1)
+    assert got.shape == ref.shape and torch.equal(got, ref)

@@ -1034,6 +1034,26 @@ __global__ void __launch_bounds__(256) k_pool2(const _Float16* __restrict__ in, 
     *reinterpret_cast<h8v*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + 8 * c8) = o;
 }
 
+// [N,C,H,W] fp32 -> [N,H,W,cp] fp16 with the channels >= C written as zeros (round to nearest even, like Tensor.half()):
+// the entry conversion of every trunk input in one pass instead of a zero fill plus a strided copy.  Thread = (pixel,
+// 4-channel piece): plane reads are coalesced along x, a pixel's pieces are written by adjacent lanes.
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc_h(const float* __restrict__ in, _Float16* __restrict__ out, int N, int C, int HW, int cp) {
+    const int c4n = cp >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * HW * c4n) return;
+    const int c4 = (int)(idx % c4n);
+    const long long px = idx / c4n;          // n * HW + p
+    const int n = (int)(px / HW);
+    const int pp = (int)(px - (long long)n * HW);
+    h4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * c4 + j;
+        v[j] = c < C ? (_Float16)in[((size_t)n * C + c) * HW + pp] : (_Float16)0.0f;
+    }
+    *reinterpret_cast<h4*>(out + (size_t)px * cp + 4 * c4) = v;
+}
+
 // out[n,y,x,:] = a[n, y*Ha/H, x*Wa/W, slice a] (nearest, as F.interpolate(size)) + b[n,y,x, slice b]; b == null: resize only.
 __global__ void __launch_bounds__(256) k_resize_add(const _Float16* __restrict__ a, int a_ld, int a_coff, int Ha, int Wa,
                                                     const _Float16* __restrict__ b, int b_ld, int b_coff,
@@ -1204,6 +1224,14 @@ int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int 
     hipLaunchKernelGGL(k_pool2, dim3(vsr::cdiv(total, 256)), dim3(256), 0, vsr::S(stream), (const _Float16*)in, in_ld, in_coff,
                        (_Float16*)out, N, H, W, C, mode);
     return vsr::launched("pool2x2");
+}
+
+int vsr_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, int W, int cp, vsr_stream_t stream) {
+    VSR_REQUIRE(in && out, "nchw_to_nhwc: null pointer");
+    VSR_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && cp >= C && (cp & 3) == 0, "nchw_to_nhwc: bad shape");
+    const long long total = (long long)N * H * W * (cp >> 2);
+    hipLaunchKernelGGL(k_nchw_to_nhwc_h, dim3(vsr::cdiv(total, 256)), dim3(256), 0, vsr::S(stream), in, (_Float16*)out, N, C, H * W, cp);
+    return vsr::launched("nchw_f32_to_nhwc_f16");
 }
 
 int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,

@@ -56,6 +56,10 @@ def to_nhwc_half(x_nchw: torch.Tensor, cp: int = None) -> torch.Tensor:
     """[N,C,H,W] any float -> [N,H,W,pad32(C)] float16, zero padded."""
     N, C, H, W = x_nchw.shape
     cp = cp or pad32(C)
+    if x_nchw.is_cuda and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous():   # one pass (csrc/conv_igemm.hip k_nchw_to_nhwc_h)
+        out = torch.empty((N, H, W, cp), dtype=torch.float16, device=x_nchw.device)
+        L.check(L.load().vsr_nchw_f32_to_nhwc_f16(L.dptr(x_nchw), L.dptr(out, torch.float16), N, C, H, W, cp, L.stream()), "nchw_f32_to_nhwc_f16")
+        return out
     out = torch.zeros((N, H, W, cp), dtype=torch.float16, device=x_nchw.device)
     out[..., :C] = x_nchw.permute(0, 2, 3, 1)
     return out
