@@ -102,13 +102,14 @@ class EventTimer:
 
     def __init__(self):
         self.enabled = False
+        self.only = None   # optional set of names: everything else stays untimed (bench.py times the dominant kernel only)
         self._pairs = {}
 
     def reset(self):
         self._pairs = {}
 
     def start(self, name: str):
-        if not self.enabled:
+        if not self.enabled or (self.only is not None and name not in self.only):
             return None
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
