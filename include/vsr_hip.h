@@ -213,6 +213,14 @@ int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out
  * LDS-ring build with the skip inside the tail (agree up to fp32 summation order). */
 int vsr_sr_tail3_f16(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* raw,
                      int N, int h, int w, int rows_per_seg, int slopes_le_one, int decimate, vsr_stream_t stream);
+/* vsr_sr_tail3_f16 with the FeedbackBlock's last compress_out folded in (SRProjectionModule.py:99): lr_a, lr_b are the two LR
+ * maps it reads ([N,h,w,32] fp16), cmap_nhwc its constant map ([h*w,32] fp32), blob_fold a deconv-only blob whose fragments
+ * follow the accumulator's channel order and whose BLOB_CO section holds the 1x1 (host: pack_utd_blob(..., fold_co=...)).
+ * Same raw planes as vsr_sr_chain1x1_f16 (one stage, two inputs + map) followed by vsr_sr_tail3_f16 up to the fp32 summation
+ * order of the deconv's K dimension; one launch and a 265 MB write + read less. */
+int vsr_sr_tail3_fold_f16(const void* lr_a, const void* lr_b, const float* cmap_nhwc, const void* blob_fold, const void* conv3_frags,
+                          const float* tail_params, float* raw, int N, int h, int w, int rows_per_seg, int slopes_le_one, int decimate,
+                          vsr_stream_t stream);
 /* Fusion MLP over the 8 planes (vsr_sr_fc_planes_f32) reading RAW planes and finishing them on the fly:
  * plane = (bilinear x4 of (x * sub_scale + sub_bias) + raw) * add_scale + add_bias; x [8,3,h,w] fp32; out [3,4h,4w] (or
  * [3,h,w] with decimate != 0) fp32. */

@@ -209,3 +209,24 @@ def test_fusion_builds_bit_identical(gpu_vsr_f16, shape):
         lib.vsr_sr_chain_variant(0)
     assert torch.isfinite(got).all()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (9, 40), (37, 33), (2, 2), (1, 7)])
+@pytest.mark.parametrize("decimate", [False, True])
+def test_tail_with_folded_compress_out(gpu_vsr_f16, shape, decimate):
+    """The FeedbackBlock's last compress_out applied inside k_tail3's LR load path (k_tail3<.., FOLD>) against its own
+    chain launch followed by k_tail3: the 1x1 is computed with the same operands in the same order; only the deconv's K
+    index is permuted (fp32 summation order), so the frames agree to 1e-4 of range."""
+    m = gpu_vsr_f16.model
+    h, w = shape
+    x = torch.from_numpy(np.random.RandomState(h * 17 + w).randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    try:
+        with torch.no_grad():
+            m.fold_tail = False
+            ref = m(x, decimate=decimate).clone()
+            m.fold_tail = True
+            got = m(x, decimate=decimate)
+    finally:
+        m.fold_tail = True
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())

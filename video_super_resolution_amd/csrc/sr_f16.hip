@@ -1280,7 +1280,8 @@ int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w
                 int diag, hipStream_t stream);
 int utd3_set_stamps(void* buf);
 int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* prefc, int N,
-                 int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream);
+                 int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream, const void* in2 = nullptr,
+                 const float* cmap = nullptr);
 }
 
 static int g_fc_one_pixel = 0;     // 1: full frames through the one-pixel fusion build too (cross-check)
@@ -1482,6 +1483,16 @@ int vsr_sr_tail3_f16(const void* hid_nhwc, const void* blob, const void* conv3_f
     VSR_REQUIRE(vsr::cdiv(h, rows_per_seg) <= 65535, "sr_tail3_f16: too many row segments");
     return vsr::launch_tail3(hid_nhwc, blob, conv3_frags, tail_params, raw, N, h, w, rows_per_seg, slopes_le_one, decimate,
                              vsr::S(stream));
+}
+
+int vsr_sr_tail3_fold_f16(const void* lr_a, const void* lr_b, const float* cmap_nhwc, const void* blob_fold, const void* conv3_frags,
+                          const float* tail_params, float* raw, int N, int h, int w, int rows_per_seg, int slopes_le_one, int decimate,
+                          vsr_stream_t stream) {
+    VSR_REQUIRE(lr_a && lr_b && cmap_nhwc && blob_fold && conv3_frags && tail_params && raw, "sr_tail3_fold_f16: null pointer");
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_tail3_fold_f16: bad shape");
+    VSR_REQUIRE(vsr::cdiv(h, rows_per_seg) <= 65535, "sr_tail3_fold_f16: too many row segments");
+    return vsr::launch_tail3(lr_a, blob_fold, conv3_frags, tail_params, raw, N, h, w, rows_per_seg, slopes_le_one, decimate,
+                             vsr::S(stream), lr_b, cmap_nhwc);
 }
 
 int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tail_params, const float* w1, const float* b1,

@@ -32,7 +32,9 @@ constexpr int BLOB_UP = 0;                    // [wave 8][phase 2][tap 4][mt 2][
 constexpr int BLOB_DN = 8 * 16 * 1024;        // [wave 8][lo/hi 2][kx 8][lane 64][8] fp16 (kernel rows w&3, (w&3)+4; co half w>>2)
 constexpr int BLOB_DT = BLOB_DN + 8 * 16 * 1024;  // [mt 2][lane 64][8] fp16
 constexpr int BLOB_F32 = BLOB_DT + 2 * 1024;  // b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn
-constexpr int BLOB_BYTES = BLOB_F32 + 512;
+constexpr int BLOB_CO = BLOB_F32 + 512;       // folded compress_out 1x1 (k_tail3<.., FOLD>): [input 2][mt 2][lane 64][8] fp16, then b_co[32], slope_co (fp32)
+constexpr int BLOB_CO_BYTES = 4 * 1024 + 256;
+constexpr int BLOB_BYTES = BLOB_CO + BLOB_CO_BYTES;
 
 static_assert(RING_BYTES % 16 == 0 && PART_BYTES % 16 == 0 && LR_SLOT % 16 == 0, "LDS carve must stay 16-B aligned");
 static_assert(UTD_LDS <= 160 * 1024, "LDS budget");

@@ -26,9 +26,15 @@ constexpr int T3_PART = (T3_ROWS * 3 + 1) * T3_PLANE;    // + one dump plane for
 constexpr int T3_LDS = T3_PART + LR_BYTES + 256;
 
 // DEC: only output pixels (4i, 4j) are wanted (pass 1 of VSR.forward): prefc is [N,3,h,w]
-template <bool ALLMAX, bool DEC>
+// FOLD: the FeedbackBlock's last compress_out (1x1 over two LR maps + constant map + PReLU, SRProjectionModule.py:99) is
+// applied to every LR row on its way into LDS: `in`, `in2` are the two maps, `cmap` the [h*w,32] fp32 constant map; the
+// loader lanes sit in MFMA fragment layout (pixel l15 of the wave's 16 columns, 16-byte channel piece g), four MFMAs per
+// 16 pixels and row on three waves.  The rows then hold the accumulator's channel order, which the FOLD blob's deconv
+// fragments follow.  Saves the 1x1's own launch (0.2 ms: three 265 MB reads and a 265 MB write that this kernel re-reads).
+template <bool ALLMAX, bool DEC, bool FOLD>
 __global__ void __launch_bounds__(256)
-k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, const unsigned char* __restrict__ acv3,
+k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const float* __restrict__ cmap,
+        const unsigned char* __restrict__ blob, const unsigned char* __restrict__ acv3,
         const float* __restrict__ tpar, float* __restrict__ prefc, int h, int w, int rows_per_seg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const pb = smem;
@@ -81,15 +87,60 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
         lr_b[0][nt] = lr_off(j + 1, g);
         lr_b[1][nt] = lr_off(j, g);
     }
-    const bool lr_loader = tid < LR_COLS * 4;
-    const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 1 + lr_px;
+    const int lr_px = FOLD ? 16 * wv + l15 : tid >> 2, lr_ch = FOLD ? g : tid & 3, lr_col = x0 - 1 + lr_px;
+    const bool lr_loader = FOLD ? (wv < 3 && lr_px < LR_COLS) : tid < LR_COLS * 4;
     const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
     const int lr_st = lr_off(lr_px, lr_ch);
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(FOLD ? in2 : in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cm_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FOLD ? cmap : tpar), 0, FOLD ? (int)((size_t)h * w * NF * 4) : 0, 0x00020000);
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    auto fetch_lr = [&](int r) __attribute__((always_inline)) -> u4 {
-        const unsigned off = (lr_col_ok && r >= 0 && r < h) ? (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
-        return __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+    // one LR row piece of this loader lane: FOLD carries the second map's piece and the two constant-map tiles as well
+    struct RawRow {
+        u4 a, b, c0, c1;
+    };
+    h8 Aco[2][2];
+    f4 bco[2];
+    float a_co = 1.0f;
+    if (FOLD) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) Aco[t][mt] = *reinterpret_cast<const h8*>(blob + BLOB_CO + ((t * 2 + mt) * 64 + lane) * 16);
+        const float* cpar = reinterpret_cast<const float*>(blob + BLOB_CO + 4096);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) bco[mt] = *reinterpret_cast<const f4*>(cpar + 16 * mt + 4 * g);
+        a_co = cpar[32];
+    }
+    const h2 a_co2 = {(_Float16)a_co, (_Float16)a_co};
+    const bool co_max = a_co <= 1.0f;
+    auto fetch_lr = [&](int r) __attribute__((always_inline)) -> RawRow {
+        const bool ok = lr_col_ok && r >= 0 && r < h;
+        const unsigned off = ok ? (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
+        RawRow v;
+        v.a = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+        if (FOLD) {
+            v.b = __builtin_amdgcn_raw_buffer_load_b128(in2_rsrc, off, 0, 0);
+            const unsigned coff = ok ? (unsigned)((((size_t)r * w + lr_col) * NF + 4 * g) * 4) : 0xFFFFFFFFu;
+            v.c0 = __builtin_amdgcn_raw_buffer_load_b128(cm_rsrc, coff, 0, 0);
+            v.c1 = __builtin_amdgcn_raw_buffer_load_b128(cm_rsrc, ok ? coff + 64 : 0xFFFFFFFFu, 0, 0);
+        }
+        return v;
+    };
+    // value stored for LR row r: the fetched piece, or (FOLD) PReLU(W_co [a; b] + b_co + cmap) of its pixel -- same
+    // operation order as k_chain1x1 (bias + map, then the two products) -- and zero outside the image: the deconv's
+    // padding applies to the 1x1's output.  Wave-uniform callers (wv < 3).
+    auto row_value = [&](const RawRow& v, int r) __attribute__((always_inline)) -> u4 {
+        if (!FOLD) return v.a;
+        f4 acc[2] = {bco[0] + __builtin_bit_cast(f4, v.c0), bco[1] + __builtin_bit_cast(f4, v.c1)};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            acc[mt] = mfma16(Aco[0][mt], __builtin_bit_cast(h8, v.a), acc[mt]);
+            acc[mt] = mfma16(Aco[1][mt], __builtin_bit_cast(h8, v.b), acc[mt]);
+        }
+        const u4 o = __builtin_bit_cast(u4, act_pack(acc[0], acc[1], a_co2, co_max));
+        const bool ok = lr_col_ok && r >= 0 && r < h;
+        return u4{ok ? o[0] : 0u, ok ? o[1] : 0u, ok ? o[2] : 0u, ok ? o[3] : 0u};
     };
     auto lr_slot = [&](int r) __attribute__((always_inline)) { return ((r + 1) % 3) * LR_SLOT; };
     auto load_lr_frags = [&](int s_i, int s_i1, h8 (&Bf)[4][2]) __attribute__((always_inline)) {
@@ -241,16 +292,19 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
     };
 
     // ---- march: groups G(r0-1) .. G(r1-1), then two more steps that only finish rows
-    if (lr_loader) {
-        *reinterpret_cast<u4*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
-        *reinterpret_cast<u4*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
-        *reinterpret_cast<u4*>(lrr + lr_slot(r0 + 1) + lr_st) = fetch_lr(r0 + 1);
+    if (FOLD ? wv < 3 : true) {
+        const u4 ra = row_value(fetch_lr(r0 - 1), r0 - 1), rb = row_value(fetch_lr(r0), r0), rc = row_value(fetch_lr(r0 + 1), r0 + 1);
+        if (lr_loader) {
+            *reinterpret_cast<u4*>(lrr + lr_slot(r0 - 1) + lr_st) = ra;
+            *reinterpret_cast<u4*>(lrr + lr_slot(r0) + lr_st) = rb;
+            *reinterpret_cast<u4*>(lrr + lr_slot(r0 + 1) + lr_st) = rc;
+        }
     }
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0);
     for (int i = r0 - 1; i <= r1 + 1; ++i) {
         const bool produce = i <= r1 - 1;
-        const u4 nxt = fetch_lr(i + 3);
+        const RawRow nxt = fetch_lr(i + 3);
         h8 Bf[4][2], ob[4][2];
         if (produce) load_lr_frags(lr_slot(i), lr_slot(i + 1), Bf);
         __syncthreads();
@@ -261,8 +315,9 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
             deconv_row(i, Bf, ob);
             conv_row(i, ob);
         }
-        if (produce) {
-            if (wv < 3 && lr_loader) *reinterpret_cast<u4*>(lrr + lr_slot(i + 3) + lr_st) = nxt;   // over row i: read above the barrier
+        if (produce && wv < 3) {
+            const u4 nv = row_value(nxt, i + 3);
+            if (lr_loader) *reinterpret_cast<u4*>(lrr + lr_slot(i + 3) + lr_st) = nv;   // over row i: read above the barrier
         }
     }
 }
@@ -272,9 +327,12 @@ k_tail3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob,
 namespace vsr {
 
 int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* prefc, int N,
-                 int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream) {
-    typedef void (*kern_t)(const _Float16*, const unsigned char*, const unsigned char*, const float*, float*, int, int, int);
-    static const kern_t kerns[4] = {k_tail3<false, false>, k_tail3<true, false>, k_tail3<false, true>, k_tail3<true, true>};
+                 int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream, const void* in2, const float* cmap) {
+    typedef void (*kern_t)(const _Float16*, const _Float16*, const float*, const unsigned char*, const unsigned char*, const float*,
+                           float*, int, int, int);
+    static const kern_t kerns[8] = {k_tail3<false, false, false>, k_tail3<true, false, false>, k_tail3<false, true, false>,
+                                    k_tail3<true, true, false>,   k_tail3<false, false, true>, k_tail3<true, false, true>,
+                                    k_tail3<false, true, true>,   k_tail3<true, true, true>};
     static bool attr_done = false;
     if (!attr_done) {
         for (kern_t k : kerns)
@@ -284,9 +342,10 @@ int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags
     }
     if ((size_t)N * h * w * NF * 2 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail3: input beyond 2 GiB");
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
-    hipLaunchKernelGGL(kerns[(dec ? 2 : 0) + (slopes_le_one ? 1 : 0)], dim3(strips, segs, N), dim3(256), T3_LDS, stream,
-                       (const _Float16*)hid_nhwc, (const unsigned char*)blob, (const unsigned char*)conv3_frags, tail_params,
-                       prefc, h, w, rows_per_seg);
+    if (in2 && (size_t)h * w * NF * 4 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail3: constant map beyond 2 GiB");
+    hipLaunchKernelGGL(kerns[(in2 ? 4 : 0) + (dec ? 2 : 0) + (slopes_le_one ? 1 : 0)], dim3(strips, segs, N), dim3(256), T3_LDS, stream,
+                       (const _Float16*)hid_nhwc, (const _Float16*)in2, cmap, (const unsigned char*)blob,
+                       (const unsigned char*)conv3_frags, tail_params, prefc, h, w, rows_per_seg);
     return vsr::launched("sr_tail3");
 }
 

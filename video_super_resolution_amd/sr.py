@@ -167,6 +167,9 @@ class SRProjectionModule(nn.Module):
             P["utd"][j] = pack_utd_blob(*args)             # k_utd (every wave both phases)
             P["utd2"][j] = pack_utd_blob(*args, layout=2)  # k_utd2 (producer / consumer waves)
         P["utd_out"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0)
+        if G == 6:   # compress_out reads exactly two live maps (lr3, lr6): folded into the tail's LR path
+            P["utd_out_fold"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0,
+                                              fold_co=(P["co_w"], (_NF * 2, _NF * 5), P["co_b"], P["co_a"]))
         P["cv_frags"] = pack_conv_out_frags(self.conv_out[0].weight)
         P["cv_frags3"] = pack_conv_out_frags3(self.conv_out[0].weight)
         P["tail_par"] = torch.cat((P["cv_b"], P["sub_s"], P["sub_b"], P["add_s"], P["add_b"])).contiguous()
@@ -393,6 +396,8 @@ class SRProjectionModule(nn.Module):
         L.TIMER.stop(tok)
         return out
 
+    fold_tail = True   # the last compress_out inside k_tail3's LR path (False: its own chain launch; cross-check)
+
     def _utd(self, a, blob, N, h, w, deconv_only=False):
         out = torch.empty((N, 4 * h, 4 * w, _NF) if deconv_only else (N, h, w, _NF), dtype=torch.float16, device=a.device)
         tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else "sr_utd_f16")
@@ -454,6 +459,23 @@ class SRProjectionModule(nn.Module):
             if taps is not None and step == self.num_steps - 1:
                 for k, v in live.items():
                     taps[f"lr{k}"] = nchw(v)
+        ho, wo = (h, w) if decimate else (4 * h, 4 * w)
+        if self.fold_tail and taps is None and self.tail_build == 3 and "utd_out_fold" in P and sorted(k for k in live if k > 0) == [3, 6]:
+            # compress_out inside the tail (k_tail3<.., FOLD>): no `hid` tensor, one launch less
+            prefc = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
+            out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=dev)
+            tok = L.TIMER.start("sr_tail_dec_f16" if decimate else "sr_tail_f16")
+            L.check(lib.vsr_sr_tail3_fold_f16(L.dptr(live[3], torch.float16), L.dptr(live[6], torch.float16), L.dptr(cmap_nhwc),
+                                              L.dptr(P["utd_out_fold"], torch.uint8), L.dptr(P["cv_frags3"], torch.float16),
+                                              L.dptr(P["tail_par"]), L.dptr(prefc), N, h, w, self._rows_per_segment(N, h, w),
+                                              int(P["slopes_le_one"]), int(decimate), L.stream()), "sr_tail3_fold_f16")
+            L.TIMER.stop(tok)
+            tok = L.TIMER.start("sr_fc_planes_skip_dec" if decimate else "sr_fc_planes_skip") if L.TIMER.enabled else None
+            L.check(lib.vsr_sr_fc_planes_skip_f32(L.dptr(prefc), L.dptr(x), L.dptr(P["tail_par"]), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]),
+                                                  L.dptr(P["fc_w2"]), L.dptr(P["fc_b2"]), N, P["fc_w1"].shape[0], L.dptr(out), h, w,
+                                                  int(decimate), L.stream()), "sr_fc_planes_skip")
+            L.TIMER.stop(tok)
+            return out
         hid = self._chain([co(live)], N, hp, keep=[True])[0] if len(co(live)["ins"]) <= 2 else \
             self._c1h(co(live)["ins"], P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
         if taps is not None:
@@ -506,11 +528,14 @@ def _chunk_channel_order(device):
     return torch.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4))  # [4,8]
 
 
-def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a, layout: int = 1) -> torch.Tensor:
+def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a, layout: int = 1, fold_co=None) -> torch.Tensor:
     """Weights of one fused up->tran->down stage in the per-wave MFMA fragment order of csrc/sr_f16.hip.
 
     up_w [32(in),32(out),8,8] ConvTranspose2d weight; tr_w [32,ld] 1x1 weight whose live slice starts at column
     tr_col0; dn_w [32(out),32(in),8,8] Conv2d weight.  tr_w/dn_w None -> deconv-only blob (tail).
+    fold_co = (co_w [32,ld], (col0_a, col0_b), co_b [32], co_a): the 1x1 + PReLU over two LR maps (+ constant map) that
+    produces the deconv's input, applied by k_tail3<.., FOLD> on the rows' way into LDS; the deconv fragments then take
+    their K index in the accumulator's channel order (vsr_sr_tail3_fold_f16).
     """
     dev = up_w.device
     nbytes = int(L.load().vsr_sr_utd_blob_bytes())
@@ -525,7 +550,7 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a,
     MT = torch.arange(2, device=dev).view(1, 1, 1, 2, 1, 1)
     LN = lane.view(1, 1, 1, 1, 64, 1)
     J = j8.view(1, 1, 1, 1, 1, 8)
-    ci = 8 * (LN >> 4) + J
+    ci = 8 * (LN >> 4) + J if fold_co is None else perm[LN >> 4, J]
     co = 16 * MT + (LN & 15)
     ky = (W >> 1) + 4 * (T >> 1)
     kx = 2 * (W & 1) + C + 4 * (T & 1)
@@ -577,6 +602,20 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a,
         fpar[97] = float(tr_a)
         fpar[98] = float(dn_a)
     blob[off_f:off_f + 512] = fpar.view(torch.uint8)
+    if fold_co is not None:
+        co_w, cols, co_b, co_a = fold_co
+        off_co = off_f + 512
+        T2 = torch.arange(2, device=dev).view(2, 1, 1, 1)
+        MT = torch.arange(2, device=dev).view(1, 2, 1, 1)
+        col0 = torch.tensor(list(cols), device=dev).view(2, 1, 1, 1)
+        co = 16 * MT + col_l.view(1, 1, 64, 1)
+        ci = col0 + 8 * g.view(1, 1, 64, 1) + j8.view(1, 1, 1, 8)   # the 1x1 reads the raw maps: natural channel order
+        co, ci = torch.broadcast_tensors(co, ci)
+        blob[off_co:off_co + 4096] = co_w.detach().float()[co, ci].to(torch.float16).contiguous().view(torch.uint8).reshape(-1)
+        cpar = torch.zeros(64, dtype=torch.float32, device=dev)
+        cpar[0:32] = co_b.detach().float()
+        cpar[32] = float(co_a)
+        blob[off_co + 4096:off_co + 4096 + 256] = cpar.view(torch.uint8)
     return blob
 
 
