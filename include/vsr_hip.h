@@ -261,6 +261,14 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
                         int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
                         int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
                         vsr_stream_t stream);
+/* The same with a column stride of its own (stride applies to rows, stride_x to columns; 0 = the same).  Used by the host to
+ * run a stride-2 first convolution on a <=16-channel map as a stride-(2,1) convolution over PIXEL PAIRS: [N,H,W,16] viewed as
+ * [N,H,W/2,32], kernel columns folded into (pair tap, parity) -- 43 % less K than the 32-channel padding (igemm.py HConvPairS2). */
+int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
+                           int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
+                           int kh, int kw, int stride, int stride_x, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
+                           int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
+                           vsr_stream_t stream);
 
 /* Trunk input conversion: [N,C,H,W] fp32 (contiguous) -> [N,H,W,cp] fp16, channels C..cp-1 zero (cp a multiple of 4, >= C);
  * rounding as Tensor.half().  Replaces torch.zeros + a strided copy per trunk input (FlowNet2 alone converts four). */

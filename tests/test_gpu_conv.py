@@ -201,3 +201,19 @@ def test_nchw_f32_to_nhwc_f16(shape):
     ref = torch.zeros((N, H, W, cpp), dtype=torch.float16, device="cuda")
     ref[..., :C] = x.permute(0, 2, 3, 1)
     assert got.shape == ref.shape and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("case", [(2, 12, 64, 96, 64, 7, 3), (1, 12, 37, 50, 64, 7, 3), (1, 16, 20, 34, 32, 5, 2), (1, 5, 9, 8, 16, 3, 1)])
+def test_pair_conv_stride2(case):
+    """Stride-2 first convolution of a <=16-channel map as a stride-(2,1) convolution over pixel pairs (FlowNetS conv1)."""
+    N, cin, H, W, cout, k, pad = case
+    rs = np.random.RandomState(cin + k + W)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.leaky_relu(F.conv2d(x.float(), w, b, stride=2, padding=pad), 0.1)
+    conv = igemm.HConvPairS2(w, b, pad=pad, act=igemm.ACT_LEAKY, slope=0.1)
+    out = conv(igemm.to_nhwc_half(x.float(), 16))
+    got = igemm.to_nchw_float(out, cout)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()

@@ -29,7 +29,8 @@ struct ConvP {
     _Float16* out;
     int in_ld, in_coff, out_ld, out_coff;
     int N, H, W, cin, Ho, Wo, cout, cout_pad;
-    int kh, kw, stride, pad_y, pad_x;
+    int kh, kw, stride, pad_y, pad_x;   // stride: rows (and columns unless stride_x differs)
+    int stride_x;
     int outH, outW, oy_mul, oy_off, ox_mul, ox_off;
     int act;
     float slope;
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         pn[r] = n;
         piy0[r] = oy * p.stride - pad_y;
-        pix0[r] = ox * p.stride - pad_x;
+        pix0[r] = ox * p.stride_x - pad_x;
     }
     const int bchunk = tid & 3;
     const int brow[2] = {tid >> 2, (tid + 256) >> 2};
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         pn[r] = n;
         piy0[r] = oy * p.stride - pad_y;
-        pix0[r] = ox * p.stride - pad_x;
+        pix0[r] = ox * p.stride_x - pad_x;
     }
     const int bchunk = g;
 
@@ -1305,7 +1306,7 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
     p.in = (const _Float16*)in; p.wpk = nullptr; p.bias = bias; p.out = (_Float16*)out;
     p.in_ld = in_ld; p.in_coff = in_coff; p.out_ld = out_ld; p.out_coff = out_coff;
     p.N = N; p.H = H; p.W = W; p.cin = cin; p.Ho = H; p.Wo = W; p.cout = cout; p.cout_pad = cout_pad;
-    p.kh = 2; p.kw = 2; p.stride = 1; p.pad_y = 0; p.pad_x = 0;
+    p.kh = 2; p.kw = 2; p.stride = 1; p.stride_x = 1; p.pad_y = 0; p.pad_x = 0;
     p.outH = 2 * H; p.outW = 2 * W; p.oy_mul = 2; p.oy_off = 0; p.ox_mul = 2; p.ox_off = 0;
     p.act = act; p.slope = slope;
     p.nphase = 4;
@@ -1356,11 +1357,12 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
     VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && cout > 0 && kh > 0 && kw > 0 && kw <= 8 && stride > 0, "conv2d_stem: bad shape");
     VSR_REQUIRE(out_coff >= 0 && out_coff + cout <= out_ld && cout_pad >= cout && (cout_pad & 15) == 0, "conv2d_stem: output slice");
     VSR_REQUIRE(act >= 0 && act <= 2, "conv2d_stem: activation %d", act);
+    const int stride_x = 0;
     ConvP p;
     p.in = (const _Float16*)in4; p.wpk = (const _Float16*)w_packed; p.bias = bias; p.out = (_Float16*)out;
     p.in_ld = 4; p.in_coff = 0; p.out_ld = out_ld; p.out_coff = out_coff;
     p.N = N; p.H = H; p.W = W; p.cin = 32; p.Ho = Ho; p.Wo = Wo; p.cout = cout; p.cout_pad = cout_pad;
-    p.kh = kh; p.kw = kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.stride_x = stride_x > 0 ? stride_x : stride; p.pad_y = pad_y; p.pad_x = pad_x;
     p.outH = Ho; p.outW = Wo; p.oy_mul = 1; p.oy_off = 0; p.ox_mul = 1; p.ox_off = 0;
     p.act = act; p.slope = slope; p.ws = nullptr; p.splits = 1; p.nphase = 0;
     const long long M = (long long)N * Ho * Wo;
@@ -1389,11 +1391,11 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
     return vsr::launched("conv2d_stem_f16");
 }
 
-int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
-                        int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
-                        int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
-                        int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
-                        vsr_stream_t stream) {
+int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
+                           int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
+                           int kh, int kw, int stride, int stride_x, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
+                           int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
+                           vsr_stream_t stream) {
     VSR_REQUIRE(in && w_packed && out, "conv2d: null pointer");
     VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0, "conv2d: bad shape");
     VSR_REQUIRE(cin > 0 && (cin & 31) == 0, "conv2d: input channels %d must be padded to a multiple of 32", cin);
@@ -1407,14 +1409,14 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
     p.in = (const _Float16*)in; p.wpk = (const _Float16*)w_packed; p.bias = bias; p.out = (_Float16*)out;
     p.in_ld = in_ld; p.in_coff = in_coff; p.out_ld = out_ld; p.out_coff = out_coff;
     p.N = N; p.H = H; p.W = W; p.cin = cin; p.Ho = Ho; p.Wo = Wo; p.cout = cout; p.cout_pad = cout_pad;
-    p.kh = kh; p.kw = kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.stride_x = stride_x > 0 ? stride_x : stride; p.pad_y = pad_y; p.pad_x = pad_x;
     p.outH = outH; p.outW = outW; p.oy_mul = oy_mul; p.oy_off = oy_off; p.ox_mul = ox_mul; p.ox_off = ox_off;
     p.act = act; p.slope = slope; p.nphase = 0;
     const long long M = (long long)N * Ho * Wo;
     // stride-1 layers with a real spatial kernel and enough pixels: the 2-D LDS patch kernel (stages the input once per
     // 32-channel chunk instead of gathering it kh*kw times from L2).  Measured on MI355X (tools/conv_microbench.py).
     const int patch_lds = (PT_H + kh - 1) * (PT_W + kw - 1) * 64;
-    const bool patch_legal = stride == 1 && Ho >= 4 && Wo >= 16 && patch_lds <= 64 * 1024 && N <= 65535 && (cout_pad & 15) == 0 &&
+    const bool patch_legal = stride == 1 && (stride_x <= 0 || stride_x == 1) && Ho >= 4 && Wo >= 16 && patch_lds <= 64 * 1024 && N <= 65535 && (cout_pad & 15) == 0 &&
                              (unsigned long long)H * W * in_ld * 2 < (1ull << 31);   // (staging uses 32-bit byte offsets per image)
     const bool patch_pays = (long long)Ho * Wo >= 8192 && kh * kw >= 9 && ((cout_pad == 16 && (cin >> 5) <= 8) || cout_pad >= 32);
     const bool force = g_patch_mode == 2 || g_patch_mode == 6 || g_patch_mode == 7;
@@ -1456,7 +1458,7 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
     }
     // 1x1 over many pixels with more than one 64-channel block of outputs: the streaming kernel (input read once)
     const size_t w_lds = (size_t)(cin >> 5) * cout_pad * 64;
-    if (kh == 1 && kw == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && oy_mul == 1 && ox_mul == 1 && oy_off == 0 && ox_off == 0 &&
+    if (kh == 1 && kw == 1 && stride == 1 && (stride_x <= 0 || stride_x == 1) && pad_y == 0 && pad_x == 0 && oy_mul == 1 && ox_mul == 1 && oy_off == 0 && ox_off == 0 &&
         outH == Ho && outW == Wo && (cin >> 5) <= C1_MAX_CHUNKS && w_lds <= 128 * 1024 && cout_pad > 64 && M >= 65536 &&
         g_patch_mode != 1) {
         p.ws = nullptr;
@@ -1512,6 +1514,17 @@ int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_pa
         hipLaunchKernelGGL(k_splitk_finish, dim3(vsr::cdiv(M * (cout_pad >> 2), 256)), dim3(256), 0, vsr::S(stream), p);
     }
     return vsr::launched("conv2d_nhwc_f16");
+}
+
+/* the common case: one stride for rows and columns */
+int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
+                        int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
+                        int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
+                        int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
+                        vsr_stream_t stream) {
+    return vsr_conv2d_nhwc_sx_f16(in, in_ld, in_coff, w_packed, bias, out, out_ld, out_coff, N, H, W, cin, Ho, Wo, cout, cout_pad, kh, kw,
+                                  stride, stride, pad_y, pad_x, outH, outW, oy_mul, oy_off, ox_mul, ox_off, act, slope, splitk_ws,
+                                  splitk_ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -100,7 +100,7 @@ class HConv:
     def out_hw(self, H, W):
         return (H + 2 * self.pad_y - self.kh) // self.stride + 1, (W + 2 * self.pad_x - self.kw) // self.stride + 1
 
-    def __call__(self, x, out=None, out_coff=0, in_coff=0, out_hw=None):
+    def __call__(self, x, out=None, out_coff=0, in_coff=0, out_hw=None, stride_x=0):
         N, H, W, in_ld = x.shape
         Ho, Wo = out_hw or self.out_hw(H, W)
         if out is None:
@@ -109,13 +109,43 @@ class HConv:
                 torch.empty((N, Ho * self.oy[0], Wo * self.ox[0], out_coff + self.cout), dtype=torch.float16, device=x.device)
         tok = L.TIMER.start(f"conv N{N} {H}x{W} c{self.cin_pad}->{self.cout} k{self.kh}x{self.kw} s{self.stride}"
                             f"{' ph' if self.oy[0] > 1 else ''}") if L.TIMER.enabled else None
-        L.check(L.load().vsr_conv2d_nhwc_f16(
+        L.check(L.load().vsr_conv2d_nhwc_sx_f16(
             L.dptr(x, torch.float16), in_ld, in_coff, L.dptr(self.w, torch.float16), L.optr(self.b), L.dptr(out, torch.float16),
             out.shape[3], out_coff, N, H, W, self.cin_pad, Ho, Wo, self.cout, self.cout_pad, self.kh, self.kw, self.stride,
-            self.pad_y, self.pad_x, out.shape[1], out.shape[2], self.oy[0], self.oy[1], self.ox[0], self.ox[1], self.act,
+            stride_x, self.pad_y, self.pad_x, out.shape[1], out.shape[2], self.oy[0], self.oy[1], self.ox[0], self.ox[1], self.act,
             L.cf(self.slope), L.dptr(_splitk_ws(x.device)), ctypes.c_size_t(_WS_BYTES), L.stream()), "conv2d_nhwc_f16")
         L.TIMER.stop(tok)
         return out
+
+
+class HConvPairS2:
+    """Stride-2 first convolution on a map with <= 16 channels (FlowNetS conv1: 12 -> 64, 7x7): the input [N,H,W,16] is
+    viewed as pixel PAIRS [N,H,W/2,32] and the kernel columns are folded into (pair tap, parity): column x_in = 2 ox - pad
+    + kx = 2 (ox - P) + (kx + s) with P = ceil(pad/2), s = 2P - pad, so pair tap kx' = (kx + s) >> 1 and parity e =
+    (kx + s) & 1 (channel 16 e + c).  The result is a stride-(2,1) convolution with kw' = (kw - 1 + s) // 2 + 1 taps per
+    row whose K chunks are full: 7 x 4 x 32 instead of 49 x 32 for the 7x7.  Same products, another summation order."""
+
+    def __init__(self, weight, bias, pad, act=ACT_NONE, slope=0.1):
+        weight = weight.detach().float()
+        cout, cin, kh, kw = weight.shape
+        if cin > 16:
+            raise ValueError("HConvPairS2: at most 16 input channels")
+        dev = weight.device
+        P2 = (pad + 1) // 2
+        s = 2 * P2 - pad
+        kwp = (kw - 1 + s) // 2 + 1
+        w2 = torch.zeros((cout, 32, kh, kwp), dtype=torch.float32, device=dev)
+        for kx in range(kw):
+            w2[:, 16 * ((kx + s) & 1):16 * ((kx + s) & 1) + cin, :, (kx + s) >> 1] = weight[:, :, :, kx]
+        self.inner = HConv(w2, bias, stride=2, pad=0, act=act, slope=slope)
+        self.inner.pad_y, self.inner.pad_x = pad, P2
+        self.kh, self.kw, self.pad, self.cout = kh, kw, pad, cout
+
+    def __call__(self, x16, out=None, out_coff=0):
+        N, H, W, c = x16.shape
+        assert c == 16 and W % 2 == 0 and x16.is_contiguous()
+        Ho, Wo = (H + 2 * self.pad - self.kh) // 2 + 1, (W + 2 * self.pad - self.kw) // 2 + 1
+        return self.inner(x16.view(N, H, W // 2, 32), out=out, out_coff=out_coff, out_hw=(Ho, Wo), stride_x=1)
 
 
 class HConvStem:

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from . import _lib as L
 from . import ops
 from .depth import HOURGLASS
-from .igemm import (ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvStem, HDeconv4s2, cached_zeros, pad32, pool2x2, resize_add,
+from .igemm import (ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvPairS2, HConvStem, HDeconv4s2, cached_zeros, pad32, pool2x2, resize_add,
                     to_nhwc_half)
 
 
@@ -242,7 +242,11 @@ class _Refine:
 
 class _FlowNetSExec:
     def __init__(self, net, cin):
-        self.conv1 = _cv(net.conv1, cin_pad=pad32(cin))
+        c1 = net.conv1[0] if isinstance(net.conv1, nn.Sequential) else net.conv1
+        # 12 -> 64, 7x7, stride 2 on the warped-pair concat: as a convolution over pixel pairs (igemm.HConvPairS2)
+        self.conv1 = HConvPairS2(c1.weight, c1.bias, pad=(c1.kernel_size[0] - 1) // 2, act=ACT_LEAKY, slope=0.1) \
+            if cin <= 16 and c1.stride[0] == 2 else _cv(net.conv1, cin_pad=pad32(cin))
+        self.pair_input = isinstance(self.conv1, HConvPairS2)
         self.names = ["conv2", "conv3", "conv3_1", "conv4", "conv4_1", "conv5", "conv5_1", "conv6", "conv6_1"]
         self.convs = {n: _cv(getattr(net, n)) for n in self.names}
         self.refine = _Refine(net, with_inter=False)
@@ -403,9 +407,9 @@ class FlowNet2Exec:
         x6.record_stream(side)
         flow_c = up_bil(self.c(x6)) * self.div_flow
         concat1 = ops.warp_concat(x, flow_c, self.div_flow)
-        flow_s1 = up_bil(self.s1(to_nhwc_half(concat1))) * self.div_flow
+        flow_s1 = up_bil(self.s1(to_nhwc_half(concat1, 16 if self.s1.pair_input else None))) * self.div_flow
         concat2 = ops.warp_concat(x, flow_s1, self.div_flow)
-        flow_s2 = up_nn(self.s2(to_nhwc_half(concat2))) * self.div_flow
+        flow_s2 = up_nn(self.s2(to_nhwc_half(concat2, 16 if self.s2.pair_input else None))) * self.div_flow
         n_s2, d_s2 = ops.warp_norms(x, flow_s2)
         main.wait_stream(side)
         concat3 = torch.cat((x[:, :3], flow_sd, flow_s2, n_sd, n_s2, d_sd, d_s2), dim=1)
