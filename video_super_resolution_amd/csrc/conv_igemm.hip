@@ -1030,15 +1030,14 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 // ceil(W/2); the last window of an odd side holds one row / column).  in [N,H,W,in_ld] slice [in_coff, +C) -> out [N,Ho,Wo,C]
 __global__ void __launch_bounds__(256) k_pool2(const _Float16* __restrict__ in, int in_ld, int in_coff, _Float16* __restrict__ out,
                                                int N, int H, int W, int C, int mode) {
-    const int Ho = mode == 2 ? (H + 1) >> 1 : H >> 1, Wo = mode == 2 ? (W + 1) >> 1 : W >> 1, c8n = C >> 3;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)N * Ho * Wo * c8n) return;
-    const int c8 = (int)(idx % c8n);
-    long long r = idx / c8n;
-    const int ox = (int)(r % Wo); r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int n = (int)(r / Ho);
-    const int dy = 2 * oy + 1 < H ? 1 : 0, dx = 2 * ox + 1 < W ? 1 : 0;   // (ceil mode: a clamped window re-reads its own row / column)
+    // blockIdx.y = output row (n * Ho + oy), blockIdx.x walks (ox, 8-channel piece): 32-bit index math only
+    const int Ho = mode == 2 ? (H + 1) >> 1 : H >> 1, Wo = mode == 2 ? (W + 1) >> 1 : W >> 1;
+    const unsigned c8n = (unsigned)C >> 3;
+    const unsigned q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= (unsigned)Wo * c8n) return;
+    const unsigned ox = q / c8n, c8 = q - ox * c8n;
+    const unsigned row = blockIdx.y, n = row / (unsigned)Ho, oy = row - n * (unsigned)Ho;
+    const int dy = 2 * (int)oy + 1 < H ? 1 : 0, dx = 2 * (int)ox + 1 < W ? 1 : 0;   // (ceil mode: a clamped window re-reads its own row / column)
     const _Float16* p00 = in + (((size_t)n * H + 2 * oy) * W + 2 * ox) * in_ld + in_coff + 8 * c8;
     const h8v a = *reinterpret_cast<const h8v*>(p00), b = *reinterpret_cast<const h8v*>(p00 + (size_t)dx * in_ld);
     const h8v c = *reinterpret_cast<const h8v*>(p00 + (size_t)dy * W * in_ld), d = *reinterpret_cast<const h8v*>(p00 + ((size_t)dy * W + dx) * in_ld);
@@ -1049,7 +1048,7 @@ __global__ void __launch_bounds__(256) k_pool2(const _Float16* __restrict__ in, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (_Float16)(((float)a[e] + (float)b[e] + (float)c[e] + (float)d[e]) * 0.25f);
     }
-    *reinterpret_cast<h8v*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + 8 * c8) = o;
+    *reinterpret_cast<h8v*>(out + ((size_t)row * Wo + ox) * C + 8 * c8) = o;
 }
 
 // [N,C,H,W] fp32 -> [N,H,W,cp] fp16 with the channels >= C written as zeros (round to nearest even, like Tensor.half()):
@@ -1076,20 +1075,19 @@ __global__ void __launch_bounds__(256) k_nchw_to_nhwc_h(const float* __restrict_
 __global__ void __launch_bounds__(256) k_resize_add(const _Float16* __restrict__ a, int a_ld, int a_coff, int Ha, int Wa,
                                                     const _Float16* __restrict__ b, int b_ld, int b_coff,
                                                     _Float16* __restrict__ out, int N, int H, int W, int C) {
-    const int c8n = C >> 3;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)N * H * W * c8n) return;
-    const int c8 = (int)(idx % c8n);
-    long long r = idx / c8n;
-    const int x = (int)(r % W); r /= W;
-    const int y = (int)(r % H);
-    const int n = (int)(r / H);
+    // blockIdx.y = image row (n * H + y), blockIdx.x walks (x, 8-channel piece) of that row: 32-bit index math only
+    // (a flat 64-bit index with three divisions per thread made this copy VALU-bound at a third of the device's copy rate)
+    const unsigned c8n = (unsigned)C >> 3;
+    const unsigned q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= (unsigned)W * c8n) return;
+    const unsigned x = q / c8n, c8 = q - x * c8n;
+    const unsigned row = blockIdx.y, n = row / (unsigned)H, y = row - n * (unsigned)H;
     // ATen nearest: src = min(floor(dst * (in / out)), in - 1) with a float scale
     const int ya = min((int)floorf((float)y * ((float)Ha / (float)H)), Ha - 1);
     const int xa = min((int)floorf((float)x * ((float)Wa / (float)W)), Wa - 1);
     h8v v = *reinterpret_cast<const h8v*>(a + (((size_t)n * Ha + ya) * Wa + xa) * a_ld + a_coff + 8 * c8);
-    if (b) v += *reinterpret_cast<const h8v*>(b + (((size_t)n * H + y) * W + x) * b_ld + b_coff + 8 * c8);
-    *reinterpret_cast<h8v*>(out + (((size_t)n * H + y) * W + x) * C + 8 * c8) = v;
+    if (b) v += *reinterpret_cast<const h8v*>(b + ((size_t)row * W + x) * b_ld + b_coff + 8 * c8);
+    *reinterpret_cast<h8v*>(out + ((size_t)row * W + x) * C + 8 * c8) = v;
 }
 
 // ---- OSVOS head (reference networks/vgg_osvos.py: side_prep -> upscale ConvTranspose2d(16,16,k=2s,stride=s) -> centre
@@ -1238,9 +1236,10 @@ int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int 
     VSR_REQUIRE(in && out, "pool2x2: null pointer");
     VSR_REQUIRE(N > 0 && H >= 2 && W >= 2 && C > 0 && (C & 7) == 0 && (in_ld & 7) == 0 && (in_coff & 7) == 0 && in_coff + C <= in_ld &&
                     (mode >= 0 && mode <= 2), "pool2x2: bad arguments");
-    const long long total = (long long)N * (mode == 2 ? (H + 1) >> 1 : H >> 1) * (mode == 2 ? (W + 1) >> 1 : W >> 1) * (C >> 3);
-    hipLaunchKernelGGL(k_pool2, dim3(vsr::cdiv(total, 256)), dim3(256), 0, vsr::S(stream), (const _Float16*)in, in_ld, in_coff,
-                       (_Float16*)out, N, H, W, C, mode);
+    const int Ho = mode == 2 ? (H + 1) >> 1 : H >> 1, Wo = mode == 2 ? (W + 1) >> 1 : W >> 1;
+    VSR_REQUIRE((long long)N * Ho <= 65535 && (long long)Wo * (C >> 3) < (1ll << 31), "pool2x2: more than 65535 output rows");
+    hipLaunchKernelGGL(k_pool2, dim3(vsr::cdiv((long long)Wo * (C >> 3), 256), (unsigned)(N * Ho)), dim3(256), 0, vsr::S(stream),
+                       (const _Float16*)in, in_ld, in_coff, (_Float16*)out, N, H, W, C, mode);
     return vsr::launched("pool2x2");
 }
 
@@ -1258,9 +1257,9 @@ int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa,
     VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ha > 0 && Wa > 0 && C > 0 && (C & 7) == 0 && (a_ld & 7) == 0 && (a_coff & 7) == 0 &&
                     a_coff + C <= a_ld, "resize_add: bad arguments");
     VSR_REQUIRE(!b_or_null || ((b_ld & 7) == 0 && (b_coff & 7) == 0 && b_coff + C <= b_ld), "resize_add: bad addend slice");
-    const long long total = (long long)N * H * W * (C >> 3);
-    hipLaunchKernelGGL(k_resize_add, dim3(vsr::cdiv(total, 256)), dim3(256), 0, vsr::S(stream), (const _Float16*)a, a_ld, a_coff, Ha,
-                       Wa, (const _Float16*)b_or_null, b_ld, b_coff, (_Float16*)out, N, H, W, C);
+    VSR_REQUIRE((long long)N * H <= 65535 && (long long)W * (C >> 3) < (1ll << 31), "resize_add: more than 65535 image rows");
+    hipLaunchKernelGGL(k_resize_add, dim3(vsr::cdiv((long long)W * (C >> 3), 256), (unsigned)(N * H)), dim3(256), 0, vsr::S(stream),
+                       (const _Float16*)a, a_ld, a_coff, Ha, Wa, (const _Float16*)b_or_null, b_ld, b_coff, (_Float16*)out, N, H, W, C);
     return vsr::launched("resize_add");
 }
 
