@@ -977,10 +977,10 @@ __global__ void __launch_bounds__(256) k_stem7_rows(const ConvP p, int tiles_x, 
 // sums the split-K partials in a fixed order, + bias, activation, fp16 store (4 channels per thread)
 __global__ void __launch_bounds__(256) k_splitk_finish(const ConvP p) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
-    const int c4n = p.cout_pad >> 2;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= M * c4n) return;
-    const long long m = idx / c4n;
+    const unsigned c4n = (unsigned)p.cout_pad >> 2;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;   // (split-K layers are small: M * cout_pad / 4 < 2^31, checked by the launcher)
+    if (idx >= (unsigned)M * c4n) return;
+    const unsigned m = idx / c4n;
     const int c = (int)(idx - m * c4n) * 4;
     if (c >= p.cout) return;
     const int ph = blockIdx.y, nph = p.nphase > 1 ? 4 : 1;
@@ -1004,9 +1004,9 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const ConvP p) {
         s += v1;
     }
     if (z < p.splits) s += *reinterpret_cast<const f4*>(wp + (size_t)z * zstride);
-    const int n = (int)(m / ((long long)p.Ho * p.Wo));
-    const int rem = (int)(m - (long long)n * p.Ho * p.Wo);
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
+    const unsigned n = m / HoWo, rem = m - n * HoWo;
+    const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
     _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + oy_off) * p.outW + ox * p.ox_mul + ox_off) * p.out_ld +
                     p.out_coff;
 #pragma unroll
