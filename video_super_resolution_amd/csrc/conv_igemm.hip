@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(256) k_conv_patch_rows(const ConvP p) {
 // fragment loads and KH+7 LDS reads -- half the L1 traffic and a third to a sixth of the LDS traffic per MFMA.
 constexpr int P8_H = 16, P8_W = 32, P8_R = 8;
 template <int KH, int MT>
-__global__ void __launch_bounds__(256, MT == 4 ? 2 : 1) k_conv_patch_r8(const ConvP p) {
+__global__ void __launch_bounds__(256) k_conv_patch_r8(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     const int PH = P8_H + KH - 1, PW = P8_W + p.kw - 1;
     unsigned char* const patch = psm;                      // [PH][PW] pixels of 64 B (chunk XOR pixel-column bits 1-2)
@@ -1424,16 +1424,15 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         p.ws = nullptr;
         p.splits = 1;
         const unsigned tiles = vsr::cdiv(Ho, PT_H) * vsr::cdiv(Wo, PT_W);
-        // 16 x 32 tiles, 8 rows per wave (k_conv_patch_r8) where a build exists and the patch fits the LDS
+        // 16 x 32 tiles, 8 rows per wave (k_conv_patch_r8) where a build exists and the patch fits the LDS: 32 out-channels
+        // per workgroup (grid.z walks the blocks; measured against 64 per workgroup on the 8 x 32 tile, tools/patch_exp.py:
+        // 3x3 32->64 at 2x512x960 93 -> 75 us, 64->128 at 2x256x480 80 -> 67 us) or the layer's 16
         const int r8_lds = (P8_H + kh - 1) * (P8_W + kw - 1) * 64;
-        const int r8_mt = (cout_pad & 63) == 0 && kh == 3 ? 4 : ((cout_pad & 31) == 0 ? 2 : (cout_pad == 16 ? 1 : 0));
-        // measured (tools/patch_exp.py): pays for 5x5 and larger kernels and for 16-channel outputs; 3x3 layers with 32+
-        // out-channels are staging-bound and keep the smaller tile's occupancy
-        const bool r8_pays = kh >= 5 || cout_pad == 16 || g_patch_mode == 2;
-        if (!no_r8 && r8_pays && r8_mt && r8_lds <= 80 * 1024 && Ho >= 12 && (kh == 3 || kh == 5 || kh == 7 || kh == 11)) {
+        const int r8_mt = (cout_pad & 31) == 0 ? 2 : (cout_pad == 16 ? 1 : 0);
+        if (!no_r8 && r8_mt && r8_lds <= 80 * 1024 && Ho >= 12 && (kh == 3 || kh == 5 || kh == 7 || kh == 11)) {
             hipStream_t st = vsr::S(stream);
 #define VSR_R8(KH_) \
-            if (kh == KH_) { if (r8_mt == 4 && KH_ == 3) launch_patch_r8<3, 4>(p, N, st); else if (r8_mt == 2) launch_patch_r8<KH_, 2>(p, N, st); else launch_patch_r8<KH_, 1>(p, N, st); }
+            if (kh == KH_) { if (r8_mt == 2) launch_patch_r8<KH_, 2>(p, N, st); else launch_patch_r8<KH_, 1>(p, N, st); }
             VSR_R8(3) VSR_R8(5) VSR_R8(7) VSR_R8(11)
 #undef VSR_R8
             return vsr::launched("conv2d_nhwc_f16/patch_r8");
