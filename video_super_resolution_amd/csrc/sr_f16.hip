@@ -651,59 +651,72 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
     __syncthreads();
     const h2 a1 = {(_Float16)slope_in, (_Float16)slope_in}, a2 = {(_Float16)slope_feat, (_Float16)slope_feat};
     const bool max1 = slope_in <= 1.0f, max2 = slope_feat <= 1.0f;
-    // this lane's 8 taps of the 27 (k = 8g + j): channel and offsets are lane constants
-    int tc[8], tdy[8], tdx[8];
-    float ts[8], tb[8];
+    // Tiles are 16 pixels of one image row (wave-uniform row decode, 32-bit).  The 3 x 3 x 18 mean-shifted input values a
+    // tile needs (3 channels, rows y-1..y+1, columns x0-1..x0+16; zero outside the image) are staged in the wave's LDS
+    // slice by three loads per lane, requested one tile ahead of the MFMAs; a lane then picks its eight taps with
+    // ds_read_b32 -- no per-tap address arithmetic, clamps or compares (the gather was the kernel's issue bound).
+    constexpr int SROW = 20, SCH = 3 * SROW, SWAVE = 3 * SCH;   // floats: [channel][row][column, padded to 20]
+    __shared__ __attribute__((aligned(16))) float stg[4 * SWAVE];
+    __shared__ __attribute__((aligned(16))) unsigned char ost[4 * 1024];
+    const int wvi = threadIdx.x >> 6;
+    float* const my = stg + wvi * SWAVE;
+    int toff[8];   // this lane's taps k = 8g + j -> float offset of (c, dy, dx) for pixel l15; k >= 27: any (weight 0)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = 8 * g + j, kk = k < 27 ? k : 0;
-        tc[j] = kk / 9;
-        tdy[j] = (kk % 9) / 3 - 1;
-        tdx[j] = kk % 3 - 1;
-        ts[j] = k < 27 ? sub_scale[tc[j]] : 0.0f;
-        tb[j] = k < 27 ? sub_bias[tc[j]] : 0.0f;
+        toff[j] = (kk / 9) * SCH + ((kk % 9) / 3) * SROW + (kk % 3) + l15;
     }
-    // tiles are 16 pixels of one image row (wave-uniform row decode, 32-bit); the eight taps of a lane are loaded from
-    // clamped coordinates with no branch (all in flight together, padding selected afterwards), one tile ahead of the
-    // MFMAs that use them
+    // staging elements of this lane: e = lane + 64 q < 162 -> (c, r, col) = (e / 54, (e % 54) / 18, e % 18)
+    int ec[3], er[3], ecol[3], eoff[3];
+    float es[3], eb[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e0 = lane + 64 * q, ee = e0 < 162 ? e0 : 0;
+        ec[q] = ee / 54; er[q] = (ee % 54) / 18; ecol[q] = ee % 18;
+        eoff[q] = e0 < 162 ? ec[q] * SCH + er[q] * SROW + ecol[q] : -1;
+        es[q] = sub_scale[ec[q]]; eb[q] = sub_bias[ec[q]];
+    }
     const unsigned tpr = (unsigned)(w + 15) >> 4;
     const unsigned ntiles = (unsigned)N * (unsigned)h * tpr;
     const unsigned wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
-    auto gather = [&](unsigned tile, float (&raw)[8], unsigned& okmask, unsigned& row_out) __attribute__((always_inline)) {
+    auto fetch = [&](unsigned tile, float (&raw)[3], unsigned& okmask, unsigned& row_out) __attribute__((always_inline)) {
         const unsigned row = tile / tpr, xt = tile - row * tpr;   // row = n * h + y
         const unsigned n = row / (unsigned)h;
-        const int y = (int)(row - n * (unsigned)h), xx = (int)(16 * xt) + l15;
+        const int y = (int)(row - n * (unsigned)h), x0 = (int)(16 * xt);
         const float* const img = x + (size_t)n * 3 * hw;
         unsigned m = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int yy = y + tdy[j], xc = xx + tdx[j];
+        for (int q = 0; q < 3; ++q) {
+            const int yy = y - 1 + er[q], xc = x0 - 1 + ecol[q];
             const bool ok = yy >= 0 && yy < h && xc >= 0 && xc < w;
             const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy), xl = xc < 0 ? 0 : (xc >= w ? w - 1 : xc);
-            raw[j] = img[(size_t)tc[j] * hw + (size_t)yc * w + xl];
-            m |= ok ? (1u << j) : 0u;
+            raw[q] = img[(size_t)ec[q] * hw + (size_t)yc * w + xl];
+            m |= ok ? (1u << q) : 0u;
         }
         okmask = m;
         row_out = row;
     };
-    float cur[8];
+    float cur[3];
     unsigned curm = 0, cur_row = 0;
-    if (wave0 < ntiles) gather(wave0, cur, curm, cur_row);
+    if (wave0 < ntiles) fetch(wave0, cur, curm, cur_row);
     for (unsigned tile = wave0; tile < ntiles; tile += nwaves) {
-        float nxr[8];
+        float nxr[3];
         unsigned nxm, nx_row;
         const unsigned tnext = tile + nwaves < ntiles ? tile + nwaves : tile;
-        gather(tnext, nxr, nxm, nx_row);
+        fetch(tnext, nxr, nxm, nx_row);
         const unsigned xt = tile - cur_row * tpr;
         const int xx = (int)(16 * xt) + l15;
-        const size_t px = (size_t)cur_row * w + (xx < w ? xx : w - 1);
-        const bool px_ok = xx < w;
+        // stage (mean shift applied here, zero outside the image: the conv's padding applies after the shift)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float t = cur[q] * es[q] + eb[q];
+            if (eoff[q] >= 0) my[eoff[q]] = (curm >> q) & 1u ? t : 0.0f;
+        }
+        asm volatile("" ::: "memory");   // (same wave, in-order LDS)
         h8 bfrag;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float t = cur[j] * ts[j] + tb[j];
-            bfrag[j] = (curm >> j) & 1u ? (_Float16)t : (_Float16)0.0f;
-        }
+        for (int j = 0; j < 8; ++j) bfrag[j] = (_Float16)my[toff[j]];
+        asm volatile("" ::: "memory");
         unsigned loff = lane * 16, boff = g * 16;
         asm volatile("" : "+v"(loff), "+v"(boff));   // opaque per trip: the weight reads stay in the loop (hoisted they cost the occupancy)
         const unsigned char* const a1p = reinterpret_cast<const unsigned char*>(&A1s[0][0]) + loff;
@@ -724,24 +737,32 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
 #pragma unroll
             for (int mt2 = 0; mt2 < 2; ++mt2) acc2[mt2] = mfma16(*reinterpret_cast<const h8*>(a2p + (2 * s4 + mt2) * 1024), mid, acc2[mt2]);
         }
-        if (px_ok) {
+        {
+            // out through the wave's LDS slice: the 16 pixels x 64 bytes leave as one contiguous store (see k_chain1x1_s)
             typedef float f2v __attribute__((ext_vector_type(2)));
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            unsigned char* const o = ost + wvi * 1024;
+            const int sw = l15 & 3;
 #pragma unroll
             for (int mt2 = 0; mt2 < 2; ++mt2) {
                 const h2 p0 = prelu_h2(__builtin_convertvector(f2v{acc2[mt2][0], acc2[mt2][1]}, h2), a2, max2);
                 const h2 p1 = prelu_h2(__builtin_convertvector(f2v{acc2[mt2][2], acc2[mt2][3]}, h2), a2, max2);
-                *reinterpret_cast<h4*>(out + px * NF + 16 * mt2 + 4 * g) = h4{p0[0], p0[1], p1[0], p1[1]};
+                *reinterpret_cast<h4*>(o + l15 * 64 + (((2 * mt2 + (g >> 1)) ^ sw) << 4) + ((g & 1) << 3)) = h4{p0[0], p0[1], p1[0], p1[1]};
             }
+            asm volatile("" ::: "memory");
+            const int opx = lane >> 2, opc = (lane & 3) ^ (opx & 3);
+            const h8 ov = *reinterpret_cast<const h8*>(o + lane * 16);
+            asm volatile("" ::: "memory");
+            const int ox = (int)(16 * xt) + opx;
+            if (ox < w) *reinterpret_cast<h8*>(out + ((size_t)cur_row * w + ox) * NF + 8 * opc) = ov;
         }
+        (void)xx;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cur[j] = nxr[j];
+        for (int q = 0; q < 3; ++q) cur[q] = nxr[q];
         curm = nxm;
         cur_row = nx_row;
     }
 }
-
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_utd2: the same fused stage with SPECIALISED wave roles.  In k_utd every wave runs P2 then P1 and both waves of
