@@ -60,6 +60,27 @@ __device__ __forceinline__ h8 act_pack(f4 lo, f4 hi, h2 a, bool use_max) {
 
 __device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+typedef float f2v_act __attribute__((ext_vector_type(2)));
+// One PReLU unit = 8 accumulator values of a lane -> 4 packed fp16 dwords, as 12 single VALU instructions that the
+// step schedule places one by one: stage 0-3 convert, 4-7 multiply by the slope, 8-11 max (min for slopes > 1).
+struct ActU {
+    h2 c[4], m[4], r[4];
+};
+__device__ __forceinline__ void act_stage(ActU& u, int j, const f4& lo, const f4& hi, h2 a, bool use_max) {
+    if (j < 4) {
+        const f2v_act s = j == 0 ? f2v_act{lo[0], lo[1]} : j == 1 ? f2v_act{lo[2], lo[3]} : j == 2 ? f2v_act{hi[0], hi[1]} : f2v_act{hi[2], hi[3]};
+        u.c[j] = __builtin_convertvector(s, h2);
+    } else if (j < 8) {
+        u.m[j - 4] = u.c[j - 4] * a;
+    } else {
+        u.r[j - 8] = use_max ? __builtin_elementwise_max(u.c[j - 8], u.m[j - 8]) : __builtin_elementwise_min(u.c[j - 8], u.m[j - 8]);
+    }
+}
+__device__ __forceinline__ h8 act_result(const ActU& u) {
+    return h8{u.r[0][0], u.r[0][1], u.r[1][0], u.r[1][1], u.r[2][0], u.r[2][1], u.r[3][0], u.r[3][1]};
+}
+
+
 // byte offset of (column cc, 16-byte chunk) inside a ring row
 // (80-byte pitch + chunk XOR column bits 3-4: every ds_read_b128 / ds_write_b128 lane group of the access patterns
 // below lands on distinct banks -- checked by exhaustive simulation of the gfx950 lane groups, tools/lds_bank_sim.py)

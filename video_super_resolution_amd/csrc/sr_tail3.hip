@@ -196,6 +196,80 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         }
     };
 
+    int cq[2];
+    bool okq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int u = lane + 64 * q;
+        cq[q] = 4 * x0 + u - 2;
+        okq[q] = u >= 2 && u < 126 && cq[q] < W && (!DEC || (cq[q] & 3) == 0);
+    }
+    const float bo[3] = {tpar[0], tpar[1], tpar[2]};
+    // The same for a row inside the image (full frames), written out slot by slot like k_utd3's step: the PReLU of column
+    // phases 0,1 (48 single VALU stages + 16 edge selects) rides in the gaps of the 32 MFMAs of phases 2,3, and the finish
+    // of the output row two steps back (LDS reads, sums, stores) in the gaps of the first 32.  Left to hipcc the step ran
+    // its MFMAs and its VALU back to back (4400 cycles for 92 MFMAs).
+    auto dmf = [&](int half, int k, const h8 (&Bf)[4][2], f4 (&acc)[2][2][2]) __attribute__((always_inline)) {
+        const int c = k >> 4, t = (k >> 2) & 3, mt = (k >> 1) & 1, nt = k & 1;
+        acc[c][mt][nt] = mfma16(Aup[2 * half + c][t][mt], Bf[t][nt], t == 0 ? bup[mt] : acc[c][mt][nt]);
+    };
+    auto deconv_row_fast = [&](int i, const h8 (&Bf)[4][2], h8 (&ob)[4][2], int Rfin) __attribute__((always_inline)) {
+        f4 accA[2][2][2], accB[2][2][2];
+        ActU uA[4];
+        const bool fin = Rfin >= 4 * r0 && Rfin < 4 * r1;   // wave-uniform
+        const unsigned char* const fsrc = pb + ((Rfin & (T3_ROWS - 1)) * 3) * T3_PLANE;
+        f4 fs[2][3];
+        bool colok[4][2];
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
+                colok[px][nt] = (c_hr >= 0) && (c_hr < W);
+            }
+        VSR_FENCE();
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            dmf(0, s, Bf, accA);
+            if (fin) {
+                if (s < 6) fs[s / 3][s % 3] = *reinterpret_cast<const f4*>(fsrc + (s % 3) * T3_PLANE + (lane + 64 * (s / 3)) * 16);
+                if (s == 10 || s == 14) { const int q = (s - 10) >> 2; fs[q][0] += fs[q][1]; fs[q][0] += fs[q][2]; }
+                if (s == 18 || s == 24) {
+                    const int q = s == 18 ? 0 : 1;
+                    if (okq[q]) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) prefc[(((size_t)n * 3 + ch) * H + Rfin) * W + cq[q]] = fs[q][0][ch] + bo[ch];
+                    }
+                }
+            }
+            VSR_FENCE();
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            dmf(1, s, Bf, accB);
+#pragma unroll
+            for (int v = 2 * s; v < 2 * s + 2; ++v) {
+                const int u = v >> 4, st = v & 15, c = u >> 1, nt = u & 1;
+                if (st < 12) act_stage(uA[u], st, accA[c][0][nt], accA[c][1][nt], a_up2, up_max);
+                else {
+                    const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
+                    uA[u].r[st - 12] = colok[c][nt] ? uA[u].r[st - 12] : z;
+                    if (st == 15) ob[c][nt] = act_result(uA[u]);
+                }
+            }
+            VSR_FENCE();
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                h8 hb = act_pack(accB[c][0][nt], accB[c][1][nt], a_up2, up_max);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hb[e] = colok[2 + c][nt] ? hb[e] : (_Float16)0.0f;
+                ob[2 + c][nt] = hb;
+            }
+    };
+
     // ---- P3: contributions of this HR row to output rows R'+1 (dy 0), R' (dy 1), R'-1 (dy 2) -> partial planes
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     auto ror1 = [&](const h8& src) __attribute__((always_inline)) -> u4v {    // row_ror:1: lane i <- src[(i-1)%16]
@@ -262,15 +336,6 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
     //      u = lane and lane + 64.  The bilinear skip and add_mean are applied where the planes are read next, in the
     //      fusion-MLP kernel (k_fc_planes_skip): there they cost HBM-bound elementwise time instead of ~0.45 ms of
     //      dependent gathers inside this MFMA kernel.
-    int cq[2];
-    bool okq[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int u = lane + 64 * q;
-        cq[q] = 4 * x0 + u - 2;
-        okq[q] = u >= 2 && u < 126 && cq[q] < W && (!DEC || (cq[q] & 3) == 0);
-    }
-    const float bo[3] = {tpar[0], tpar[1], tpar[2]};
     auto finish_row = [&](int R) __attribute__((always_inline)) {
         if (R < 4 * r0 || R >= 4 * r1) return;   // wave-uniform
         if (DEC && (R & 3) != 0) return;
@@ -310,10 +375,16 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         __syncthreads();
         // rows whose last contribution was stored two steps ago (visible since the previous barrier; their planes are
         // not rewritten before step i+2): anywhere in this step, so beside the MFMAs
-        finish_row(4 * i - 7 + wv);
-        if (produce && !(DEC && wv == 0)) {   // DEC: HR row 4i+2 feeds output rows 4i+1..4i+3 only, none of them kept
-            deconv_row(i, Bf, ob);
+        const int r_hr = 4 * i + 2 + wv;
+        if (!DEC && produce && r_hr >= 0 && r_hr < H) {   // steady state of a full frame: the hand-ordered deconv, finish inside
+            deconv_row_fast(i, Bf, ob, 4 * i - 7 + wv);
             conv_row(i, ob);
+        } else {
+            finish_row(4 * i - 7 + wv);
+            if (produce && !(DEC && wv == 0)) {   // DEC: HR row 4i+2 feeds output rows 4i+1..4i+3 only, none of them kept
+                deconv_row(i, Bf, ob);
+                conv_row(i, ob);
+            }
         }
         if (produce && wv < 3) {
             const u4 nv = row_value(nxt, i + 3);

@@ -28,25 +28,6 @@ __device__ unsigned long long* g_stamp3_ptr = nullptr;
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-// One PReLU unit = 8 accumulator values of a lane -> 4 packed fp16 dwords, as 12 single VALU instructions that the
-// step schedule places one by one: stage 0-3 convert, 4-7 multiply by the slope, 8-11 max (min for slopes > 1).
-struct ActU {
-    h2 c[4], m[4], r[4];
-};
-__device__ __forceinline__ void act_stage(ActU& u, int j, const f4& lo, const f4& hi, h2 a, bool use_max) {
-    if (j < 4) {
-        const f2v s = j == 0 ? f2v{lo[0], lo[1]} : j == 1 ? f2v{lo[2], lo[3]} : j == 2 ? f2v{hi[0], hi[1]} : f2v{hi[2], hi[3]};
-        u.c[j] = __builtin_convertvector(s, h2);
-    } else if (j < 8) {
-        u.m[j - 4] = u.c[j - 4] * a;
-    } else {
-        u.r[j - 8] = use_max ? __builtin_elementwise_max(u.c[j - 8], u.m[j - 8]) : __builtin_elementwise_min(u.c[j - 8], u.m[j - 8]);
-    }
-}
-__device__ __forceinline__ h8 act_result(const ActU& u) {
-    return h8{u.r[0][0], u.r[0][1], u.r[1][0], u.r[1][1], u.r[2][0], u.r[2][1], u.r[3][0], u.r[3][1]};
-}
-
 #define VSR_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 constexpr int UTD3_LDS = PART_BYTES + LR_BYTES;   // no HR ring: the x4 map never leaves the registers
