@@ -232,7 +232,7 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         for (int s = 0; s < 32; ++s) {
             dmf(0, s, Bf, accA);
             if (fin) {
-                if (s < 6) fs[s / 3][s % 3] = *reinterpret_cast<const f4*>(fsrc + (s % 3) * T3_PLANE + (lane + 64 * (s / 3)) * 16);
+                if (s < 6) { const int u = lane + 64 * (s / 3); fs[s / 3][s % 3] = *reinterpret_cast<const f4*>(fsrc + (s % 3) * T3_PLANE + (u ^ ((u >> 4) & 3)) * 16); }
                 if (s == 10 || s == 14) { const int q = (s - 10) >> 2; fs[q][0] += fs[q][1]; fs[q][0] += fs[q][2]; }
                 if (s == 18 || s == 24) {
                     const int q = s == 18 ? 0 : 1;
@@ -311,6 +311,10 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         // lane group g = dy: partial plane of output row Rp + 1 - g (idle group 3 -> dump plane)
         const int plane = g < 3 ? ((Rp + 1 - g) & (T3_ROWS - 1)) * 3 + g : T3_ROWS * 3;
         unsigned char* const dst = pb + plane * T3_PLANE + l15 * 64;   // + (16 nt) * 64 + pxo * 16:  u = 4 (16 nt + l15) + pxo
+        // 16-byte slot of u inside its 64-byte pixel group XOR (l15 >> 2): lanes l15, l15+4, l15+8, l15+12 are 256 bytes
+        // apart, i.e. on the same banks -- unswizzled every partial store was a 4-way conflict (1870 cycles per step in
+        // this block against 400 of MFMA, s_memtime stamps); readers apply u ^ ((u >> 4) & 3)
+        const int psw = (l15 >> 2) & 3;
         f4 acc[4][2];   // dx outermost: 8 independent accumulator chains between two MFMAs on the same tile
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
@@ -328,7 +332,7 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 if (DEC && pxo != 2) continue;
-                *reinterpret_cast<f4*>(dst + nt * 1024 + pxo * 16) = acc[pxo][nt];
+                *reinterpret_cast<f4*>(dst + nt * 1024 + ((pxo ^ psw) << 4)) = acc[pxo][nt];
             }
     };
 
@@ -344,9 +348,10 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         for (int q = 0; q < 2; ++q) {
             if (!okq[q]) continue;
             const int u = lane + 64 * q;
-            f4 s = *reinterpret_cast<const f4*>(src + u * 16);
-            s += *reinterpret_cast<const f4*>(src + T3_PLANE + u * 16);
-            s += *reinterpret_cast<const f4*>(src + 2 * T3_PLANE + u * 16);
+            const int us = u ^ ((u >> 4) & 3);   // (slot swizzle of the partial planes, see conv_row)
+            f4 s = *reinterpret_cast<const f4*>(src + us * 16);
+            s += *reinterpret_cast<const f4*>(src + T3_PLANE + us * 16);
+            s += *reinterpret_cast<const f4*>(src + 2 * T3_PLANE + us * 16);
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 const float v = s[ch] + bo[ch];
