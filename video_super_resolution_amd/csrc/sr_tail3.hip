@@ -332,7 +332,10 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 if (DEC && pxo != 2) continue;
-                *reinterpret_cast<f4*>(dst + nt * 1024 + ((pxo ^ psw) << 4)) = acc[pxo][nt];
+                // rows 4 dy + co of the tile: lane groups 0..2 hold the three channels of one dy each (12 useful bytes), group
+                // 3 nothing -- 9/16 of a full-tile store (the LDS writes of the four waves in lockstep were 600 cycles a step)
+                typedef float f3 __attribute__((ext_vector_type(3)));
+                if (g < 3) *reinterpret_cast<f3*>(dst + nt * 1024 + ((pxo ^ psw) << 4)) = f3{acc[pxo][nt][0], acc[pxo][nt][1], acc[pxo][nt][2]};
             }
     };
 
