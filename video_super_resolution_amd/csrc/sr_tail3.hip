@@ -232,7 +232,7 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         for (int s = 0; s < 32; ++s) {
             dmf(0, s, Bf, accA);
             if (fin) {
-                if (s < 6) { const int u = lane + 64 * (s / 3); fs[s / 3][s % 3] = *reinterpret_cast<const f4*>(fsrc + (s % 3) * T3_PLANE + (u ^ ((u >> 4) & 3)) * 16); }
+                if (s < 6) { const int u = lane + 64 * (s / 3); fs[s / 3][s % 3] = *reinterpret_cast<const f4*>(fsrc + (s % 3) * T3_PLANE + (u ^ ((u >> 3) & 3)) * 16); }
                 if (s == 10 || s == 14) { const int q = (s - 10) >> 2; fs[q][0] += fs[q][1]; fs[q][0] += fs[q][2]; }
                 if (s == 18 || s == 24) {
                     const int q = s == 18 ? 0 : 1;
@@ -311,10 +311,11 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         // lane group g = dy: partial plane of output row Rp + 1 - g (idle group 3 -> dump plane)
         const int plane = g < 3 ? ((Rp + 1 - g) & (T3_ROWS - 1)) * 3 + g : T3_ROWS * 3;
         unsigned char* const dst = pb + plane * T3_PLANE + l15 * 64;   // + (16 nt) * 64 + pxo * 16:  u = 4 (16 nt + l15) + pxo
-        // 16-byte slot of u inside its 64-byte pixel group XOR (l15 >> 2): lanes l15, l15+4, l15+8, l15+12 are 256 bytes
-        // apart, i.e. on the same banks -- unswizzled every partial store was a 4-way conflict (1870 cycles per step in
-        // this block against 400 of MFMA, s_memtime stamps); readers apply u ^ ((u >> 4) & 3)
-        const int psw = (l15 >> 2) & 3;
+        // 16-byte slot of u inside its 64-byte pixel group XOR (l15 >> 1): a ds_write_b128 retires eight lanes per pass
+        // over 32 banks, and lanes l15, l15+2, .. are 128 bytes apart, i.e. on the same banks -- unswizzled every partial
+        // store conflicted (1870 cycles per step in this block against 400 of MFMA, s_memtime stamps; tools/lds_bank_sim.py
+        // rules); readers apply u ^ ((u >> 3) & 3)
+        const int psw = (l15 >> 1) & 3;
         f4 acc[4][2];   // dx outermost: 8 independent accumulator chains between two MFMAs on the same tile
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
@@ -351,7 +352,7 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         for (int q = 0; q < 2; ++q) {
             if (!okq[q]) continue;
             const int u = lane + 64 * q;
-            const int us = u ^ ((u >> 4) & 3);   // (slot swizzle of the partial planes, see conv_row)
+            const int us = u ^ ((u >> 3) & 3);   // (slot swizzle of the partial planes, see conv_row)
             f4 s = *reinterpret_cast<const f4*>(src + us * 16);
             s += *reinterpret_cast<const f4*>(src + T3_PLANE + us * 16);
             s += *reinterpret_cast<const f4*>(src + 2 * T3_PLANE + us * 16);
