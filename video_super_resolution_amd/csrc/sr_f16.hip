@@ -589,11 +589,11 @@ k_chain1x1_s(const ChainP cp, unsigned P, unsigned total_px) {
                 // instructions of 8 bytes per lane, 32 bytes per pixel each.  16-byte pieces XOR (pixel & 3).
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                 unsigned char* const o = ost + wv * 1024;
-                const int sw = l15 & 3;
+                const int sw = (l15 >> 1) & 3;   // (8 lanes per ds_write pass over 32 banks: lanes two pixels apart share banks)
                 *reinterpret_cast<h4*>(o + l15 * 64 + (((g >> 1) ^ sw) << 4) + ((g & 1) << 3)) = h4{prev[0], prev[1], prev[2], prev[3]};
                 *reinterpret_cast<h4*>(o + l15 * 64 + (((2 + (g >> 1)) ^ sw) << 4) + ((g & 1) << 3)) = h4{prev[4], prev[5], prev[6], prev[7]};
                 asm volatile("" ::: "memory");
-                const int opx = lane >> 2, opc = (lane & 3) ^ (opx & 3);   // this lane's linear slot holds piece opc of pixel opx
+                const int opx = lane >> 2, opc = (lane & 3) ^ ((opx >> 1) & 3);   // this lane's linear slot holds piece opc of pixel opx
                 const h8 ov = *reinterpret_cast<const h8*>(o + lane * 16);
                 asm volatile("" ::: "memory");
                 const unsigned gpx = tile * 16 + opx;
@@ -742,7 +742,7 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
             typedef float f2v __attribute__((ext_vector_type(2)));
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             unsigned char* const o = ost + wvi * 1024;
-            const int sw = l15 & 3;
+            const int sw = (l15 >> 1) & 3;   // (8 lanes per ds_write pass over 32 banks: lanes two pixels apart share banks)
 #pragma unroll
             for (int mt2 = 0; mt2 < 2; ++mt2) {
                 const h2 p0 = prelu_h2(__builtin_convertvector(f2v{acc2[mt2][0], acc2[mt2][1]}, h2), a2, max2);
@@ -750,7 +750,7 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
                 *reinterpret_cast<h4*>(o + l15 * 64 + (((2 * mt2 + (g >> 1)) ^ sw) << 4) + ((g & 1) << 3)) = h4{p0[0], p0[1], p1[0], p1[1]};
             }
             asm volatile("" ::: "memory");
-            const int opx = lane >> 2, opc = (lane & 3) ^ (opx & 3);
+            const int opx = lane >> 2, opc = (lane & 3) ^ ((opx >> 1) & 3);
             const h8 ov = *reinterpret_cast<const h8*>(o + lane * 16);
             asm volatile("" ::: "memory");
             const int ox = (int)(16 * xt) + opx;
