@@ -49,7 +49,16 @@ def _db(P: Params, pre: str, x, stride, padding):
     return F.prelu(y, P[pre + ".1.weight"])
 
 
-def feedback_block(P: Params, pre: str, x, last_hidden, num_groups: int, nf: int, taps: Optional[dict] = None):
+def sr_geometry(upscale_factor: int):
+    """(kernel, stride, padding) of the up / down / `out` (de)convolutions.  The reference hard-wires (8, 4, 2)
+    (SRProjectionModule.py:10-12,101-103: the x4 row of SRFBN's table); x2 / x3 are that table's other rows, the
+    "scale-2 extension" of SURVEY.md 7-1 / 8(d) -- parity-unpinned by construction (the reference crashes there), and
+    differing from the pinned x4 case in these three literals only."""
+    return {2: (6, 2, 2), 3: (7, 3, 2), 4: (8, 4, 2)}[upscale_factor]
+
+
+def feedback_block(P: Params, pre: str, x, last_hidden, num_groups: int, nf: int, taps: Optional[dict] = None,
+                   stride: int = 4, padding: int = 2):
     """FeedbackBlock.forward with the zero-fill semantic -- SRProjectionModule.py:44-90."""
     lr: List[torch.Tensor] = [_cb(P, pre + "compress_in", torch.cat((x, last_hidden), 1))]  # :49-53
     hr: List[torch.Tensor] = []
@@ -61,7 +70,7 @@ def feedback_block(P: Params, pre: str, x, last_hidden, num_groups: int, nf: int
             ld_l[:, nf * idx:nf * (idx + 1)] = lr[i]
         if idx > 0:
             ld_l = _cb(P, f"{pre}uptranBlocks.{idx - 1}", ld_l)  # :62-63
-        ld_h = _db(P, f"{pre}upBlocks.{idx}", ld_l, 4, 2)  # :64
+        ld_h = _db(P, f"{pre}upBlocks.{idx}", ld_l, stride, padding)  # :64
         hr.append(ld_h)
         shp = list(hr[0].shape)
         shp[1] *= idx + 1
@@ -70,7 +79,7 @@ def feedback_block(P: Params, pre: str, x, last_hidden, num_groups: int, nf: int
             ld_hc[:, nf * idx:nf * (idx + 1)] = hr[i]
         if idx > 0:
             ld_hc = _cb(P, f"{pre}downtranBlocks.{idx - 1}", ld_hc)  # :77-78
-        lr.append(_cb(P, f"{pre}downBlocks.{idx}", ld_hc, stride=4, padding=2))  # :79-80
+        lr.append(_cb(P, f"{pre}downBlocks.{idx}", ld_hc, stride=stride, padding=padding))  # :79-80
     if taps is not None:
         for i, t in enumerate(lr):
             taps[f"lr{i}"] = t
@@ -83,6 +92,8 @@ def sr_forward(P: Params, x: torch.Tensor, pre: str = "", num_steps: int = 3, nu
                upscale_factor: int = 4, taps: Optional[dict] = None, group_taps_step: int = -1) -> torch.Tensor:
     """SRProjectionModule.forward -- SRProjectionModule.py:133-147.  x: [8,3,h,w] -> [1,3,4h,4w]."""
     nf = P[pre + "feat_in.0.weight"].shape[0]
+    kernel, stride, padding = sr_geometry(upscale_factor)
+    assert P[pre + "out.0.weight"].shape[-1] == kernel, "weights were built for another upscale_factor"
     x = F.conv2d(x, P[pre + "sub_mean.weight"], P[pre + "sub_mean.bias"])  # :135
     inter_res = F.interpolate(x, scale_factor=upscale_factor, mode="bilinear", align_corners=False)  # :136
     if taps is not None:
@@ -95,9 +106,9 @@ def sr_forward(P: Params, x: torch.Tensor, pre: str = "", num_steps: int = 3, nu
     h = None
     for step in range(num_steps):  # :140
         gt = {} if (taps is not None and step == (group_taps_step % num_steps)) else None
-        hid = feedback_block(P, pre + "block.", x, last_hidden, num_groups, nf, gt)
+        hid = feedback_block(P, pre + "block.", x, last_hidden, num_groups, nf, gt, stride, padding)
         last_hidden = hid  # :89
-        h = inter_res + F.conv2d(_db(P, pre + "out", hid, 4, 2), P[pre + "conv_out.0.weight"],
+        h = inter_res + F.conv2d(_db(P, pre + "out", hid, stride, padding), P[pre + "conv_out.0.weight"],
                                  P[pre + "conv_out.0.bias"], padding=1)  # :142
         h = F.conv2d(h, P[pre + "add_mean.weight"], P[pre + "add_mean.bias"])  # :143
         if taps is not None:
@@ -452,8 +463,10 @@ def _nhwc2nchw(x):
 
 
 def vsr_forward(P: Params, data: torch.Tensor, estimated_image: Optional[torch.Tensor],
-                high_frames: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> torch.Tensor:
-    """One frame.  data [3,h,w,3] (0..255 floats), estimated_image None | [1,4h,4w,3] -> output [1,4h,4w,3]."""
+                high_frames: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
+                upscale_factor: int = 4) -> torch.Tensor:
+    """One frame.  data [3,h,w,3] (0..255 floats), estimated_image None | [1,4h,4w,3] -> output [1,4h,4w,3]
+    (4 -> `upscale_factor` for the scale extension, see sr_geometry)."""
     hw = (data.shape[1], data.shape[2])
     d = data.clone()
     flow_pics = torch.stack([flow_projection(P, d[0], d[1], "FlowModule.net."),
@@ -465,7 +478,7 @@ def vsr_forward(P: Params, data: torch.Tensor, estimated_image: Optional[torch.T
     flow_pics = F.interpolate(_nhwc2nchw(flow_pics), hw)  # :35 (nearest)
     est = F.interpolate(_nhwc2nchw(estimated_image), hw) if estimated_image is not None else frames[0:1]  # :37-38
     x8 = torch.cat((frames, flow_pics, depth, est), 0)  # :40
-    out1 = sr_forward(P, x8, "model.")  # :41
+    out1 = sr_forward(P, x8, "model.", upscale_factor=upscale_factor)  # :41
     if taps is not None:
         taps.update(pass1_input=x8, pass1_output=out1)
 
@@ -480,7 +493,7 @@ def vsr_forward(P: Params, data: torch.Tensor, estimated_image: Optional[torch.T
     mid = trip[1].permute(2, 0, 1)  # tools.transpose1201 -> [3,h,w]
     masked = torch.where(mask != 0, torch.zeros_like(mid), mid).unsqueeze(0)  # :58-60 MaskedArray(...).filled(0)
     x8 = torch.cat((_nhwc2nchw(data), flow_pics, depth, masked), 0)  # :57,:62
-    out = sr_forward(P, x8, "model.").permute(0, 2, 3, 1)  # :64 transpose1312
+    out = sr_forward(P, x8, "model.", upscale_factor=upscale_factor).permute(0, 2, 3, 1)  # :64 transpose1312
     if taps is not None:
         taps.update(pass2_input=x8, vos_mask=mask)
     if high_frames is not None:

@@ -37,6 +37,21 @@ def test_argument_validation_without_a_gpu():
     assert (oc.value, oh.value, ow.value) == (441, 64, 120)  # reference correlation_cuda.cc:31-34 at 960x512 / 8
 
 
+def test_conv_launcher_refuses_an_image_beyond_its_32_bit_offsets():
+    """The gather kernels address their input with 32-bit byte offsets: a batch beyond 4 GiB is split into whole images
+    by the launcher, and ONE image beyond 4 GiB is refused before anything is launched (it used to wrap)."""
+    lib = _lib.load()
+    fake = ctypes.c_void_p(0x1000)   # never dereferenced on the host; the call must fail before any launch
+    H = W = 32768                    # 32768^2 pixels x 32 channels x 2 bytes = 64 GiB
+    rc = lib.vsr_conv2d_nhwc_sx_f16(fake, 32, 0, fake, None, fake, 32, 0, 1, H, W, 32, H // 2, W // 2, 32, 32, 3, 3, 2, 0, 1, 1,
+                                    H // 2, W // 2, 1, 0, 1, 0, 0, ctypes.c_float(0.0), None, ctypes.c_size_t(0), None)
+    assert rc == -1 and b"4 GiB" in lib.vsr_last_error()
+    ph = (ctypes.c_void_p * 4)(0x1000, 0x1000, 0x1000, 0x1000)
+    rc = lib.vsr_deconv4s2_nhwc_f16(fake, 32, 0, ph, None, fake, 32, 0, 1, H, W, 32, 32, 32, 0, ctypes.c_float(0.0), None,
+                                    ctypes.c_size_t(0), None)
+    assert rc == -1 and b"4 GiB" in lib.vsr_last_error()
+
+
 def test_sr_state_dict_has_the_reference_layout(cpu_vsr):
     sd = cpu_vsr.model.state_dict()
     expect = {"sub_mean.weight": (3, 3, 1, 1), "conv_in.0.weight": (128, 3, 3, 3), "conv_in.1.weight": (1,),

@@ -230,3 +230,44 @@ def test_tail_with_folded_compress_out(gpu_vsr_f16, shape, decimate):
         m.fold_tail = True
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(12, 20), (9, 40)])
+def test_prelu_slopes_above_one_and_negative(gpu_vsr_f16, shape):
+    """A trained checkpoint may hold PReLU slopes > 1 or < 0; then max(v, a v) is not PReLU and the kernels switch to
+    their select builds (k_utd3<false,..>, k_tail3<false,..>, k_utd<*,false>, prelu_h2's other branch), which the
+    synthetic weights (slopes in (0.1, 0.3)) never reach (ADVICE r1).  One slope of every kind is moved out of (0, 1];
+    the fp16 path is compared with the oracle on the same weights at the golden-vector bars."""
+    import copy
+    from oracle import vsr_oracle as O
+    m = copy.deepcopy(gpu_vsr_f16.model)
+    b = m.block
+    with torch.no_grad():
+        b.upBlocks[1][1].weight.fill_(1.25)       # live chain lr0 -> hr1
+        b.downtranBlocks[1][1].weight.fill_(-0.15)
+        b.downBlocks[2][1].weight.fill_(1.1)
+        b.upBlocks[4][1].weight.fill_(-0.1)       # second live chain
+        b.uptranBlocks[0][1].weight.fill_(1.5)
+        b.compress_out[1].weight.fill_(1.2)
+        m.out[1].weight.fill_(1.3)
+        b.upBlocks[0][1].weight.fill_(1.4)        # input-independent branch (constant map, exact fp32 kernels)
+    assert not m._packed()["slopes_le_one"]
+    h, w = shape
+    x = torch.from_numpy(np.random.RandomState(h * 31 + w).randint(0, 256, (8, 3, h, w)).astype(np.float32))
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.sr_forward(P, x).numpy()
+    for decimate in (False, True):
+        got = m(x.cuda(), decimate=decimate).cpu().numpy()
+        want = ref[..., ::4, ::4] if decimate else ref
+        assert np.isfinite(got).all()
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err < 2e-3, (decimate, err)
+    m.precision = "fp32"
+    got32 = m(x.cuda()).cpu().numpy()
+    assert np.abs(got32 - ref).max() <= 2e-5 * np.abs(ref).max()
+    # the LDS-ring cross-check builds take the same switch
+    m.precision = "fp16"
+    m.tail_build = 1
+    got1 = m(x.cuda()).cpu().numpy()
+    assert np.abs(got1 - ref).max() / np.abs(ref).max() < 2e-3

@@ -11,6 +11,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3
+# fp16 end-to-end bars (measured on MI355X in round 2)
+# measured: PSNR(255) 63.1 / 63.8 dB, PSNR(signal span) 50.3 / 50.2 dB, p99 0.61 / 0.58, median 0.07 grey levels
+PSNR255_BAR, PSNR_SIGNAL_BAR, P99_BAR = 58.0, 45.0, 1.2
 
 
 def _relerr(a, ref):
@@ -90,7 +93,14 @@ def test_headline_fp16_configuration_end_to_end(golden, gpu_vsr_f16):
     out0, loss = gpu_vsr_f16(data, None, None, None, train=False)
     out1, _ = gpu_vsr_f16(data, None, None, out0, train=False)
     assert loss is None
-    for out, ref in ((out0, g["out0"]), (out1, g["out1"])):
+    for i, (out, ref) in enumerate(((out0, g["out0"]), (out1, g["out1"]))):
         err = np.abs(out.cpu().numpy() - ref)
-        psnr = 10 * np.log10(255.0 ** 2 / float(np.mean(err ** 2)))
-        assert psnr > 50.0 and np.percentile(err, 99) < 2.0, (psnr, np.percentile(err, 99))
+        mse = float(np.mean(err ** 2))
+        psnr = 10 * np.log10(255.0 ** 2 / mse)                       # at the pixel peak
+        span = float(ref.max() - ref.min())
+        psnr_sig = 10 * np.log10(span ** 2 / mse)                    # against the golden frame's own value range
+        p50, p99 = np.percentile(err, 50), np.percentile(err, 99)
+        print(f"[fp16 e2e frame {i}] PSNR(255) {psnr:.2f} dB, PSNR(signal span {span:.1f}) {psnr_sig:.2f} dB, "
+              f"median {p50:.4f}, p99 {p99:.4f}, max {err.max():.3f} grey levels")
+        # bars = measured minus a margin for box-to-box differences in the discrete planes
+        assert psnr > PSNR255_BAR and psnr_sig > PSNR_SIGNAL_BAR and p99 < P99_BAR, (psnr, psnr_sig, p99)

@@ -78,7 +78,38 @@ def optr(t, dtype=torch.float32):
 
 
 def stream() -> ctypes.c_void_p:
+    """The current stream of the CURRENT device: entry points make the tensors' device current first (`on_device`)."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _first_cuda_tensor(objs):
+    for o in objs:
+        if isinstance(o, torch.Tensor):
+            if o.is_cuda:
+                return o
+        elif isinstance(o, (list, tuple)):
+            t = _first_cuda_tensor(o)
+            if t is not None:
+                return t
+    return None
+
+
+def on_device(fn):
+    """Run `fn` with the device of its first CUDA tensor argument made current: kernels are launched on the current
+    device's current stream and the >64 KB LDS attribute is kept per device, so a module living on cuda:1 must not launch
+    while cuda:0 is current.  No-op (no context switch) when that device is current already."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        t = _first_cuda_tensor(args)
+        if t is None:
+            t = _first_cuda_tensor(tuple(kwargs.values()))
+        if t is None or t.device.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(t.device):
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 def cf(v: float) -> ctypes.c_float:

@@ -1219,6 +1219,9 @@ __global__ void __launch_bounds__(256) k_corr_mfma(const _Float16* __restrict__ 
 static int g_splitk_fill = 256;   // split K when a launch has fewer workgroups than this (measured: tools/probe_splitk.py)
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
 
+// byte range a gather kernel's buffer resource and its 32-bit offsets cover (0xFFFFFFFF marks "outside the image")
+static constexpr unsigned long long kGatherLimit = 0xFFFFFFFFull;
+
 extern "C" {
 
 int vsr_conv2d_tuning(int patch_mode) {
@@ -1301,6 +1304,21 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
     VSR_REQUIRE((in_ld & 7) == 0 && (in_coff & 7) == 0 && in_coff + cin <= in_ld, "deconv4s2: input slice");
     VSR_REQUIRE(out_coff >= 0 && out_coff + cout <= out_ld && cout_pad >= cout && (cout_pad & 15) == 0, "deconv4s2: output slice");
     VSR_REQUIRE(act >= 0 && act <= 2, "deconv4s2: activation %d", act);
+    {   // 32-bit input offsets in the gather kernel: sub-batches of whole images beyond 4 GiB (see vsr_conv2d_nhwc_sx_f16)
+        const unsigned long long img_in = (unsigned long long)H * W * in_ld * 2;
+        if (img_in * N >= kGatherLimit) {
+            VSR_REQUIRE(img_in < kGatherLimit, "deconv4s2: one %dx%dx%d fp16 image exceeds the 4 GiB the kernel addresses", H, W, in_ld);
+            const int per = (int)((kGatherLimit - 1) / img_in);
+            for (int n0 = 0; n0 < N; n0 += per) {
+                const int rc = vsr_deconv4s2_nhwc_f16((const _Float16*)in + (size_t)n0 * (img_in / 2), in_ld, in_coff, w_packed4, bias,
+                                                      (_Float16*)out + (size_t)n0 * 4 * H * W * out_ld, out_ld, out_coff,
+                                                      N - n0 < per ? N - n0 : per, H, W, cin, cout, cout_pad, act, slope, splitk_ws,
+                                                      splitk_ws_bytes, stream);
+                if (rc) return rc;
+            }
+            return VSR_OK;
+        }
+    }
     ConvP p;
     p.in = (const _Float16*)in; p.wpk = nullptr; p.bias = bias; p.out = (_Float16*)out;
     p.in_ld = in_ld; p.in_coff = in_coff; p.out_ld = out_ld; p.out_coff = out_coff;
@@ -1356,6 +1374,7 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
     VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && cout > 0 && kh > 0 && kw > 0 && kw <= 8 && stride > 0, "conv2d_stem: bad shape");
     VSR_REQUIRE(out_coff >= 0 && out_coff + cout <= out_ld && cout_pad >= cout && (cout_pad & 15) == 0, "conv2d_stem: output slice");
     VSR_REQUIRE(act >= 0 && act <= 2, "conv2d_stem: activation %d", act);
+    VSR_REQUIRE((unsigned long long)N * H * W * 8 < kGatherLimit, "conv2d_stem: input batch beyond the 4 GiB the kernel addresses");
     const int stride_x = 0;
     ConvP p;
     p.in = (const _Float16*)in4; p.wpk = (const _Float16*)w_packed; p.bias = bias; p.out = (_Float16*)out;
@@ -1404,6 +1423,23 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     VSR_REQUIRE((Ho - 1) * oy_mul + oy_off < outH && (Wo - 1) * ox_mul + ox_off < outW && oy_off >= 0 && ox_off >= 0,
                 "conv2d: output window exceeds the destination tensor");
     VSR_REQUIRE(act >= 0 && act <= 2, "conv2d: activation %d", act);
+    {   // the gather kernels address the whole input batch through one buffer resource with 32-bit byte offsets
+        // (0xFFFFFFFF = "out of image"): a batch beyond that is run as sub-batches of whole images (images are independent)
+        const unsigned long long img_in = (unsigned long long)H * W * in_ld * 2;
+        if (img_in * N >= kGatherLimit) {
+            VSR_REQUIRE(img_in < kGatherLimit, "conv2d: one %dx%dx%d fp16 image exceeds the 4 GiB the kernels address", H, W, in_ld);
+            const int per = (int)((kGatherLimit - 1) / img_in);
+            const size_t img_out = (size_t)outH * outW * out_ld;
+            for (int n0 = 0; n0 < N; n0 += per) {
+                const int rc = vsr_conv2d_nhwc_sx_f16((const _Float16*)in + (size_t)n0 * (img_in / 2), in_ld, in_coff, w_packed, bias,
+                                                      (_Float16*)out + (size_t)n0 * img_out, out_ld, out_coff, N - n0 < per ? N - n0 : per, H, W,
+                                                      cin, Ho, Wo, cout, cout_pad, kh, kw, stride, stride_x, pad_y, pad_x, outH, outW, oy_mul,
+                                                      oy_off, ox_mul, ox_off, act, slope, splitk_ws, splitk_ws_bytes, stream);
+                if (rc) return rc;
+            }
+            return VSR_OK;
+        }
+    }
     ConvP p;
     p.in = (const _Float16*)in; p.wpk = (const _Float16*)w_packed; p.bias = bias; p.out = (_Float16*)out;
     p.in_ld = in_ld; p.in_coff = in_coff; p.out_ld = out_ld; p.out_coff = out_coff;

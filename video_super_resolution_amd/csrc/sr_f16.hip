@@ -1343,12 +1343,12 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
     VSR_REQUIRE(segs <= 65535, "sr_utd: too many row segments");
     typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
     static const kern_t kerns[4] = {k_utd<0, false>, k_utd<0, true>, k_utd<1, false>, k_utd<1, true>};
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
+    if (!vsr::device_marked(attr_devs)) {
         for (kern_t k : kerns)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS) != hipSuccess)
                 return vsr::fail(VSR_E_LAUNCH, "sr_utd: cannot reserve %d bytes of LDS", UTD_LDS);
-        attr_done = true;
+        vsr::mark_device(attr_devs);
     }
     // fused stage: one wave per SIMD (k_utd3, sr_utd3.hip) unless the two-waves-per-SIMD build is selected
     if (!deconv_only && (g_utd_variant == 0 || g_utd_variant == 2 || g_utd_variant == 4))
@@ -1445,12 +1445,12 @@ int vsr_sr_utd2_f16(const void* in, const void* blob_v2, void* out, int N, int h
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0, "sr_utd2: pointers must be 16-byte aligned");
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
     VSR_REQUIRE(segs <= 65535, "sr_utd2: too many row segments");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
+    if (!vsr::device_marked(attr_devs)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_utd2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_utd2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, UTD_LDS) != hipSuccess)
             return vsr::fail(VSR_E_LAUNCH, "sr_utd2: cannot reserve %d bytes of LDS", UTD_LDS);
-        attr_done = true;
+        vsr::mark_device(attr_devs);
     }
     if (slopes_le_one)
         hipLaunchKernelGGL(k_utd2<true>, dim3(strips, segs, N), dim3(512), UTD_LDS, vsr::S(stream), (const _Float16*)in,
@@ -1472,12 +1472,12 @@ static int tail_launch(const void* hid_nhwc, const void* blob, const void* conv_
     VSR_REQUIRE(segs <= 65535, "sr_tail_f16: too many row segments");
     typedef void (*kern_t)(const _Float16*, const unsigned char*, const unsigned char*, const float*, const float*, float*, int, int, int);
     static const kern_t kerns[4] = {k_tail<false, false>, k_tail<true, false>, k_tail<false, true>, k_tail<true, true>};
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
+    if (!vsr::device_marked(attr_devs)) {
         for (kern_t k : kerns)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
                 return vsr::fail(VSR_E_LAUNCH, "sr_tail_f16: cannot reserve %d bytes of LDS", LDS);
-        attr_done = true;
+        vsr::mark_device(attr_devs);
     }
     hipLaunchKernelGGL(kerns[(dec ? 2 : 0) + (slopes_le_one ? 1 : 0)], dim3(strips, segs, N), dim3(512), LDS, vsr::S(stream),
                        (const _Float16*)hid_nhwc, (const unsigned char*)blob, (const unsigned char*)conv_out_frags, tail_params, x,

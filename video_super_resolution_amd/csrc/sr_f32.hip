@@ -86,35 +86,38 @@ __global__ void __launch_bounds__(kBlock) k_conv1x1(const float* __restrict__ in
     for (int k = 0; k < NF; ++k) out[((size_t)n * NF + k) * P + p] = prelu(acc[k], slope);
 }
 
-// ---- ConvTranspose2d(32,32,k8,s4,p2)+PReLU.  HR pixel (Y,X): iy=(Y+2)>>2, py=(Y+2)&3 (same in x);
-//      out = b + sum_{dy,dx in {0,1}} sum_ci in[ci, iy-dy, ix-dx] * W[ci, co, py+4dy, px+4dx].
+// ---- ConvTranspose2d(32,32,K,S,p2)+PReLU, (K,S) = (8,4) the reference's literals | (6,2) | (7,3) (SRFBN's table, see
+//      oracle sr_geometry).  HR pixel (Y,X): iy=(Y+2)/S, py=(Y+2)%S (same in x); T = ceil(K/S) taps per axis:
+//      out = b + sum_{dy,dx < T, py+S*dy < K, ..} sum_ci in[ci, iy-dy, ix-dx] * W[ci, co, py+S*dy, px+S*dx].
 //      wp = weight repacked to [ky][kx][ci][co] so the 32 co of one tap are contiguous and uniform.
-//      Block = one HR row Y (py uniform), lanes = LR column index q, loop over the 4 px phases.
-__global__ void __launch_bounds__(kBlock) k_deconv8s4(const float* __restrict__ in, const float* __restrict__ wp,
-                                                      const float* __restrict__ bias, float slope,
-                                                      float* __restrict__ out, int h, int w) {
+//      Block = one HR row Y (py uniform), lanes = LR column index q, loop over the S px phases.
+template <int K, int S>
+__global__ void __launch_bounds__(kBlock) k_deconv(const float* __restrict__ in, const float* __restrict__ wp,
+                                                   const float* __restrict__ bias, float slope,
+                                                   float* __restrict__ out, int h, int w) {
+    constexpr int T = (K + S - 1) / S;
     const int n = blockIdx.z, Y = blockIdx.y;
-    const int q = blockIdx.x * kBlock + threadIdx.x;  // ix in [0, w]
-    if (q > w) return;
-    const int H = 4 * h, W = 4 * w;
-    const int iy = (Y + 2) >> 2, py = (Y + 2) & 3;
+    const int q = blockIdx.x * kBlock + threadIdx.x;  // ix in [0, w + T - 2]
+    if (q > w + T - 2) return;
+    const int H = S * h, W = S * w;
+    const int iy = (Y + 2) / S, py = (Y + 2) % S;
     const size_t hw = (size_t)h * w, HW = (size_t)H * W;
     const float* ib = in + (size_t)n * NF * hw;
-    for (int px = 0; px < 4; ++px) {
-        const int X = 4 * q + px - 2;
+    for (int px = 0; px < S; ++px) {
+        const int X = S * q + px - 2;
         if (X < 0 || X >= W) continue;
         float acc[NF];
 #pragma unroll
         for (int k = 0; k < NF; ++k) acc[k] = bias[k];
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
+        for (int dy = 0; dy < T; ++dy) {
             const int yy = iy - dy;
-            if (yy < 0 || yy >= h) continue;
+            if (py + S * dy >= K || yy < 0 || yy >= h) continue;
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
+            for (int dx = 0; dx < T; ++dx) {
                 const int xc = q - dx;
-                if (xc < 0 || xc >= w) continue;
-                const float* wt = wp + ((size_t)((py + 4 * dy) * 8 + (px + 4 * dx)) * NF) * NF;
+                if (px + S * dx >= K || xc < 0 || xc >= w) continue;
+                const float* wt = wp + ((size_t)((py + S * dy) * K + (px + S * dx)) * NF) * NF;
                 for (int ci = 0; ci < NF; ++ci) {
                     const float a = ib[(size_t)ci * hw + (size_t)yy * w + xc];
 #pragma unroll
@@ -127,27 +130,28 @@ __global__ void __launch_bounds__(kBlock) k_deconv8s4(const float* __restrict__ 
     }
 }
 
-// ---- Conv2d(32,32,k8,s4,p2)+PReLU: out[co,iy,ix] = b + sum_{ky,kx,ci} in[ci,4iy-2+ky,4ix-2+kx] W[co,ci,ky,kx]
+// ---- Conv2d(32,32,K,S,p2)+PReLU: out[co,iy,ix] = b + sum_{ky,kx,ci} in[ci,S*iy-2+ky,S*ix-2+kx] W[co,ci,ky,kx]
 //      wp = weight repacked to [ky][kx][ci][co].
-__global__ void __launch_bounds__(kBlock) k_conv8s4(const float* __restrict__ in, const float* __restrict__ wp,
-                                                    const float* __restrict__ bias, float slope,
-                                                    float* __restrict__ out, int h, int w) {
+template <int K, int S>
+__global__ void __launch_bounds__(kBlock) k_conv(const float* __restrict__ in, const float* __restrict__ wp,
+                                                 const float* __restrict__ bias, float slope,
+                                                 float* __restrict__ out, int h, int w) {
     const int n = blockIdx.z, iy = blockIdx.y;
     const int ix = blockIdx.x * kBlock + threadIdx.x;
     if (ix >= w) return;
-    const int H = 4 * h, W = 4 * w;
+    const int H = S * h, W = S * w;
     const size_t hw = (size_t)h * w, HW = (size_t)H * W;
     const float* ib = in + (size_t)n * NF * HW;
     float acc[NF];
 #pragma unroll
     for (int k = 0; k < NF; ++k) acc[k] = bias[k];
-    for (int ky = 0; ky < 8; ++ky) {
-        const int Y = 4 * iy - 2 + ky;
+    for (int ky = 0; ky < K; ++ky) {
+        const int Y = S * iy - 2 + ky;
         if (Y < 0 || Y >= H) continue;
-        for (int kx = 0; kx < 8; ++kx) {
-            const int X = 4 * ix - 2 + kx;
+        for (int kx = 0; kx < K; ++kx) {
+            const int X = S * ix - 2 + kx;
             if (X < 0 || X >= W) continue;
-            const float* wt = wp + ((size_t)(ky * 8 + kx) * NF) * NF;
+            const float* wt = wp + ((size_t)(ky * K + kx) * NF) * NF;
             for (int ci = 0; ci < NF; ++ci) {
                 const float a = ib[(size_t)ci * HW + (size_t)Y * W + X];
 #pragma unroll
@@ -159,10 +163,11 @@ __global__ void __launch_bounds__(kBlock) k_conv8s4(const float* __restrict__ in
     for (int k = 0; k < NF; ++k) out[((size_t)n * NF + k) * hw + (size_t)iy * w + ix] = prelu(acc[k], slope);
 }
 
-// bilinear x4, align_corners=False, as ATen's upsample_bilinear2d: src = (dst+0.5)/4-0.5 clamped at 0,
-// i1 = min(i0+1, n-1).
-__device__ __forceinline__ void bil4(int dst, int n, int& i0, int& i1, float& l1) {
-    float src = ((float)dst + 0.5f) * 0.25f - 0.5f;
+// bilinear xS, align_corners=False, as ATen's upsample_bilinear2d: src = (dst+0.5)/S-0.5 clamped at 0,
+// i1 = min(i0+1, n-1).  `inv` = 1/S as ATen forms it (0.25, 0.5 exact; 1/3 rounded once, like `1.0 / scale_factor`
+// cast to float there).
+__device__ __forceinline__ void bil(int dst, int n, float inv, int& i0, int& i1, float& l1) {
+    float src = ((float)dst + 0.5f) * inv - 0.5f;
     if (src < 0.0f) src = 0.0f;
     i0 = (int)src;
     i1 = i0 + (i0 < n - 1 ? 1 : 0);
@@ -174,10 +179,10 @@ __global__ void __launch_bounds__(kBlock) k_tail(const float* __restrict__ hr, c
                                                  const float* __restrict__ b_out, const float* __restrict__ x,
                                                  const float* __restrict__ sub_scale, const float* __restrict__ sub_bias,
                                                  const float* __restrict__ add_scale, const float* __restrict__ add_bias,
-                                                 float* __restrict__ prefc, int h, int w) {
+                                                 float* __restrict__ prefc, int h, int w, int S) {
     const int n = blockIdx.z, Y = blockIdx.y;
     const int X = blockIdx.x * kBlock + threadIdx.x;
-    const int H = 4 * h, W = 4 * w;
+    const int H = S * h, W = S * w;
     if (X >= W) return;
     const size_t hw = (size_t)h * w, HW = (size_t)H * W;
     const float* hb = hr + (size_t)n * NF * HW;
@@ -198,8 +203,9 @@ __global__ void __launch_bounds__(kBlock) k_tail(const float* __restrict__ hr, c
         }
     int y0, y1, x0, x1;
     float ly, lx;
-    bil4(Y, h, y0, y1, ly);
-    bil4(X, w, x0, x1, lx);
+    const float inv = (float)(1.0 / (double)S);
+    bil(Y, h, inv, y0, y1, ly);
+    bil(X, w, inv, x0, x1, lx);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* xp = x + ((size_t)n * 3 + c) * hw;
@@ -256,33 +262,56 @@ int vsr_sr_conv1x1_f32(const float* in0, const float* w0, int ldw0, const float*
     return vsr::launched("sr_conv1x1");
 }
 
+int vsr_sr_deconv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
+                      int h, int w, int scale, vsr_stream_t stream) {
+    VSR_REQUIRE(in && weight_packed && bias && out, "sr_deconv: null pointer");
+    VSR_REQUIRE(scale >= 2 && scale <= 4, "sr_deconv: scale %d (2: k6 s2, 3: k7 s3, 4: k8 s4; padding 2)", scale);
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && (long long)scale * h <= 65535 && N <= 65535, "sr_deconv: bad shape");
+    const dim3 grid(vsr::cdiv(w + 2, kBlock), scale * h, N);
+    if (scale == 4) hipLaunchKernelGGL((k_deconv<8, 4>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
+    else if (scale == 3) hipLaunchKernelGGL((k_deconv<7, 3>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
+    else hipLaunchKernelGGL((k_deconv<6, 2>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
+    return vsr::launched("sr_deconv");
+}
+
+int vsr_sr_conv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
+                    int h, int w, int scale, vsr_stream_t stream) {
+    VSR_REQUIRE(in && weight_packed && bias && out, "sr_conv: null pointer");
+    VSR_REQUIRE(scale >= 2 && scale <= 4, "sr_conv: scale %d (2: k6 s2, 3: k7 s3, 4: k8 s4; padding 2)", scale);
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && h <= 65535 && N <= 65535, "sr_conv: bad shape");
+    const dim3 grid(vsr::cdiv(w, kBlock), h, N);
+    if (scale == 4) hipLaunchKernelGGL((k_conv<8, 4>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
+    else if (scale == 3) hipLaunchKernelGGL((k_conv<7, 3>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
+    else hipLaunchKernelGGL((k_conv<6, 2>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
+    return vsr::launched("sr_conv");
+}
+
 int vsr_sr_deconv8s4_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
                          int h, int w, vsr_stream_t stream) {
-    VSR_REQUIRE(in && weight_packed && bias && out, "sr_deconv8s4: null pointer");
-    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && 4 * h <= 65535 && N <= 65535, "sr_deconv8s4: bad shape");
-    hipLaunchKernelGGL(k_deconv8s4, dim3(vsr::cdiv(w + 1, kBlock), 4 * h, N), dim3(kBlock), 0, vsr::S(stream), in,
-                       weight_packed, bias, slope, out, h, w);
-    return vsr::launched("sr_deconv8s4");
+    return vsr_sr_deconv_f32(in, weight_packed, bias, slope, out, N, h, w, 4, stream);
 }
 
 int vsr_sr_conv8s4_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
                        int h, int w, vsr_stream_t stream) {
-    VSR_REQUIRE(in && weight_packed && bias && out, "sr_conv8s4: null pointer");
-    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && h <= 65535 && N <= 65535, "sr_conv8s4: bad shape");
-    hipLaunchKernelGGL(k_conv8s4, dim3(vsr::cdiv(w, kBlock), h, N), dim3(kBlock), 0, vsr::S(stream), in, weight_packed,
-                       bias, slope, out, h, w);
-    return vsr::launched("sr_conv8s4");
+    return vsr_sr_conv_f32(in, weight_packed, bias, slope, out, N, h, w, 4, stream);
+}
+
+int vsr_sr_tail_scale_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
+                          const float* sub_bias3, const float* add_scale3, const float* add_bias3, float* prefc, int N, int h,
+                          int w, int scale, vsr_stream_t stream) {
+    VSR_REQUIRE(hr && w_out && b_out && x && sub_scale3 && sub_bias3 && add_scale3 && add_bias3 && prefc,
+                "sr_tail: null pointer");
+    VSR_REQUIRE(scale >= 2 && scale <= 4, "sr_tail: scale %d", scale);
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && (long long)scale * h <= 65535 && N <= 65535, "sr_tail: bad shape");
+    hipLaunchKernelGGL(k_tail, dim3(vsr::cdiv((long long)scale * w, kBlock), scale * h, N), dim3(kBlock), 0, vsr::S(stream), hr, w_out,
+                       b_out, x, sub_scale3, sub_bias3, add_scale3, add_bias3, prefc, h, w, scale);
+    return vsr::launched("sr_tail");
 }
 
 int vsr_sr_tail_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
                     const float* sub_bias3, const float* add_scale3, const float* add_bias3, float* prefc, int N, int h,
                     int w, vsr_stream_t stream) {
-    VSR_REQUIRE(hr && w_out && b_out && x && sub_scale3 && sub_bias3 && add_scale3 && add_bias3 && prefc,
-                "sr_tail: null pointer");
-    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && 4 * h <= 65535 && N <= 65535, "sr_tail: bad shape");
-    hipLaunchKernelGGL(k_tail, dim3(vsr::cdiv(4 * w, kBlock), 4 * h, N), dim3(kBlock), 0, vsr::S(stream), hr, w_out,
-                       b_out, x, sub_scale3, sub_bias3, add_scale3, add_bias3, prefc, h, w);
-    return vsr::launched("sr_tail");
+    return vsr_sr_tail_scale_f32(hr, w_out, b_out, x, sub_scale3, sub_bias3, add_scale3, add_bias3, prefc, N, h, w, 4, stream);
 }
 
 int vsr_sr_fc_fuse_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,

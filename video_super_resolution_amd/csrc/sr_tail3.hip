@@ -413,12 +413,12 @@ int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags
     static const kern_t kerns[8] = {k_tail3<false, false, false>, k_tail3<true, false, false>, k_tail3<false, true, false>,
                                     k_tail3<true, true, false>,   k_tail3<false, false, true>, k_tail3<true, false, true>,
                                     k_tail3<false, true, true>,   k_tail3<true, true, true>};
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
+    if (!vsr::device_marked(attr_devs)) {
         for (kern_t k : kerns)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS) != hipSuccess)
                 return vsr::fail(VSR_E_LAUNCH, "sr_tail3: cannot reserve %d bytes of LDS", T3_LDS);
-        attr_done = true;
+        vsr::mark_device(attr_devs);
     }
     if ((size_t)N * h * w * NF * 2 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail3: input beyond 2 GiB");
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);

@@ -475,12 +475,12 @@ int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w
                 int diag, hipStream_t stream) {
     typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
     static const kern_t kerns[4] = {k_utd3<false, 0>, k_utd3<true, 0>, k_utd3<true, 1>, k_utd3<true, 2>};
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
+    if (!vsr::device_marked(attr_devs)) {
         for (kern_t k : kerns)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, UTD3_LDS) != hipSuccess)
                 return vsr::fail(VSR_E_LAUNCH, "sr_utd3: cannot reserve %d bytes of LDS", UTD3_LDS);
-        attr_done = true;
+        vsr::mark_device(attr_devs);
     }
     if ((size_t)N * h * w * NF * 2 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_utd3: tensors beyond 2 GiB");
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);

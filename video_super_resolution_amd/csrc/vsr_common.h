@@ -32,6 +32,16 @@ inline hipStream_t S(vsr_stream_t s) { return reinterpret_cast<hipStream_t>(s); 
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+// hipFuncSetAttribute (dynamic LDS beyond 64 KB) holds per DEVICE: a launcher keeps one bit per device ordinal and
+// sets the attribute again the first time it runs with another device current.
+inline int current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 63;
+}
+inline bool device_marked(unsigned long long mask) { return (mask >> current_device()) & 1ull; }
+inline void mark_device(unsigned long long& mask) { mask |= 1ull << current_device(); }
+
 }  // namespace vsr
 
 #define VSR_REQUIRE(cond, ...) \

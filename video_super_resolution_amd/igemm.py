@@ -15,6 +15,7 @@ import ctypes
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 _WS_BYTES = 64 << 20
+_MAX_SHAPES = 4   # cached_zeros: shapes kept per (owner, tag, device, stream)
 _ws = {}
 
 
@@ -46,9 +47,16 @@ def cached_zeros(owner, tag, shape, device) -> torch.Tensor:
     every owner produces one such tensor per executor call and its consumers run before the owner's next call."""
     d = owner.__dict__.setdefault("_bufs", {})
     k = (tag, tuple(shape), device.index, torch.cuda.current_stream(device).cuda_stream)
-    t = d.get(k)
+    t = d.pop(k, None)
     if t is None:
-        t = d[k] = torch.zeros(shape, dtype=torch.float16, device=device)
+        # bounded: a frame alternates between at most a few shapes per owner (batch of 4 / batch of 1, pass 1 / pass 2);
+        # beyond _MAX_SHAPES the least recently used shape of this (tag, device, stream) is dropped, so a service that
+        # sees many resolutions does not accumulate one buffer set per resolution
+        same = [q for q in d if (q[0], q[2], q[3]) == (k[0], k[2], k[3])]
+        for q in same[:max(0, len(same) - (_MAX_SHAPES - 1))]:
+            del d[q]
+        t = torch.zeros(shape, dtype=torch.float16, device=device)
+    d[k] = t   # (re)insert at the end: the dict's order is the recency order
     return t
 
 

@@ -20,6 +20,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+@L.on_device
 def resample2d(img: torch.Tensor, flow: torch.Tensor, kernel_size: int = 1, bilinear: bool = True) -> torch.Tensor:
     """out[b,c,y,x] = bilinear(img[b,c], x + flow[b,0,y,x], y + flow[b,1,y,x]); indices clamped independently."""
     img, flow = _f32c(img), _f32c(flow)
@@ -33,6 +34,7 @@ def resample2d(img: torch.Tensor, flow: torch.Tensor, kernel_size: int = 1, bili
     return out
 
 
+@L.on_device
 def channelnorm(x: torch.Tensor) -> torch.Tensor:
     x = _f32c(x)
     B, C, H, W = x.shape
@@ -48,6 +50,7 @@ def correlation_out_shape(H, W, pad_size, kernel_size, max_displacement, stride1
     return oc.value, oh.value, ow.value
 
 
+@L.on_device
 def correlation(f1: torch.Tensor, f2: torch.Tensor, pad_size=20, kernel_size=1, max_displacement=20, stride1=1,
                 stride2=2, corr_multiply=1) -> torch.Tensor:
     f1, f2 = _f32c(f1), _f32c(f2)
@@ -61,6 +64,7 @@ def correlation(f1: torch.Tensor, f2: torch.Tensor, pad_size=20, kernel_size=1, 
     return out
 
 
+@L.on_device
 def warp_concat(x6: torch.Tensor, flow: torch.Tensor, div_flow: float) -> torch.Tensor:
     """cat(x6, warp(x6[:,3:], flow), flow/div_flow, |x6[:,:3]-warp|) in one kernel (models.py:86-91,98-103)."""
     x6, flow = _f32c(x6), _f32c(flow)
@@ -73,6 +77,7 @@ def warp_concat(x6: torch.Tensor, flow: torch.Tensor, div_flow: float) -> torch.
     return out
 
 
+@L.on_device
 def warp_norms(x6: torch.Tensor, flow: torch.Tensor):
     """(|flow|, |x6[:,:3] - warp(x6[:,3:], flow)|) without materialising the warp (models.py:107-112,116-121)."""
     x6, flow = _f32c(x6), _f32c(flow)
@@ -86,6 +91,7 @@ def warp_norms(x6: torch.Tensor, flow: torch.Tensor):
     return nf, nd
 
 
+@L.on_device
 def flow2img(flow_2hw: torch.Tensor) -> torch.Tensor:
     """[2,h,w] float32 flow -> [h,w,3] float32 picture of uint8 values (utils/flow_utils.py:4-62), no host trip."""
     flow = _f32c(flow_2hw)

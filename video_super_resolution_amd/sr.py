@@ -258,6 +258,7 @@ class SRProjectionModule(nn.Module):
         return cmap
 
     # ------------------------------------------------------------------ forward
+    @L.on_device
     @torch.no_grad()
     def forward(self, x: torch.Tensor, taps: Optional[dict] = None, decimate: bool = False) -> torch.Tensor:
         """[8,3,h,w] planes -> [1,3,4h,4w].  decimate=True returns only the pixels (4i, 4j) as [1,3,h,w] -- what a

@@ -184,6 +184,7 @@ class HourglassExec:
             return x, coff, c
         raise ValueError(node)
 
+    @L.on_device
     @torch.no_grad()
     def __call__(self, frames_nhwc3: torch.Tensor) -> torch.Tensor:
         """[k,h,w,3] float frames -> [k,1,h,w] float depth predictions."""
@@ -377,6 +378,7 @@ class FlowNet2Exec:
     def _flow_nchw(t):  # [B,h,w,>=2] half -> [B,2,h,w] float
         return t[..., :2].permute(0, 3, 1, 2).float()
 
+    @L.on_device
     @torch.no_grad()
     def __call__(self, inputs):
         """inputs [B,3,2,H,W] (0..255) -> flow [B,2,H,W] float32; mirrors flownet.FlowNet2.forward."""
@@ -438,6 +440,7 @@ class OSVOSExec:
                      for b, m in enumerate(net.upscale)]
         self.fuse_b = float(net.fuse.bias.detach())
 
+    @L.on_device
     @torch.no_grad()
     def __call__(self, x_nchw):
         """[2,3,h,w] mean-subtracted frames -> fused logit [2,1,h,w] float32."""

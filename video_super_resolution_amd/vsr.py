@@ -34,6 +34,7 @@ from .flownet import FlowProjectionModule
 from .sr import SRProjectionModule
 from .trunk_exec import FlowNet2Exec, HourglassExec, OSVOSExec, TrunkExecCache
 from .vos import VOSProjectionModule
+from ._lib import on_device as _on_device
 
 
 def maskprocess(mask: torch.Tensor) -> torch.Tensor:
@@ -88,7 +89,7 @@ class VSR(nn.Module):
         (joined before the 8-plane assembly).  `extra_depth`: frames whose depth is wanted later (batched now)."""
         h, w = trip[0].shape[:2]
         fast = self._fast()
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(trip[0].device)
         s_depth, s_vos = self._side_streams(trip[0].device) if fast else (main, main)
         if fast:
             s_depth.wait_stream(main)
@@ -125,6 +126,7 @@ class VSR(nn.Module):
                              maskprocess(self.DepthModule.combine(z[1], z[2]))])
         return pics, depth, mask
 
+    @_on_device
     def forward(self, data, target, high_frames, estimated_image, train=True):
         if data.dim() != 4 or data.shape[0] != 3 or data.shape[3] != 3:
             raise ValueError(f"data must be [3,h,w,3], got {tuple(data.shape)}")
