@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- HR frames/s of the per-frame video-SR forward (`VSR.forward`, train=False) on MI355X.
 
-Workload (BASELINE.json headline config, SURVEY.md 8(d) reading C3-A): synthetic clips of LR 540x960 frames,
-x4 -> 2160x3840 HR frames, 3-frame window + recurrent estimate, seeded synthetic weights.  One "step" = one
-VSR.forward call per rank (one output frame of that rank's clip); inputs are resident in HBM before the timed
-region; `value` = frames produced by all ranks / max-over-ranks wall time.  Ranks own independent clips (weak
+Default workload = BASELINE.json's headline config, SURVEY.md 8(d) reading C3-A: synthetic clips of LR 540x960 frames,
+x4 -> 2160x3840 HR frames, 3-frame window + recurrent estimate, seeded synthetic weights, fp16 storage / fp32 accumulate.
+One "step" = one VSR.forward call per rank (one output frame of that rank's clip); inputs are resident in HBM before the
+timed region; `value` = frames produced by all ranks / max-over-ranks wall time.  Ranks own independent clips (weak
 scaling, no data-path collective); the finished frames are gathered to rank 0 inside the timed region.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py                                   # C3-A on one GPU
+    python bench.py --config C2|C3B|C5                # the x2 configurations of BASELINE.json (scale extension)
+    python bench.py --precision fp32                  # C3-A in exact float32
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W [--clips 32]      # C4: 32 clips round-robin, per-clip gathers
+
+--config   LR -> HR                scale  precision  (BASELINE.json `configs`)
+  C3A      540x960  -> 2160x3840    x4     fp16      headline, reference-native geometry (parity-pinned)
+  C3B      1080x1920 -> 2160x3840   x2     fp16      label-faithful "1080p -> 4K" input size
+  C2       540x960  -> 1080x1920    x2     fp32
+  C5       2160x3840 -> 4320x7680   x2     fp16      depth + VOS guidance (always on), HBM stress
+  (C1, the 128x128 CPU plumbing case, is `python -m video_super_resolution_amd.driver`; C4 = C3A with --clips 32 --gpus 8)
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -36,6 +46,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector == fp32-input MFMA peak
 FP16_MFMA_PEAK_TFLOPS = 2500.0  # dense
 
+CONFIGS = {   # name: (LR h, LR w, scale, precision, label)
+    "C3A": (540, 960, 4, "fp16", "C3-A: LR 540x960 x4 -> 2160x3840"),
+    "C3B": (1080, 1920, 2, "fp16", "C3-B: LR 1080x1920 x2 -> 2160x3840 (scale extension)"),
+    "C2": (540, 960, 2, "fp32", "C2: LR 540x960 x2 -> 1080x1920 (scale extension)"),
+    "C5": (2160, 3840, 2, "fp16", "C5: LR 2160x3840 x2 -> 4320x7680 with depth + VOS guidance (scale extension)"),
+}
+
+# FLOPs per LR pixel per plane ACTUALLY executed by the SR net (SURVEY.md App. C "F_min": zero-fill dataflow, constant
+# branches cached, dead tails skipped): head 15,104 + 3 steps x (compress_in 4,096 + compress_out 12,288 +
+# 2 x [uptran slice 2,048 + dc + downtran slice 2,048 s^2 + dc]) + last tail (dc + 1,728 s^2), dc = 2*32*32*k^2/... per LR px
+SR_FLOP_PER_PX = {4: 2004736.0, 2: 1091072.0, 3: 1507264.0}
+STAGE_FLOP_PER_PX = {4: 294912.0, 2: 155648.0, 3: 219136.0}     # one up -> tran -> down stage: dc + 2,048 s^2 + dc
+TRUNK_FLOP_PER_PX = dict(flownet2=1.008e6, hourglass=1.227e6, osvos=0.637e6)   # SURVEY.md 6 (FlopCounterMode)
+
 
 def synthetic_clip(clip_id: int, n_frames: int, h: int, w: int) -> np.ndarray:
     """Distribution 'S' of SURVEY.md 8(d): blurred noise scene translated by (2k, k) px per frame, 0..255."""
@@ -49,28 +73,66 @@ def synthetic_clip(clip_id: int, n_frames: int, h: int, w: int) -> np.ndarray:
     return np.stack(frames).astype(np.float32)
 
 
-def cpu_baseline(seconds_budget: float = 25.0):
-    """The oracle (CPU restatement of the same forward) timed on this box's host cores on a bounded sample."""
+def executed_flop_per_frame(h, w, scale):
+    """FLOPs one VSR.forward executes in this implementation: 2 SR calls x 8 planes (F_min) + 4 FlowNet2 runs on the
+    64-aligned crop + 5 hourglass runs (f0, f1, f2, estimate, pass-1 frame: the reference's 8 runs have 4-5 distinct
+    inputs) + 2 OSVOS runs."""
+    crop = (h // 64) * 64 * ((w // 64) * 64)
+    sr = 2 * 8 * h * w * SR_FLOP_PER_PX[scale]
+    trunks = 4 * crop * TRUNK_FLOP_PER_PX["flownet2"] + 5 * h * w * TRUNK_FLOP_PER_PX["hourglass"] + \
+        2 * h * w * TRUNK_FLOP_PER_PX["osvos"]
+    return sr + trunks
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(scale: int, sizes=(64, 96, 128), budget_s: float = 75.0):
+    """The oracle (CPU restatement of the same forward) timed on this box's host cores at LR 64^2, 96^2, 128^2 (one frame
+    each); a least-squares line seconds = a + b * pixels gives the extrapolated headline-size figure.
+    Larger tiles are skipped once the budget is spent (the fit then uses the points measured)."""
     from oracle import vsr_oracle
     from video_super_resolution_amd import VSR
     from video_super_resolution_amd.weights import fill_module_
-    # the GPU box gives one job a CPU share of 16 cores whatever os.cpu_count() says: never oversubscribe
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(16, cores))
+    avail = host_cores()
+    cores = max(1, min(16, avail))   # a gpurun job's CPU share is 16 cores whatever the affinity mask says
     torch.set_num_threads(cores)
     torch.set_flush_denormal(True)
-    m = fill_module_(VSR().eval(), seed=0)
+    m = fill_module_(VSR(upscale_factor=scale).eval(), seed=0)
     P = {k: v.detach() for k, v in m.state_dict().items()}
-    lr = 64
-    data = torch.from_numpy(synthetic_clip(0, 3, lr, lr))
-    t0 = time.time()
-    with torch.no_grad():
-        vsr_oracle.vsr_forward(P, data, None)
-    dt = time.time() - t0
-    return dict(seconds=dt, lr_px=lr * lr, cores=cores, sample=f"1 frame of VSR.forward at LR {lr}x{lr} (x4 -> {4*lr}x{4*lr})")
+    pts = []
+    t_start = time.time()
+    for lr in sizes:
+        if pts and (time.time() - t_start) + pts[-1][1] * (lr * lr) / pts[-1][0] > budget_s:   # next tile ~ linear in pixels
+            break
+        data = torch.from_numpy(synthetic_clip(0, 3, lr, lr))
+        t0 = time.time()
+        with torch.no_grad():
+            vsr_oracle.vsr_forward(P, data, None, upscale_factor=scale)
+        pts.append((lr * lr, time.time() - t0))
+    px = np.array([p[0] for p in pts], dtype=np.float64)
+    sec = np.array([p[1] for p in pts], dtype=np.float64)
+    if len(pts) >= 2:
+        b, a = np.polyfit(px, sec, 1)
+    else:
+        b, a = sec[0] / px[0], 0.0
+    return dict(points=[(int(p), round(float(s), 2)) for p, s in pts], slope_s_per_px=float(b), intercept_s=float(a),
+                cores=cores, cores_available=avail, cpu=cpu_model())
 
 
 def main():
@@ -78,12 +140,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--lr-h", type=int, default=540)
-    ap.add_argument("--lr-w", type=int, default=960)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"],
+    ap.add_argument("--config", default="C3A", choices=sorted(CONFIGS), help="BASELINE.json configuration (default: headline C3-A)")
+    ap.add_argument("--lr-h", type=int, default=None)
+    ap.add_argument("--lr-w", type=int, default=None)
+    ap.add_argument("--scale", type=int, default=None, choices=[2, 3, 4])
+    ap.add_argument("--precision", default=None, choices=["fp16", "fp32"],
                     help="SR stack: fp16 storage + fp32 accumulate on MFMA (headline config) or exact fp32")
+    ap.add_argument("--clips", type=int, default=0,
+                    help="config C4: this many independent clips round-robin over the ranks (clip i -> rank i mod N), `steps` "
+                         "frames each, one asynchronous gather per finished clip; 0 = one clip per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    h, w, scale, precision, label = CONFIGS[args.config]
+    h, w = args.lr_h or h, args.lr_w or w
+    scale = args.scale or scale
+    precision = args.precision or precision
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -99,101 +171,156 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from video_super_resolution_amd import VSR, _lib
-    from video_super_resolution_amd.distributed import gather_frames
+    from video_super_resolution_amd.distributed import clips_of_rank, gather_frames, run_sharded_clips
     from video_super_resolution_amd.weights import fill_module_
 
-    h, w = args.lr_h, args.lr_w
-    model = fill_module_(VSR().eval(), seed=0).to(dev)
-    model.precision = model.model.precision = args.precision
+    model = fill_module_(VSR(upscale_factor=scale).eval(), seed=0).to(dev)
+    model.precision = model.model.precision = precision
+    H, W = scale * h, scale * w
+    n_clips = args.clips if args.clips > 0 else world
+    if n_clips < world:
+        raise SystemExit("--clips must be at least the number of ranks")
+    my_clips = clips_of_rank(n_clips, rank, world)
     n_frames = args.steps + args.warmup + 2
-    clip = torch.from_numpy(synthetic_clip(rank, n_frames, h, w)).to(dev)  # resident in HBM before timing
-    hf = torch.zeros((3, 4 * h, 4 * w, 3), dtype=torch.float32, device=dev)
+    # every clip of this rank resident in HBM before timing (a [K+W+2, h, w, 3] f32 clip is 50 MB at 540x960)
+    clips = {c: torch.from_numpy(synthetic_clip(c, n_frames, h, w)).to(dev) for c in my_clips}
+    hf = torch.zeros((3, H, W, 3), dtype=torch.float32, device=dev)
 
     def progress(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    progress(f"model and clip resident on {torch.cuda.get_device_name(dev)}; warm-up")
-    est = None
-    finished = torch.empty((args.steps, 4 * h, 4 * w, 3), dtype=torch.float16, device=dev)  # output frames of the timed steps
+    progress(f"{label}, {precision}; model and {len(my_clips)} clip(s) resident on {torch.cuda.get_device_name(dev)}; warm-up")
+    first = clips[my_clips[0]]
+    dom_names = {"sr_utd_f16"} if (precision == "fp16" and scale == 4) else \
+        ({"sr_stage_up", "sr_stage_dt", "sr_stage_dn"} if precision == "fp16" else
+         {"sr_conv8s4_f32", "sr_deconv8s4_f32", "sr_conv_f32", "sr_deconv_f32"})
     with torch.no_grad():
         # initialisation, not a step: both entry paths of forward (no estimate yet / recurrent estimate) run once so that
         # weight packing, executor construction and the caching allocator's first-touch hipMallocs are outside the clock
         prime = None
         for _ in range(2):
-            prime, _ = model(clip[0:3], None, hf, prime, train=False)
+            prime, _ = model(first[0:3], None, hf, prime, train=False)
         del prime
         torch.cuda.synchronize()
+        est = None
         for t in range(args.warmup):
-            est, _ = model(clip[t:t + 3], None, hf, est, train=False)
+            est, _ = model(first[t:t + 3], None, hf, est, train=False)
             torch.cuda.synchronize()
             progress(f"warm-up frame {t} done")
+        warm_est = est
+
+        def forward_clip(cid):
+            """`steps` recurrent frames of clip `cid` -> [K, H, W, 3] fp16 (pixel values 0..255-ish)."""
+            clip = clips[cid]
+            out = torch.empty((args.steps, H, W, 3), dtype=torch.float16, device=dev)
+            e = warm_est if cid == my_clips[0] else None   # the first clip continues from its warm-up frames
+            for i, t in enumerate(range(args.warmup, args.warmup + args.steps)):
+                e, _ = model(clip[t:t + 3], None, hf, e, train=False)
+                out[i].copy_(e[0])
+            return out
+
         if world > 1:
             dist.barrier()
-        # HIP events around the dominant kernel's launches only (the fused up->tran->down stage; the exact-fp32
-        # configuration's counterpart is the k8 s4 conv / deconv pair): ~12 event pairs per frame, not one per launch
+        # HIP events around the dominant kernel's launches only (SURVEY 8(d)): ~12 event pairs per frame, not one per launch
         _lib.TIMER.reset()
-        _lib.TIMER.only = {"sr_utd_f16"} if args.precision == "fp16" else {"sr_conv8s4_f32", "sr_deconv8s4_f32"}
+        _lib.TIMER.only = dom_names
         _lib.TIMER.enabled = True
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i, t in enumerate(range(args.warmup, args.warmup + args.steps)):
-            est, _ = model(clip[t:t + 3], None, hf, est, train=False)
-            finished[i].copy_(est[0])  # [K,4h,4w,3] fp16 (values are 0..255-ish pixels)
-        gathered = gather_frames(finished, dst=0)
+        if args.clips > 0:
+            gathered, ran = run_sharded_clips(forward_clip, n_clips, rank, world, dst=0)   # [n_clips, K, H, W, 3] on rank 0
+            total_frames = n_clips * args.steps
+        else:
+            finished = forward_clip(my_clips[0])
+            g = gather_frames(finished, dst=0)
+            gathered = torch.stack(g) if g is not None else None
+            ran = 1
+            total_frames = world * args.steps
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         _lib.TIMER.enabled = False
         _lib.TIMER.only = None
-        progress(f"timed region: {elapsed:.3f} s for {args.steps} steps")
+        progress(f"timed region: {elapsed:.3f} s for {args.steps} steps x {ran} clip(s) on this rank")
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     if rank == 0:
-        assert gathered is not None and sum(g.shape[0] for g in gathered) == world * args.steps
-        assert torch.isfinite(finished.float()).all()
+        assert gathered is not None and gathered.shape[0] * gathered.shape[1] == total_frames
+        assert torch.isfinite(gathered[0].float()).all() and torch.isfinite(gathered[-1].float()).all()
 
     if rank == 0:
-        fps = world * args.steps / elapsed
+        fps = total_frames / elapsed
+        calls_per_rank = ran * args.steps
+        ms_per_frame = 1e3 * elapsed / calls_per_rank
         # ---- roofline of the dominant kernel, timed with HIP events inside the timed region
         timers = _lib.TIMER.summary()
         dom = max(timers.items(), key=lambda kv: kv[1][0] * kv[1][1]) if timers else None
         roof = None
         if dom is not None:
             name, (launches, ms) = dom
-            # algorithmic FLOPs per launch (per LR pixel per image, 8 images per launch):
-            #   one k8 s4 (de)conv 32->32 = 131,072; the fused up->tran->down stage = 131,072 + 16*2,048 + 131,072
-            per_px = 294912.0 if name == "sr_utd_f16" else 131072.0
-            peak = FP16_MFMA_PEAK_TFLOPS if name.startswith("sr_utd_f16") else FP32_PEAK_TFLOPS
-            flop = 8 * h * w * per_px
-            achieved = flop / (ms * 1e-3) / 1e12
-            # HBM bytes per launch of this kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-            # separate passes, gfx950 correction applied; profiles/r01_k_utd3_pmc.json) -- same launch geometry only
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_k_utd3_pmc.json")
-            if name == "sr_utd_f16" and (h, w) == (540, 960) and os.path.exists(pmc):
-                with open(pmc) as f:
-                    traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"]
-            roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
-                        frac=round(achieved / peak, 4), traffic=traffic, launches_timed=launches, avg_ms=round(ms, 4),
-                        algorithmic_flop_per_launch=flop)
-        line = dict(metric="HR frames/sec, 1080p->4K x4 VSR (LR 540x960 -> 2160x3840), VSR.forward end-to-end",
+            traffic, traffic_source = None, None
+            if name == "sr_utd_f16":
+                # algorithmic FLOPs per launch (SURVEY.md App. C): the fused up -> tran -> down stage, 8 planes per launch
+                flop = 8 * h * w * STAGE_FLOP_PER_PX[4]
+                achieved = flop / (ms * 1e-3) / 1e12
+                # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+                # gfx950 correction applied) -- a committed measurement of the same launch geometry, not taken in this run
+                for pmc in ("r02_k_utd3_pmc.json", "r01_k_utd3_pmc.json"):
+                    path = os.path.join(ROOT, "profiles", pmc)
+                    if (h, w) == (540, 960) and os.path.exists(path):
+                        with open(path) as f:
+                            traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"]
+                        traffic_source = f"profiles/{pmc} (rocprofv3 --pmc, separate run of the same launch geometry)"
+                        break
+                roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=FP16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(achieved / FP16_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
+                            launches_timed=launches, avg_ms=round(ms, 4), algorithmic_flop_per_launch=flop)
+            elif name.startswith("sr_stage_"):
+                # unfused x2 stage (scale extension): each of its three launches is an HBM pass over the HR map.
+                # algorithmic bytes per LR pixel and plane (fp16, 32 ch = 64 B per pixel): up 64 in + 64 s^2 out;
+                # dt 64 s^2 in + 64 s^2 out; dn 64 s^2 in + 64 out.  A launch covers `planes` planes (chunked below 2 GiB).
+                from video_super_resolution_amd.sr import _planes_per_chunk
+                planes = _planes_per_chunk(8, scale * h, scale * w)
+                per_px = {"sr_stage_up": 64 + 64 * scale ** 2, "sr_stage_dt": 128 * scale ** 2, "sr_stage_dn": 64 * scale ** 2 + 64}[name]
+                nbytes = planes * h * w * per_px
+                achieved = nbytes / (ms * 1e-3) / 1e9
+                roof = dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, traffic_source=None, launches_timed=launches,
+                            avg_ms=round(ms, 4), algorithmic_bytes_per_launch=nbytes, planes_per_launch=planes)
+            else:
+                flop = 8 * h * w * (STAGE_FLOP_PER_PX[scale] - 2048 * scale ** 2) / 2    # one k x k (de)conv, 8 planes
+                achieved = flop / (ms * 1e-3) / 1e12
+                roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(achieved / FP32_PEAK_TFLOPS, 4), traffic=None, traffic_source=None, launches_timed=launches,
+                            avg_ms=round(ms, 4), algorithmic_flop_per_launch=flop)
+            # the whole frame against the same peak: FLOPs this implementation executes per forward / wall time per forward
+            peak = FP16_MFMA_PEAK_TFLOPS if precision == "fp16" else FP32_PEAK_TFLOPS
+            exe = executed_flop_per_frame(h, w, scale)
+            roof["whole_frame"] = dict(executed_flop_per_frame=exe, achieved_tflops=round(exe / (ms_per_frame * 1e-3) / 1e12, 2),
+                                       frac_of_peak=round(exe / (ms_per_frame * 1e-3) / 1e12 / peak, 4), peak_tflops=peak)
+        line = dict(metric=f"HR frames/sec, 1080p->4K x4 VSR (LR {h}x{w} -> {H}x{W}), VSR.forward end-to-end" if args.config == "C3A" and scale == 4
+                    else f"HR frames/sec, VSR.forward end-to-end (LR {h}x{w} x{scale} -> {H}x{W})",
                     value=round(fps, 4), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                    ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="weak",
-                    vs_baseline=None, dtype="f32" if args.precision == "fp32" else "f16", data="synthetic",
-                    config=dict(workload=f"C3-A: LR {h}x{w} x4 -> {4*h}x{4*w}, 3-frame window + recurrent estimate, "
-                                         f"one clip per GPU, seeded synthetic weights", precision=args.precision,
-                                parallelism=f"clip-dp{world}"),
+                    ms_per_step=round(ms_per_frame, 3), higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype="f32" if precision == "fp32" else "f16", data="synthetic",
+                    config=dict(workload=f"{label if (h, w, scale) == CONFIGS[args.config][:3] else f'LR {h}x{w} x{scale}'}, 3-frame window "
+                                         f"+ recurrent estimate, {n_clips} clip(s) over {world} GPU(s), seeded synthetic weights",
+                                precision=precision, parallelism=f"clip-dp{world}", clips=n_clips, scale=scale),
                     roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
-            progress("timing the CPU oracle on a 64x64 LR tile (about half a minute)")
-            cb = cpu_baseline()
-            px_per_s = cb["lr_px"] / cb["seconds"]
-            line["cpu_baseline"] = dict(value=round(px_per_s / (h * w), 8), unit="frames/s", cores=cb["cores"], kind="port",
-                                        sample=cb["sample"] + f", {cb['seconds']:.1f} s; scaled linearly in pixels to "
-                                                              f"LR {h}x{w} (extrapolated)")
+            progress("timing the CPU oracle on LR 64x64 / 96x96 / 128x128 tiles (about a minute)")
+            cb = cpu_baseline(scale)
+            sec_full = cb["intercept_s"] + cb["slope_s_per_px"] * h * w
+            pts = ", ".join(f"{int(p ** 0.5)}x{int(p ** 0.5)}: {s} s" for p, s in cb["points"])
+            line["cpu_baseline"] = dict(value=round(1.0 / sec_full, 8), unit="frames/s", cores=cb["cores"], kind="port",
+                                        cores_available=cb["cores_available"], cpu=cb["cpu"], points=cb["points"],
+                                        sample=f"1 frame of VSR.forward (the oracle, x{scale}) at LR {pts}; least-squares line "
+                                               f"{cb['intercept_s']:.2f} s + {cb['slope_s_per_px'] * 1e3:.4f} ms/px evaluated at "
+                                               f"LR {h}x{w} = {sec_full:.0f} s per frame (extrapolated)")
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

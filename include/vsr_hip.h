@@ -111,6 +111,19 @@ int vsr_sr_deconv8s4_f32(const float* in, const float* weight_packed, const floa
 int vsr_sr_conv8s4_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
                        int h, int w, vsr_stream_t stream);
 
+/* The same two blocks for the other rows of SRFBN's (kernel, stride) table: scale 4 = (8,4) the reference's literals
+ * (SRProjectionModule.py:10-12,101-103), 3 = (7,3), 2 = (6,2); padding 2 in all.  This is the "scale-2 extension" of
+ * SURVEY.md 7-1 / 8(d) (configs C1/C2/C3-B/C5 are labelled x2); the reference itself crashes for upscale_factor != 4.
+ * in [N,32,h,w] <-> [N,32,scale*h,scale*w]; weight_packed [ky][kx][in][out] as above with K x K taps. */
+int vsr_sr_deconv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
+                      int h, int w, int scale, vsr_stream_t stream);
+int vsr_sr_conv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
+                    int h, int w, int scale, vsr_stream_t stream);
+/* vsr_sr_tail_f32 with the skip's bilinear factor (= upscale_factor, :136) as a parameter. */
+int vsr_sr_tail_scale_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
+                          const float* sub_bias3, const float* add_scale3, const float* add_bias3, float* prefc, int N,
+                          int h, int w, int scale, vsr_stream_t stream);
+
 /* conv_out 3x3 (32->3, no activation) + bilinear x4 skip of sub_mean(x) + add_mean (:136,:142-143).
  * hr [N,32,4h,4w] (output of the `out` DeconvBlock), x [N,3,h,w] -> prefc [N,3,4h,4w]. */
 int vsr_sr_tail_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
@@ -228,6 +241,16 @@ int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tai
                               const float* w2, const float* b2, int nplanes, int hidden, float* out, int h, int w, int decimate,
                               vsr_stream_t stream);
 
+/* Tail of the fp16 path for upscale factors other than the reference's x4 (scale extension, see vsr_sr_deconv_f32):
+ * conv_out 3x3 (32->3, :121-123,142) over the `out` DeconvBlock's HR map [N,H,W,32] fp16 -> raw planes [N,3,Ho,Wo] fp32
+ * at the pixels (step*i, step*j) (step = 1: all; step = scale: what the nearest x1/scale resize of pass 1 reads). */
+int vsr_sr_convout_planes_f16(const void* hr_nhwc, const float* weight, const float* bias3, float* raw, int N, int H, int W,
+                              int step, vsr_stream_t stream);
+/* vsr_sr_fc_planes_skip_f32 with the bilinear factor of the skip (:136) as a parameter (one pixel per thread). */
+int vsr_sr_fc_planes_skip_scale_f32(const float* raw, const float* x, const float* tail_params, const float* w1, const float* b1,
+                                    const float* w2, const float* b2, int nplanes, int hidden, float* out, int h, int w, int scale,
+                                    int decimate, vsr_stream_t stream);
+
 /* The same tail evaluated only at the output pixels (4i, 4j): prefc_dec [N,3,h,w] fp32.  Pass 1 of VSR.forward hands its
  * frame to a nearest-neighbour x1/4 resize and nothing else (video_super_resolution.py:41-44), so only these pixels of
  * it are ever read. */
@@ -310,6 +333,21 @@ int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, in
 /* Tuning hook for benchmarks: 0 heuristic choice between the gather kernel and the LDS-patch kernel (cout <= 16,
  * stride 1), 1 never the patch kernel, 2 whenever legal.  Returns the previous mode. */
 int vsr_conv2d_tuning(int patch_mode);
+
+/* ------------------------------------------------------------------------------------------
+ * Clip I/O: the data formats either side of the path.
+ * ------------------------------------------------------------------------------------------ */
+
+/* main.py:155-167 per dataset item: uint8 NHWC frames [F,H,W,3] (RGB, as utils/video_utils.py:21-23 delivers them) ->
+ *   lr         [F,h,w,3] float32: `interpolate(transpose1323(d.float()), (h, w))` (default mode nearest, ATen's index rule
+ *              src = min(floor(dst * (float)in/out), in-1)) back in NHWC -- MakeDataDatasetToTensor;
+ *   hr_or_null [F,H,W,3] float32: `datas.type(torch.float32)` -- MakeHFDatasetToTensor / MakeTargetDatasetToTensor (optional). */
+int vsr_clip_ingest_u8(const void* frames_u8, float* lr, float* hr_or_null, int F, int H, int W, int h, int w,
+                       vsr_stream_t stream);
+
+/* HR write-out: float32 frame (n values, any layout) -> uint8, round half to even, clamped to 0..255, NaN -> 0. */
+int vsr_frame_to_u8(const float* frame, void* out_u8, size_t n, vsr_stream_t stream);
+
 
 #ifdef __cplusplus
 }

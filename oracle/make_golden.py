@@ -11,6 +11,8 @@ Fixture families:
   g3_flow2img  Middlebury colour coding incl. zero / NaN / >1e7 flows
   g4_wrappers  Depth and VOS wrappers at 32x48, FlowNet2 + wrapper at 64x128
   g6_vsr       full VSR.forward, two recurrent frames at LR 66x70 (crop 64x64)
+  g7_layout    layout helpers + nearest resizes on arange tensors
+  g8_sr_x*     scale extension: the reference's forward code + block classes with the (kernel, stride, padding) of x2 / x3
 """
 from __future__ import annotations
 
@@ -134,11 +136,57 @@ def g6(vsr):
           high_frames1_matches_out0=np.array(bool(torch.equal(side_effect, out0[0]))))
 
 
+def g7():
+    """Layout helpers and the nearest resizes of VSR.forward on arange tensors (tools.py:76-77,102-123;
+    video_super_resolution.py:35,37,44)."""
+    from utils import tools
+    from torch.nn.functional import interpolate
+    a = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).view(2, 3, 4, 5)
+    arrs = {"a": a.numpy()}
+    for name in ("transpose1323", "transpose1223", "transpose1312", "transpose030112", "transpose031323"):
+        arrs[name] = getattr(tools, name)(a).contiguous().numpy()
+    arrs["transpose1201"] = tools.transpose1201(a[0]).contiguous().numpy()
+    arrs["maskprocess"] = tools.maskprocess(a[0, 0]).numpy()
+    hr = torch.arange(1 * 3 * 24 * 40, dtype=torch.float32).view(1, 3, 24, 40)
+    arrs["hr"] = hr.numpy()
+    arrs["down4"] = interpolate(hr, (6, 10)).numpy()          # :44 nearest x1/4 -> pixels (4i, 4j)
+    arrs["down2"] = interpolate(hr, (12, 20)).numpy()         # the scale-2 extension's counterpart
+    pic = torch.arange(1 * 3 * 64 * 64, dtype=torch.float32).view(1, 3, 64, 64)
+    arrs["pic_to_66x70"] = interpolate(pic, (66, 70)).numpy()  # :35 flow picture (crop 64x64) back to h x w
+    _save("g7_layout", **arrs)
+
+
+@torch.no_grad()
+def g8():
+    """Scale extension: the reference's forward code and block classes with the geometry literals of another scale
+    (ref_harness.reference_sr_module_scaled)."""
+    for scale, shape, seed in ((2, (8, 3, 12, 20), 801), (2, (8, 3, 9, 7), 802), (3, (8, 3, 6, 10), 803)):
+        sr = ref_harness.reference_sr_module_scaled(scale).eval()
+        fill_module_(sr, seed=SEED, prefix="model.")
+        x = torch.from_numpy(_u8(np.random.RandomState(seed), shape))
+        taps = {}
+        hooks = [sr.feat_in.register_forward_hook(lambda m, i, o: taps.setdefault("feat_in", o.detach().clone())),
+                 sr.block.register_forward_hook(lambda m, i, o: taps.__setitem__("block_last", o.detach().clone())),
+                 sr.add_mean.register_forward_hook(lambda m, i, o: taps.__setitem__("prefc_last", o.detach().clone()))]
+        out = sr(x)
+        for h in hooks:
+            h.remove()
+        _save(f"g8_sr_x{scale}_{shape[2]}x{shape[3]}", x=x.numpy(), out=out.numpy(), feat_in=taps["feat_in"].numpy(),
+              block2=taps["block_last"].numpy(), prefc2=taps["prefc_last"].numpy(), scale=np.array(scale))
+
+
 def main():
     torch.manual_seed(0)
+    which = set(sys.argv[1:]) or {"g1", "g3", "g4", "g6", "g7", "g8"}
+    if "g7" in which:
+        ref_harness.install()
+        g7()
+    if "g8" in which:
+        g8()
+    if not which & {"g1", "g3", "g4", "g6"}:
+        return
     vsr = ref_harness.reference_vsr().eval()
     fill_module_(vsr, seed=SEED)
-    which = set(sys.argv[1:]) or {"g1", "g3", "g4", "g6"}
     if "g1" in which:
         g1_g2(vsr)
     if "g3" in which:

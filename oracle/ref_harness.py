@@ -125,6 +125,26 @@ def reference_sr_module(**kw):
     return SRProjectionModule(**kw)
 
 
+def reference_sr_module_scaled(upscale_factor: int):
+    """The reference's SRProjectionModule with its three geometry literals (kernel 8 / stride 4 / padding 2,
+    SRProjectionModule.py:10-12,101-103) replaced by SRFBN's row for another scale.  Nothing of the reference's forward
+    code changes (FeedbackBlock.forward / SRProjectionModule.forward never mention the geometry): the up / down / `out`
+    blocks are rebuilt with the reference's OWN DeconvBlock / ConvBlock classes and the same constructor arguments, only
+    (kernel, stride, padding) differ.  This is what pins the scale extension (tests/golden/g8_sr_x*.npz)."""
+    install()
+    from my_packages.SRProjection.SRProjectionModule import SRProjectionModule
+    from my_packages.SRProjection.blocks import ConvBlock, DeconvBlock
+    k, st, pd = {2: (6, 2, 2), 3: (7, 3, 2), 4: (8, 4, 2)}[upscale_factor]
+    m = SRProjectionModule(upscale_factor=upscale_factor)
+    nf, blk = m.num_features, m.block
+    for idx in range(blk.num_groups):
+        blk.upBlocks[idx] = DeconvBlock(nf, nf, kernel_size=k, stride=st, padding=pd, act_type="prelu", norm_type=None)
+        blk.downBlocks[idx] = ConvBlock(nf, nf, kernel_size=k, stride=st, padding=pd, act_type="prelu", norm_type=None,
+                                        valid_padding=False)
+    m.out = DeconvBlock(nf, nf, kernel_size=k, stride=st, padding=pd, act_type="prelu", norm_type=None)
+    return m
+
+
 def reference_vsr():
     """The reference's `VSR()` (no-arg ctor, network/video_super_resolution.py:13-21), cwd-independent."""
     install()

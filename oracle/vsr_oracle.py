@@ -499,3 +499,34 @@ def vsr_forward(P: Params, data: torch.Tensor, estimated_image: Optional[torch.T
     if high_frames is not None:
         high_frames[1] = out  # :66 (broadcast over the leading 1)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Either side of the path: the dataset windows and main.py's per-item tensor preparation
+# ----------------------------------------------------------------------------------------------
+
+
+def video_windows(imgs, splitvideonum: int = 20):
+    """utils/video_utils.py:24-27 -- 3-frame windows, chunked by int(length / splitvideonum) FRAMES."""
+    length = len(imgs)
+    data = [imgs[i:i + 3] for i in range(len(imgs) - 2)]
+    out = []
+    for i in range(0, length, int(length / splitvideonum)):
+        out.append(data[i:i + int(length / splitvideonum)])
+    return out
+
+
+def make_lr(datas_u8: torch.Tensor, scale: int = 4) -> torch.Tensor:
+    """main.py:155-159 MakeDataDatasetToTensor: [T,3,H,W,3] uint8 -> [T,3,H/4,W/4,3] float32 (default-mode nearest)."""
+    return torch.stack([F.interpolate(d.type(torch.float32).permute(0, 3, 1, 2), (int(d.shape[1] / scale), int(d.shape[2] / scale)))
+                        .permute(0, 2, 3, 1) for d in datas_u8])
+
+
+def make_target_and_hf(datas_u8: torch.Tensor):
+    """main.py:161-167 MakeTargetDatasetToTensor / MakeHFDatasetToTensor."""
+    return datas_u8[:, 1:2].type(torch.float32), datas_u8.type(torch.float32)
+
+
+def frames_to_u8(frames: torch.Tensor) -> torch.Tensor:
+    """HR write-out convention of this build (the reference never writes frames): rint (half to even), clamp 0..255, NaN -> 0."""
+    return torch.nan_to_num(torch.round(frames), nan=0.0).clamp(0, 255).to(torch.uint8)

@@ -90,7 +90,7 @@ def test_product_refuses_cpu_execution(cpu_vsr):
 def test_unsupported_geometries_fail_loudly():
     from video_super_resolution_amd import SRProjectionModule
     with pytest.raises(NotImplementedError):
-        SRProjectionModule(upscale_factor=2)  # crashes with a shape mismatch in the reference too
+        SRProjectionModule(upscale_factor=8)  # 4 = the reference; 2 / 3 = the scale extension (tests/test_gpu_sr_scale.py)
     with pytest.raises(NotImplementedError):
         SRProjectionModule(num_features=16)
 

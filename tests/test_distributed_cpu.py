@@ -59,3 +59,55 @@ def test_round_robin_assignment_covers_every_clip_once():
             seen = sorted(c for r in range(world) for c in clips_of_rank(n, r, world))
             assert seen == list(range(n))
     assert clips_of_rank(32, 3, 8) == [3, 11, 19, 27]  # config 4: 32 clips, 4 per GPU
+
+
+def _worker_clips(rank, world, port, n_clips, q):
+    sys.path.insert(0, ROOT)
+    from video_super_resolution_amd.distributed import run_sharded_clips
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def stub_forward_clip(cid):   # stands in for K recurrent VSR.forward calls on this rank's device
+        calls.append(cid)
+        est = torch.zeros(2, 3)
+        frames = []
+        for t in range(3):       # K = 3 frames, each depending on the previous one (the estimated_image recurrence)
+            est = est + cid + 0.1 * t
+            frames.append(est.clone())
+        return torch.stack(frames)
+
+    full, n_mine = run_sharded_clips(stub_forward_clip, n_clips, rank, world, dst=0)
+    assert calls == list(range(rank, n_clips, world)) and n_mine == len(calls)
+    if rank == 0:
+        q.put((tuple(full.shape), full[:, :, 0, 0].tolist()))
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [4, 5, 2])
+def test_bench_clip_control_flow_two_ranks(n_clips):
+    """`bench.py --clips N` (config C4) with a stub model: round-robin clips, per-clip asynchronous gathers, clip order
+    restored on rank 0, a rank without a clip in the last round."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_clips, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    shape, vals = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert shape == (n_clips, 3, 2, 3)
+    for c in range(n_clips):
+        expect = [c, 2 * c + 0.1, 3 * c + 0.3]
+        assert vals[c] == pytest.approx(expect)
+
+
+def test_clip_gather_single_process_is_a_pass_through():
+    from video_super_resolution_amd.distributed import run_sharded_clips
+    full, n = run_sharded_clips(lambda cid: torch.full((2, 4), float(cid)), 3, 0, 1)
+    assert n == 3 and full.shape == (3, 2, 4) and full[:, 0, 0].tolist() == [0.0, 1.0, 2.0]

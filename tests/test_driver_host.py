@@ -1,0 +1,79 @@
+"""Host-side checks (no GPU) of the callers either side of the path: the dataset's windowing against the oracle's
+restatement of utils/video_utils.py, and checkpoint interchange with a file the REFERENCE's own code saved
+(tests/golden/g9_ref_checkpoint.pth.tar, written by oracle/make_checkpoint_fixture.py through utils/tools.save_checkpoint)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsr_oracle as O
+from video_super_resolution_amd import VSR, driver
+from video_super_resolution_amd.weights import fill_module_
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("n_frames", [20, 43, 61])
+def test_dataset_windows_follow_the_reference_indexing(n_frames, tmp_path):
+    frames = np.random.RandomState(n_frames).randint(0, 256, (n_frames, 4, 6, 3)).astype(np.uint8)
+    np.save(tmp_path / "clip0.npy", frames)
+    want = O.video_windows(list(frames))                     # video_utils.py:24-27
+    ds = driver.VideoDataset(str(tmp_path))
+    assert len(ds) == 21                                      # one video x (splitvideonum + 1), video_utils.py:14-15
+    for idx in range(min(len(want), len(ds))):                 # (a 43-frame clip yields 22 chunks; the 22nd is never handed out)
+        got = ds[idx]                                          # idx 0 reads the video, every item pops a chunk (:29-33)
+        assert len(got) == len(want[idx])
+        for a, b in zip(got, want[idx]):
+            assert np.array_equal(np.stack(a), np.stack(b))
+    # a chunk is what main.py:186 turns into `datas` [T,3,H,W,3]
+    first = torch.tensor(np.stack([np.stack(wd) for wd in want[0]]))
+    assert first.shape == (n_frames // 20, 3, 4, 6, 3) and first.dtype == torch.uint8
+    with pytest.raises(ValueError):
+        driver.sliding_windows(list(frames[:10]))             # fewer than 20 frames: int(length / 20) == 0 (range() step 0 in the reference)
+
+
+def test_raw_rgb24_clip_reader(tmp_path):
+    frames = np.random.RandomState(1).randint(0, 256, (5, 8, 10, 3)).astype(np.uint8)
+    frames.tofile(tmp_path / "clip.rgb")
+    assert np.array_equal(driver.read_clip(str(tmp_path / "clip.rgb"), (8, 10)), frames)
+    with pytest.raises(ValueError):
+        driver.read_clip(str(tmp_path / "clip.rgb"))
+
+
+def test_reference_saved_checkpoint_loads_strict_and_round_trips(tmp_path):
+    with open(os.path.join(GOLDEN, "g9_ref_checkpoint.json")) as f:
+        meta = json.load(f)
+    m = VSR().eval()
+    fill_module_(m, seed=0)
+    before = m.model.conv_in[0].weight.detach().clone()
+    ckpt = driver.load_checkpoint(m, os.path.join(GOLDEN, "g9_ref_checkpoint.pth.tar"), map_location="cpu")   # strict (main.py:118)
+    assert ckpt["epoch"] == meta["epoch"] and ckpt["arch"] == meta["arch"] and set(ckpt) == {"arch", "epoch", "state_dict", "optimizer"}
+    sd = m.model.state_dict()
+    assert set(sd) == set(meta["tensors"]) and len(sd) == 91
+    for k, info in meta["tensors"].items():
+        assert list(sd[k].shape) == info["shape"] and str(sd[k].dtype) == info["dtype"], k
+        assert hashlib.sha256(sd[k].detach().contiguous().numpy().tobytes()).hexdigest()[:16] == info["sha256_16"], k
+    assert not torch.equal(before, m.model.conv_in[0].weight)            # the load is observable (another seed)
+    want = fill_module_(VSR().eval().model, seed=meta["seed"], prefix="model.").state_dict()
+    assert all(torch.equal(sd[k], want[k]) for k in sd)                  # = the generator's seed-7 set, bit for bit
+    # and back out in the reference's file layout (tools.py:68-73, main.py:233-237): same keys, loadable again
+    opt = torch.optim.Adam(m.model.parameters(), lr=1e-4)
+    name = driver.save_checkpoint(driver.checkpoint_state(m, epoch=4, optimizer=opt), True, str(tmp_path), "VSR")
+    assert os.path.basename(name) == "VSR_checkpoint.pth.tar" and os.path.exists(tmp_path / "VSR_model_best.pth.tar")
+    again = torch.load(name, weights_only=False)
+    assert list(again["state_dict"]) == list(ckpt["state_dict"]) and again["epoch"] == 4
+    assert all(torch.equal(again["state_dict"][k], ckpt["state_dict"][k]) for k in ckpt["state_dict"])
+    m2 = VSR().eval()
+    driver.load_checkpoint(m2, name, map_location="cpu")
+    assert torch.equal(m2.model.fc[0].weight, m.model.fc[0].weight)
+
+
+def test_oracle_make_lr_is_the_pixels_4i_4j():
+    d = torch.from_numpy(np.random.RandomState(2).randint(0, 256, (2, 3, 16, 24, 3)).astype(np.uint8))
+    lr = O.make_lr(d, 4)
+    assert lr.shape == (2, 3, 4, 6, 3) and torch.equal(lr, d[:, :, ::4, ::4].float())
+    t, hf = O.make_target_and_hf(d)
+    assert t.shape == (2, 1, 16, 24, 3) and torch.equal(hf, d.float())

@@ -97,8 +97,8 @@ __global__ void __launch_bounds__(kBlock) k_deconv(const float* __restrict__ in,
                                                    float* __restrict__ out, int h, int w) {
     constexpr int T = (K + S - 1) / S;
     const int n = blockIdx.z, Y = blockIdx.y;
-    const int q = blockIdx.x * kBlock + threadIdx.x;  // ix in [0, w + T - 2]
-    if (q > w + T - 2) return;
+    const int q = blockIdx.x * kBlock + threadIdx.x;  // ix = (X + 2) / S in [0, w]
+    if (q > w) return;
     const int H = S * h, W = S * w;
     const int iy = (Y + 2) / S, py = (Y + 2) % S;
     const size_t hw = (size_t)h * w, HW = (size_t)H * W;
@@ -267,7 +267,7 @@ int vsr_sr_deconv_f32(const float* in, const float* weight_packed, const float* 
     VSR_REQUIRE(in && weight_packed && bias && out, "sr_deconv: null pointer");
     VSR_REQUIRE(scale >= 2 && scale <= 4, "sr_deconv: scale %d (2: k6 s2, 3: k7 s3, 4: k8 s4; padding 2)", scale);
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && (long long)scale * h <= 65535 && N <= 65535, "sr_deconv: bad shape");
-    const dim3 grid(vsr::cdiv(w + 2, kBlock), scale * h, N);
+    const dim3 grid(vsr::cdiv(w + 1, kBlock), scale * h, N);
     if (scale == 4) hipLaunchKernelGGL((k_deconv<8, 4>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
     else if (scale == 3) hipLaunchKernelGGL((k_deconv<7, 3>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
     else hipLaunchKernelGGL((k_deconv<6, 2>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);

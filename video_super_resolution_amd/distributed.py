@@ -52,3 +52,74 @@ def interleave_clips(per_rank: List[torch.Tensor], n_clips: int) -> torch.Tensor
         for j, cid in enumerate(range(r, n_clips, world)):
             out[cid] = t[j]
     return torch.stack(out)
+
+
+class ClipGather:
+    """The gather of config C4 issued clip by clip: as soon as a rank has finished a clip, its frames leave for `dst`
+    (asynchronous `gather`, one per round of W clips) while the rank computes its next clip -- the xGMI transfers
+    (7 direct links into the root) overlap with compute instead of forming one end-of-job burst of `clips_per_rank`
+    times the size.  Every rank calls `submit` once per round, in the same order (a collective); a rank without a clip
+    in the last round (n_clips not a multiple of W) submits None.  `finish()` waits for all rounds and returns
+    `[n_clips, K, ...]` in clip order on `dst`, None elsewhere.  Single process (no process group): pass-through."""
+
+    def __init__(self, n_clips: int, dst: int = 0, group=None):
+        self.n_clips, self.dst, self.group = n_clips, dst, group
+        self.dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.rank = dist.get_rank(group) if self.dist else 0
+        self.rounds = []   # (work handle or None, receive buffers or [local])
+        self._shape = None
+
+    def submit(self, frames: Optional[torch.Tensor], like: Optional[torch.Tensor] = None):
+        """frames [K, ...] of this rank's clip of the current round (None: no clip this round; `like` gives the shape)."""
+        if frames is None:
+            if like is None:
+                raise ValueError("a rank without a clip must pass `like` (shape/dtype of a clip's frames)")
+            frames = torch.zeros_like(like)
+        frames = frames.contiguous()
+        if not self.dist:
+            self.rounds.append((None, [frames]))
+            return
+        bufs = [torch.empty_like(frames) for _ in range(self.world)] if self.rank == self.dst else None
+        work = dist.gather(frames, bufs, dst=self.dst, group=self.group, async_op=True)
+        self.rounds.append((work, bufs, frames))   # keep `frames` alive until the transfer has completed
+
+    def finish(self) -> Optional[torch.Tensor]:
+        out = []
+        for entry in self.rounds:
+            if entry[0] is not None:
+                entry[0].wait()
+            if self.rank == self.dst:
+                out.extend(entry[1])
+        self.rounds = []
+        if self.rank != self.dst:
+            return None
+        # round j delivered clips j*W + r for r = 0..W-1, i.e. already in clip order; drop the padding of the last round
+        return torch.stack(out[:self.n_clips])
+
+
+def run_sharded_clips(forward_clip, n_clips: int, rank: int, world: int, dst: int = 0, group=None):
+    """Control flow of config C4 (`bench.py --clips N`): clip i runs on rank i mod W, clips of a rank one after the other
+    (frames inside a clip are serial), each finished clip gathered to `dst` while the next one runs.
+    `forward_clip(clip_id) -> [K, ...]` produces the finished frames of one clip on this rank's device.
+    Returns ([n_clips, K, ...] on dst | None, number of clips this rank ran)."""
+    mine = clips_of_rank(n_clips, rank, world)
+    rounds = -(-n_clips // world)
+    g = ClipGather(n_clips, dst=dst, group=group)
+    like = None
+    pending_none = 0
+    for j in range(rounds):
+        if j < len(mine):
+            frames = forward_clip(mine[j])
+            like = frames
+            for _ in range(pending_none):   # (cannot happen with round-robin: a rank's missing clip is always its last)
+                g.submit(None, like=like)
+            pending_none = 0
+            g.submit(frames)
+        elif like is not None:
+            g.submit(None, like=like)
+        else:
+            pending_none += 1
+    if pending_none:
+        raise RuntimeError("a rank without any clip cannot take part in the gather: use n_clips >= world size")
+    return g.finish(), len(mine)

@@ -32,6 +32,18 @@ from . import _lib as L
 _NF = 32  # the kernels are specialised for the reference's num_features
 
 
+def sr_geometry(upscale_factor: int):
+    """(kernel, stride, padding) of the up / down / `out` (de)convolutions: (8, 4, 2) are the reference's literals
+    (SRProjectionModule.py:10-12,101-103 -- the x4 row of SRFBN's table); x2 = (6, 2, 2) and x3 = (7, 3, 2) are that
+    table's other rows: the scale extension SURVEY.md 7-1 / 8(d) asks for (BASELINE configs C1, C2, C3-B, C5 are labelled
+    x2).  The reference itself crashes for upscale_factor != 4, so x2 / x3 have no reference output: they are checked
+    against the oracle evaluated with the same three literals (parity-unpinned by construction)."""
+    try:
+        return {2: (6, 2, 2), 3: (7, 3, 2), 4: (8, 4, 2)}[int(upscale_factor)]
+    except KeyError:
+        raise NotImplementedError(f"upscale_factor {upscale_factor}: 4 (the reference's geometry), 2 or 3") from None
+
+
 class MeanShift(nn.Conv2d):
     """1x1 conv with identity/std weight and sign*255*mean/std bias, frozen (reference blocks.py:46-55)."""
 
@@ -58,9 +70,10 @@ def _deconv_act(cin, cout, k, stride, padding) -> nn.Sequential:
 class FeedbackBlock(nn.Module):
     """Parameter container with the reference's names (SRProjectionModule.py:7-42); evaluated by the parent."""
 
-    def __init__(self, num_features, num_groups, act_type="prelu", norm_type=None):
+    def __init__(self, num_features, num_groups, act_type="prelu", norm_type=None, upscale_factor=4):
         super().__init__()
         nf = num_features
+        k, st, pd = sr_geometry(upscale_factor)
         self.num_groups = num_groups
         self.num_features = nf
         self.compress_in = _conv_act(2 * nf, nf, 1)
@@ -69,8 +82,8 @@ class FeedbackBlock(nn.Module):
         self.uptranBlocks = nn.ModuleList()
         self.downtranBlocks = nn.ModuleList()
         for idx in range(num_groups):
-            self.upBlocks.append(_deconv_act(nf, nf, 8, 4, 2))
-            self.downBlocks.append(_conv_act(nf, nf, 8, stride=4, padding=2))
+            self.upBlocks.append(_deconv_act(nf, nf, k, st, pd))
+            self.downBlocks.append(_conv_act(nf, nf, k, stride=st, padding=pd))
             if idx > 0:
                 self.uptranBlocks.append(_conv_act(nf * (idx + 1), nf, 1))
                 self.downtranBlocks.append(_conv_act(nf * (idx + 1), nf, 1))
@@ -84,9 +97,9 @@ class SRProjectionModule(nn.Module):
     def __init__(self, in_channels=3, out_channels=3, num_features=32, upscale_factor=4, num_steps=3, num_groups=6,
                  act_type="prelu", norm_type=None):
         super().__init__()
-        if (in_channels, out_channels, num_features, upscale_factor) != (3, 3, _NF, 4):
-            raise NotImplementedError("the gfx950 kernels implement the reference geometry: 3->3 channels, 32 features, "
-                                      "x4 (kernel 8 / stride 4 / pad 2 are literals in the reference too)")
+        if (in_channels, out_channels, num_features) != (3, 3, _NF):
+            raise NotImplementedError("the gfx950 kernels implement the reference's widths: 3->3 channels, 32 features")
+        k, st, pd = sr_geometry(upscale_factor)   # 4: the reference (fused MFMA kernels); 2 / 3: the scale extension
         if not 3 <= num_groups <= 9:
             raise NotImplementedError("3 <= num_groups <= 9 (compress_out takes at most three live inputs per launch)")
         if act_type != "prelu" or norm_type is not None:
@@ -98,8 +111,8 @@ class SRProjectionModule(nn.Module):
         self.sub_mean = MeanShift(rgb_mean, rgb_std)
         self.conv_in = _conv_act(in_channels, 4 * num_features, 3, padding=1)
         self.feat_in = _conv_act(4 * num_features, num_features, 1)
-        self.block = FeedbackBlock(num_features, num_groups, act_type, norm_type)
-        self.out = _deconv_act(num_features, num_features, 8, 4, 2)
+        self.block = FeedbackBlock(num_features, num_groups, act_type, norm_type, upscale_factor)
+        self.out = _deconv_act(num_features, num_features, k, st, pd)
         self.conv_out = _conv_act(num_features, out_channels, 3, padding=1, act=False)
         self.add_mean = MeanShift(rgb_mean, rgb_std, 1)
         self.fc = nn.Sequential(nn.Linear(8, 32), nn.ReLU(), nn.Linear(32, 1), nn.ReLU())
@@ -158,8 +171,19 @@ class SRProjectionModule(nn.Module):
         P["fc_w1"], P["fc_b1"] = f(self.fc[0].weight), f(self.fc[0].bias)
         P["fc_w2"], P["fc_b2"] = f(self.fc[2].weight.reshape(-1)), f(self.fc[2].bias)
         P["zero_b"] = torch.zeros(_NF, dtype=torch.float32, device=wci.device)
-        # ---- MFMA path: one packed blob per live chain  lr[j] -> hr[j+1] -> lr[j+3]  and one for the tail deconv
         G = b.num_groups
+        P["slopes_le_one"] = all(a <= 1.0 for a in P["up_a"] + P["dn_a"] + P["dt_a"] + [P["out_a"]])
+        P["tail_par"] = torch.cat((P["cv_b"], P["sub_s"], P["sub_b"], P["add_s"], P["add_b"])).contiguous()
+        if self.upscale_factor != 4:
+            # scale extension: the stage as separate launches on the generic NHWC fp16 MFMA convolution (igemm.py)
+            P["stage"] = {j: _UnfusedStage(b.upBlocks[j + 1], P["dt_w"][j + 1], _NF * (j + 2), P["dt_b"][j + 1], P["dt_a"][j + 1],
+                                           b.downBlocks[j + 2], self.upscale_factor) for j in range(0, G - 2, 3)}
+            P["out_deconv"] = _PhaseDeconv(self.out[0].weight, self.out[0].bias, P["out_a"], self.upscale_factor)
+            self._pack, self._pack_key = P, key
+            self._const.clear()
+            self._const_nhwc.clear()
+            return P
+        # ---- MFMA path: one packed blob per live chain  lr[j] -> hr[j+1] -> lr[j+3]  and one for the tail deconv
         P["utd"], P["utd2"] = {}, {}
         for j in range(0, G - 2, 3):
             args = (b.upBlocks[j + 1][0].weight, b.upBlocks[j + 1][0].bias, P["up_a"][j + 1], P["dt_w"][j + 1], _NF * (j + 2),
@@ -172,8 +196,6 @@ class SRProjectionModule(nn.Module):
                                               fold_co=(P["co_w"], (_NF * 2, _NF * 5), P["co_b"], P["co_a"]))
         P["cv_frags"] = pack_conv_out_frags(self.conv_out[0].weight)
         P["cv_frags3"] = pack_conv_out_frags3(self.conv_out[0].weight)
-        P["tail_par"] = torch.cat((P["cv_b"], P["sub_s"], P["sub_b"], P["add_s"], P["add_b"])).contiguous()
-        P["slopes_le_one"] = all(a <= 1.0 for a in P["up_a"] + P["dn_a"] + P["dt_a"] + [P["out_a"]])
         self._pack, self._pack_key = P, key
         self._const.clear()
         self._const_nhwc.clear()
@@ -199,21 +221,21 @@ class SRProjectionModule(nn.Module):
                 "sr_conv1x1")
         return out
 
-    @staticmethod
-    def _up(x, w, b, a, N, h, w_):
-        out = torch.empty((N, _NF, 4 * h, 4 * w_), dtype=torch.float32, device=x.device)
-        tok = L.TIMER.start("sr_deconv8s4_f32")
-        L.check(L.load().vsr_sr_deconv8s4_f32(L.dptr(x), L.dptr(w), L.dptr(b), L.cf(a), L.dptr(out), N, h, w_, L.stream()),
-                "sr_deconv8s4")
+    def _up(self, x, w, b, a, N, h, w_):
+        S = self.upscale_factor
+        out = torch.empty((N, _NF, S * h, S * w_), dtype=torch.float32, device=x.device)
+        tok = L.TIMER.start("sr_deconv8s4_f32" if S == 4 else "sr_deconv_f32")
+        L.check(L.load().vsr_sr_deconv_f32(L.dptr(x), L.dptr(w), L.dptr(b), L.cf(a), L.dptr(out), N, h, w_, S, L.stream()),
+                "sr_deconv")
         L.TIMER.stop(tok)
         return out
 
-    @staticmethod
-    def _down(x, w, b, a, N, h, w_):
+    def _down(self, x, w, b, a, N, h, w_):
+        S = self.upscale_factor
         out = torch.empty((N, _NF, h, w_), dtype=torch.float32, device=x.device)
-        tok = L.TIMER.start("sr_conv8s4_f32")
-        L.check(L.load().vsr_sr_conv8s4_f32(L.dptr(x), L.dptr(w), L.dptr(b), L.cf(a), L.dptr(out), N, h, w_, L.stream()),
-                "sr_conv8s4")
+        tok = L.TIMER.start("sr_conv8s4_f32" if S == 4 else "sr_conv_f32")
+        L.check(L.load().vsr_sr_conv_f32(L.dptr(x), L.dptr(w), L.dptr(b), L.cf(a), L.dptr(out), N, h, w_, S, L.stream()),
+                "sr_conv")
         L.TIMER.stop(tok)
         return out
 
@@ -225,9 +247,10 @@ class SRProjectionModule(nn.Module):
 
     def _lr_from(self, P, i, hr_prev, N, h, w):
         """lr[i+1] for i >= 1 from hr[i-1]."""
-        b = self._c1([(hr_prev.view(N, _NF, 16 * h * w), P["dt_w"][i - 1], _NF * i)], P["dt_b"][i - 1], P["dt_a"][i - 1], N,
-                     16 * h * w)
-        return self._down(b.view(N, _NF, 4 * h, 4 * w), P["dn_w"][i], P["dn_b"][i], P["dn_a"][i], N, h, w)
+        S = self.upscale_factor
+        b = self._c1([(hr_prev.view(N, _NF, S * S * h * w), P["dt_w"][i - 1], _NF * i)], P["dt_b"][i - 1], P["dt_a"][i - 1], N,
+                     S * S * h * w)
+        return self._down(b.view(N, _NF, S * h, S * w), P["dn_w"][i], P["dn_b"][i], P["dn_a"][i], N, h, w)
 
     def _const_map(self, P, h, w, dev) -> torch.Tensor:
         """compress_out's share of every input-independent lr[j] (j != 0 mod 3), [32, h*w] float32."""
@@ -237,7 +260,7 @@ class SRProjectionModule(nn.Module):
         lr: Dict[int, torch.Tensor] = {}
         hr: Dict[int, torch.Tensor] = {}
         z = torch.zeros((1, _NF, h, w), dtype=torch.float32, device=dev)
-        Z = torch.zeros((1, _NF, 4 * h, 4 * w), dtype=torch.float32, device=dev)
+        Z = torch.zeros((1, _NF, self.upscale_factor * h, self.upscale_factor * w), dtype=torch.float32, device=dev)
         hr[0] = self._up(z, P["up_w"][0], P["up_b"][0], P["up_a"][0], 1, h, w)
         lr[1] = self._down(Z, P["dn_w"][0], P["dn_b"][0], P["dn_a"][0], 1, h, w)
         del z, Z
@@ -261,9 +284,9 @@ class SRProjectionModule(nn.Module):
     @L.on_device
     @torch.no_grad()
     def forward(self, x: torch.Tensor, taps: Optional[dict] = None, decimate: bool = False) -> torch.Tensor:
-        """[8,3,h,w] planes -> [1,3,4h,4w].  decimate=True returns only the pixels (4i, 4j) as [1,3,h,w] -- what a
-        nearest x1/4 resize of the full frame reads (pass 1 of VSR.forward, video_super_resolution.py:41-44); identical
-        values, the tail and the fusion MLP are evaluated at 1/16 of the pixels."""
+        """[8,3,h,w] planes -> [1,3,Sh,Sw] (S = upscale_factor, 4 in the reference).  decimate=True returns only the
+        pixels (S i, S j) as [1,3,h,w] -- what a nearest x1/S resize of the full frame reads (pass 1 of VSR.forward,
+        video_super_resolution.py:41-44); identical values, the tail and the fusion MLP are evaluated at 1/S^2 of the pixels."""
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected [planes,3,h,w], got {tuple(x.shape)}")
         N, _, h, w = x.shape
@@ -310,18 +333,19 @@ class SRProjectionModule(nn.Module):
                     for k, v in live.items():
                         taps[f"lr{k}"] = v
         up = self._up(hid.view(N, _NF, h, w), P["out_w"], P["out_b"], P["out_a"], N, h, w)
-        prefc = torch.empty((N, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev)
-        L.check(lib.vsr_sr_tail_f32(L.dptr(up), L.dptr(P["cv_w"]), L.dptr(P["cv_b"]), L.dptr(x), L.dptr(P["sub_s"]),
-                                    L.dptr(P["sub_b"]), L.dptr(P["add_s"]), L.dptr(P["add_b"]), L.dptr(prefc), N, h, w,
-                                    L.stream()), "sr_tail")
+        S = self.upscale_factor
+        prefc = torch.empty((N, 3, S * h, S * w), dtype=torch.float32, device=dev)
+        L.check(lib.vsr_sr_tail_scale_f32(L.dptr(up), L.dptr(P["cv_w"]), L.dptr(P["cv_b"]), L.dptr(x), L.dptr(P["sub_s"]),
+                                          L.dptr(P["sub_b"]), L.dptr(P["add_s"]), L.dptr(P["add_b"]), L.dptr(prefc), N, h, w, S,
+                                          L.stream()), "sr_tail")
         del up
         if taps is not None:
             taps[f"prefc{self.num_steps - 1}"] = prefc
-        out = torch.empty((1, 3, 4 * h, 4 * w), dtype=torch.float32, device=dev)
+        out = torch.empty((1, 3, S * h, S * w), dtype=torch.float32, device=dev)
         L.check(lib.vsr_sr_fc_fuse_f32(L.dptr(prefc), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]), L.dptr(P["fc_w2"]),
-                                       L.dptr(P["fc_b2"]), N, P["fc_w1"].shape[0], L.dptr(out), 16 * h * w, 0, L.stream()),
+                                       L.dptr(P["fc_b2"]), N, P["fc_w1"].shape[0], L.dptr(out), S * S * h * w, 0, L.stream()),
                 "sr_fc_fuse")
-        return out[..., ::4, ::4].contiguous() if decimate else out
+        return out[..., ::S, ::S].contiguous() if decimate else out
 
     # ------------------------------------------------------------------ MFMA path (fp16 storage, NHWC)
     @staticmethod
@@ -343,7 +367,7 @@ class SRProjectionModule(nn.Module):
         return out
 
     @staticmethod
-    def _chain(stages, N, P, keep):
+    def _chain(stages, N, P, keep, outs=None):
         """One launch of up to three chained 1x1 stages (csrc/sr_f16.hip k_chain1x1_h).  stages: dicts with `ins`
         [(tensor [N,P,32] half, weight [32,ld] float, first column)], optional `prev` (weight, first column) for the
         previous stage's output, `bias`, `slope`, optional `cmap`.  keep[s]: write stage s to memory.  -> outputs list
@@ -351,7 +375,7 @@ class SRProjectionModule(nn.Module):
         dev = stages[0]["bias"].device
         c = L.Chain1x1()
         c.nstages = len(stages)
-        outs, hold = [], []
+        given, outs, hold = outs, [], []
         for s, st in enumerate(stages):
             d = c.stage[s]
             for t, (ten, wm, col) in enumerate(st["ins"]):
@@ -370,7 +394,8 @@ class SRProjectionModule(nn.Module):
             if st.get("cmap") is not None:
                 d.cmap = L.dptr(st["cmap"]).value
             d.slope = float(st["slope"])
-            o = torch.empty((N, P, _NF), dtype=torch.float16, device=dev) if keep[s] else None
+            o = (given[s] if given is not None and given[s] is not None else
+                 torch.empty((N, P, _NF), dtype=torch.float16, device=dev)) if keep[s] else None   # (a 1x1 may run in place)
             d.out = L.dptr(o, torch.float16).value if o is not None else None
             outs.append(o)
         tok = L.TIMER.start(f"sr_chain1x1_f16 x{len(stages)}") if L.TIMER.enabled else None
@@ -455,12 +480,20 @@ class SRProjectionModule(nn.Module):
             while j + 3 <= G:
                 if j > 0:
                     a = self._chain([ut(j, live[j])], N, hp, keep=[True])[0]
-                live[j + 3] = self._utd(a, P["utd"][j], N, h, w).view(N, hp, _NF)
+                live[j + 3] = (self._utd(a, P["utd"][j], N, h, w) if self.upscale_factor == 4 else
+                               P["stage"][j](a.view(N, h, w, _NF), self._chain)).view(N, hp, _NF)
                 j += 3
             if taps is not None and step == self.num_steps - 1:
                 for k, v in live.items():
                     taps[f"lr{k}"] = nchw(v)
-        ho, wo = (h, w) if decimate else (4 * h, 4 * w)
+        S = self.upscale_factor
+        ho, wo = (h, w) if decimate else (S * h, S * w)
+        if S != 4:
+            hid = self._chain([co(live)], N, hp, keep=[True])[0] if len(co(live)["ins"]) <= 2 else \
+                self._c1h(co(live)["ins"], P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
+            if taps is not None:
+                taps[f"block{self.num_steps - 1}"] = nchw(hid)
+            return self._tail_unfused(x, hid.view(N, h, w, _NF), P, decimate, taps)
         if self.fold_tail and taps is None and self.tail_build == 3 and "utd_out_fold" in P and sorted(k for k in live if k > 0) == [3, 6]:
             # compress_out inside the tail (k_tail3<.., FOLD>): no `hid` tensor, one launch less
             prefc = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
@@ -481,7 +514,6 @@ class SRProjectionModule(nn.Module):
             self._c1h(co(live)["ins"], P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
         if taps is not None:
             taps[f"block{self.num_steps - 1}"] = nchw(hid)
-        ho, wo = (h, w) if decimate else (4 * h, 4 * w)
         prefc = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
         tok = L.TIMER.start("sr_tail_dec_f16" if decimate else "sr_tail_f16")
         out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=dev)
@@ -509,8 +541,112 @@ class SRProjectionModule(nn.Module):
             taps[f"prefc{self.num_steps - 1}"] = prefc
         return out
 
+    def _tail_unfused(self, x, hid, P, decimate, taps):
+        """`out` DeconvBlock -> conv_out 3x3 -> skip + add_mean + fusion MLP for upscale factors other than 4
+        (SRProjectionModule.py:142-146): phase convolutions on the generic MFMA kernel, then csrc/sr_scale.hip."""
+        lib = L.load()
+        N, h, w, _ = hid.shape
+        S = self.upscale_factor
+        dev = hid.device
+        ho, wo = (h, w) if decimate else (S * h, S * w)
+        raw = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
+        nb = _planes_per_chunk(N, S * h, S * w)
+        for n0 in range(0, N, nb):
+            hr = P["out_deconv"](hid[n0:n0 + nb])
+            tok = L.TIMER.start("sr_convout_planes_f16") if L.TIMER.enabled else None
+            L.check(lib.vsr_sr_convout_planes_f16(L.dptr(hr, torch.float16), L.dptr(P["cv_w"]), L.dptr(P["cv_b"]), L.dptr(raw[n0:n0 + nb]),
+                                                  hr.shape[0], S * h, S * w, S if decimate else 1, L.stream()), "sr_convout_planes")
+            L.TIMER.stop(tok)
+            del hr
+        out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=dev)
+        tok = L.TIMER.start("sr_fc_planes_skip_scale") if L.TIMER.enabled else None
+        L.check(lib.vsr_sr_fc_planes_skip_scale_f32(L.dptr(raw), L.dptr(x), L.dptr(P["tail_par"]), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]),
+                                                    L.dptr(P["fc_w2"]), L.dptr(P["fc_b2"]), N, P["fc_w1"].shape[0], L.dptr(out), h, w, S,
+                                                    int(decimate), L.stream()), "sr_fc_planes_skip_scale")
+        L.TIMER.stop(tok)
+        return out
+
     def _reset_state(self):  # API parity with SRProjectionModule.py:149-150; the state never outlives a forward here
         return None
+
+
+def _planes_per_chunk(N, H, W):
+    """Planes whose [n,H,W,32] fp16 HR map stays below 2 GiB (the 1x1 chain's streaming build and the patch kernel's
+    per-image staging use 32-bit byte offsets); the 8 planes are independent until the fusion MLP, so the HR-side
+    launches of the unfused stage walk them in chunks (which also bounds the HR buffers: 17 GB per map at 4K -> 8K)."""
+    per = H * W * _NF * 2
+    if per >= (1 << 31):
+        raise L.VsrHipError(f"one {H}x{W}x32 fp16 feature map exceeds 2 GiB")
+    return max(1, min(N, ((1 << 31) - 1) // per))
+
+
+class _PhaseDeconv:
+    """ConvTranspose2d(32, 32, K, S, padding 2) + PReLU as S*S stride-1 phase convolutions writing the interleaved HR map.
+    Output row Y = S m + r gathers input rows m + c - dy (c = (r + 2) // S) with kernel row py + S dy (py = (r + 2) % S):
+    a correlation with T = ceil(K / S) taps, tap a = T - 1 - dy, top padding T - 1 - c; same along x."""
+
+    def __init__(self, weight, bias, slope, S):
+        from .igemm import ACT_LEAKY, HConv
+        w = weight.detach().float()   # [Cin, Cout, K, K]
+        K = w.shape[2]
+        T = -(-K // S)
+        self.S = S
+        self.phases = []
+        for ry in range(S):
+            for rx in range(S):
+                wk = torch.zeros((w.shape[1], w.shape[0], T, T), dtype=torch.float32, device=w.device)   # [Cout, Cin, T, T]
+                for a in range(T):
+                    ky = (ry + 2) % S + S * (T - 1 - a)
+                    for bb in range(T):
+                        kx = (rx + 2) % S + S * (T - 1 - bb)
+                        if ky < K and kx < K:
+                            wk[:, :, a, bb] = w[:, :, ky, kx].t()
+                c = HConv(wk, bias, stride=1, pad=0, act=ACT_LEAKY, slope=float(slope))   # LeakyReLU(a) == one-slope PReLU
+                c.pad_y, c.pad_x = T - 1 - (ry + 2) // S, T - 1 - (rx + 2) // S
+                c.oy, c.ox = (S, ry), (S, rx)
+                self.phases.append(c)
+
+    def __call__(self, x):
+        N, h, w, _ = x.shape
+        out = torch.empty((N, self.S * h, self.S * w, _NF), dtype=torch.float16, device=x.device)
+        for c in self.phases:
+            c(x, out=out, out_hw=(h, w))
+        return out
+
+
+class _UnfusedStage:
+    """up_i -> downtran slice -> down_j of the FeedbackBlock (SRProjectionModule.py:62-65,77-80, zero-fill semantic) for
+    upscale factors other than 4, as separate launches: phase deconvolution, 1x1 in place on the HR map, strided conv."""
+
+    def __init__(self, up, dt_w, dt_col, dt_b, dt_a, dn, S):
+        from .igemm import ACT_LEAKY, HConv
+        self.S = S
+        self.up = _PhaseDeconv(up[0].weight, up[0].bias, float(up[1].weight.detach()), S)
+        self.dt = (dt_w, dt_col, dt_b, dt_a)
+        K = dn[0].weight.shape[2]
+        self.dn = HConv(dn[0].weight, dn[0].bias, stride=S, pad=2, act=ACT_LEAKY, slope=float(dn[1].weight.detach()))
+        assert K == S + 4
+
+    def __call__(self, a, chain):
+        N, h, w, _ = a.shape
+        S = self.S
+        out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
+        nb = _planes_per_chunk(N, S * h, S * w)
+        dt_w, dt_col, dt_b, dt_a = self.dt
+        for n0 in range(0, N, nb):
+            tok = L.TIMER.start("sr_stage_up")
+            hr = self.up(a[n0:n0 + nb])
+            L.TIMER.stop(tok)
+            n = hr.shape[0]
+            flat = hr.view(n, S * S * h * w, _NF)
+            tok = L.TIMER.start("sr_stage_dt")
+            chain([dict(ins=[(flat, dt_w, dt_col)], bias=dt_b, slope=dt_a)], n, S * S * h * w, keep=[True], outs=[flat])  # in place
+            L.TIMER.stop(tok)
+            tok = L.TIMER.start("sr_stage_dn")
+            self.dn(hr, out=out[n0:n0 + nb], out_hw=(h, w))
+            L.TIMER.stop(tok)
+            del hr, flat
+        return out
 
 
 def ctypes_ptr(view: torch.Tensor):

@@ -43,9 +43,13 @@ def maskprocess(mask: torch.Tensor) -> torch.Tensor:
 
 
 class VSR(nn.Module):
-    def __init__(self):
+    def __init__(self, upscale_factor: int = 4):
+        """`VSR()` is the reference's constructor (x4, video_super_resolution.py:13-21).  `upscale_factor` 2 / 3 select the
+        scale extension of the SR net (sr.sr_geometry; BASELINE configs C1, C2, C3-B, C5) -- every other part of the path
+        is scale-free."""
         super().__init__()
-        self.model = SRProjectionModule()
+        self.model = SRProjectionModule(upscale_factor=upscale_factor)
+        self.upscale_factor = upscale_factor
         self.FlowModule = FlowProjectionModule().eval()
         self.DepthModule = DepthProjectionModule().eval()
         self.VOSModule = VOSProjectionModule().eval()
