@@ -11,6 +11,7 @@ Fixture families:
   g3_flow2img  Middlebury colour coding incl. zero / NaN / >1e7 flows
   g4_wrappers  Depth and VOS wrappers at 32x48, FlowNet2 + wrapper at 64x128
   g6_vsr       full VSR.forward, two recurrent frames at LR 66x70 (crop 64x64)
+  g10_loss     train=True: VSR.loss_calculate on two recurrent frames at HR 264x280 (cached object mask)
   g7_layout    layout helpers + nearest resizes on arange tensors
   g8_sr_x*     scale extension: the reference's forward code + block classes with the (kernel, stride, padding) of x2 / x3
 """
@@ -175,15 +176,34 @@ def g8():
               block2=taps["block_last"].numpy(), prefc2=taps["prefc_last"].numpy(), scale=np.array(scale))
 
 
+@torch.no_grad()
+def g10(vsr):
+    """train=True: the reference's loss branch on two recurrent frames (the second reuses the cached object mask, D7).
+    Called positionally like main.py:201 (`train` left at its default)."""
+    rs = np.random.RandomState(1001)
+    hr = _u8(rs, (3, 264, 280, 3))                                   # high_frames as main.py:165-167 builds them
+    data = torch.from_numpy(hr[:, ::4, ::4].copy())                  # LR = nearest x1/4 (main.py:155-159)
+    target = torch.from_numpy(hr[1:2].copy())
+    hf = torch.from_numpy(hr.copy())
+    vsr.loss4object.mask = None
+    out0, loss0 = vsr(data.clone(), target, hf, None)
+    mask = vsr.loss4object.mask.clone()
+    hf2 = torch.from_numpy(hr.copy())
+    out1, loss1 = vsr(data.clone(), target, hf2, out0)
+    _save("g10_loss", hr=hr.astype(np.uint8), out0=out0.numpy(), out1=out1.numpy(), loss0=loss0.numpy(), loss1=loss1.numpy(),
+          mask=mask.numpy())
+    print("loss0", float(loss0), "loss1", float(loss1), "mask mean", float(mask.float().mean()))
+
+
 def main():
     torch.manual_seed(0)
-    which = set(sys.argv[1:]) or {"g1", "g3", "g4", "g6", "g7", "g8"}
+    which = set(sys.argv[1:]) or {"g1", "g3", "g4", "g6", "g7", "g8", "g10"}
     if "g7" in which:
         ref_harness.install()
         g7()
     if "g8" in which:
         g8()
-    if not which & {"g1", "g3", "g4", "g6"}:
+    if not which & {"g1", "g3", "g4", "g6", "g10"}:
         return
     vsr = ref_harness.reference_vsr().eval()
     fill_module_(vsr, seed=SEED)
@@ -195,6 +215,8 @@ def main():
         g4(vsr)
     if "g6" in which:
         g6(vsr)
+    if "g10" in which:
+        g10(vsr)
 
 
 if __name__ == "__main__":

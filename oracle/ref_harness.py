@@ -151,8 +151,14 @@ def reference_vsr():
     cwd = os.getcwd()
     os.chdir(REFERENCE_ROOT)
     try:
-        from network.video_super_resolution import VSR
-        return VSR()
+        # by file path: this repository ships a regular package `network/` (the import-path shim) that would win over the
+        # reference's namespace package of the same name whatever the order of sys.path
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_reference_network_vsr",
+                                                      os.path.join(REFERENCE_ROOT, "network", "video_super_resolution.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.VSR()
     finally:
         os.chdir(cwd)
 

@@ -530,3 +530,65 @@ def make_target_and_hf(datas_u8: torch.Tensor):
 def frames_to_u8(frames: torch.Tensor) -> torch.Tensor:
     """HR write-out convention of this build (the reference never writes frames): rint (half to even), clamp 0..255, NaN -> 0."""
     return torch.nan_to_num(torch.round(frames), nan=0.0).clamp(0, 255).to(torch.uint8)
+
+
+# ----------------------------------------------------------------------------------------------
+# train=True: VSR.loss_calculate (network/video_super_resolution.py:71-80) and loss_function.py
+# ----------------------------------------------------------------------------------------------
+_VGG16_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+
+
+def vgg16_features31(P: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """nn.Sequential(*list(vgg16().features)[:31]) -- loss_function.py:12-13, utils/models.py:60-79."""
+    idx = 0
+    for v in _VGG16_CFG:
+        if v == "M":
+            x = F.max_pool2d(x, 2, 2)
+            idx += 1
+        else:
+            x = F.relu(F.conv2d(x, P[f"{pre}{idx}.weight"], P[f"{pre}{idx}.bias"], padding=1))
+            idx += 2
+    return x
+
+
+def tv_loss(x: torch.Tensor) -> torch.Tensor:
+    """TVLoss.forward -- loss_function.py:36-44 (tv_loss_weight = 1)."""
+    b, c, h, w = x.shape
+    h_tv = torch.pow(x[:, :, 1:, :] - x[:, :, :h - 1, :], 2).sum()
+    w_tv = torch.pow(x[:, :, :, 1:] - x[:, :, :, :w - 1], 2).sum()
+    return 2 * (h_tv / (c * (h - 1) * w) + w_tv / (c * h * (w - 1))) / b
+
+
+def sr_loss(P: Params, pre: str, output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """SR_loss.forward -- loss_function.py:20-28.  [N,H,W,3] each."""
+    o, t = _nhwc2nchw(output), _nhwc2nchw(target)
+    perception = F.mse_loss(vgg16_features31(P, pre + "loss_network.", o), vgg16_features31(P, pre + "loss_network.", t))
+    return F.mse_loss(o, t) + 0.006 * perception + 2e-8 * tv_loss(o)
+
+
+def flow_loss(P: Params, pre: str, outputs: torch.Tensor) -> torch.Tensor:
+    """Flow_loss.forward -- loss_function.py:57-62."""
+    return 0.005 * torch.mean(torch.stack((sr_loss(P, pre + "SR_loss.", outputs[0:1], outputs[1:2]),
+                                           sr_loss(P, pre + "SR_loss.", outputs[1:2], outputs[2:3]))))
+
+
+def loss_calculate(P: Params, target: torch.Tensor, outputs: torch.Tensor, state: dict) -> torch.Tensor:
+    """VSR.loss_calculate -- video_super_resolution.py:71-80.  `state` plays GetObjectsForOBJLoss.mask: the OSVOS mask is
+    computed on the first call and reused ever after (loss_function.py:69-74, defect D7).  The masked-array calls are the
+    reference's own numpy expressions (:87-92, :98-99), including the [3,H,W] mask applied to [H,W,3] data."""
+    if state.get("mask") is None:
+        seg = vos_projection(P, outputs[0], outputs[1], "loss4object.VOS.net.")
+        state["mask"] = torch.stack((seg == 1,) * 3)
+    mask = state["mask"]
+    gen_sr = sr_loss(P, "SR_loss.", outputs[0:1], target)
+    with np.errstate(all="ignore"):
+        masked_output = torch.unsqueeze(torch.tensor(
+            np.ma.MaskedArray(outputs[1].numpy().astype(np.uint8), mask, fill_value=0).filled(), dtype=torch.float32), 0)
+        masked_target = torch.tensor(np.ma.MaskedArray(target.numpy().astype(np.uint8), mask, fill_value=0).filled(),
+                                     dtype=torch.float32)
+        obj_sr = sr_loss(P, "SR_loss.", masked_output, masked_target)
+        gen_flow = flow_loss(P, "Flow_loss.", outputs)
+        masked = torch.stack([torch.tensor(np.ma.MaskedArray(o.numpy().astype(np.uint8), mask).filled()) for o in outputs]
+                             ).type(torch.float32)
+        obj_flow = flow_loss(P, "Flow_loss.", masked)
+    return gen_sr + obj_sr + 0.006 * gen_flow + 0.006 * obj_flow

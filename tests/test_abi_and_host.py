@@ -63,8 +63,11 @@ def test_sr_state_dict_has_the_reference_layout(cpu_vsr):
     for k, shp in expect.items():
         assert tuple(sd[k].shape) == shp, k
     assert sum(v.numel() for v in sd.values()) == 910871
-    assert len(cpu_vsr.state_dict()) == 1142 and {"model", "FlowModule", "DepthModule", "VOSModule"} == {
-        k.split(".")[0] for k in cpu_vsr.state_dict()}
+    # the whole module tree, loss networks included: 1246 entries / 228,750,548 parameters, key for key the reference's
+    # `VSR().state_dict()` (compared with the imported reference in the development container)
+    assert len(cpu_vsr.state_dict()) == 1246 and {"model", "FlowModule", "DepthModule", "VOSModule", "SR_loss", "Flow_loss",
+                                                  "loss4object"} == {k.split(".")[0] for k in cpu_vsr.state_dict()}
+    assert sum(p.numel() for p in cpu_vsr.parameters()) == 228750548
 
 
 def test_synthetic_weights_are_name_keyed_and_reproducible(cpu_vsr):

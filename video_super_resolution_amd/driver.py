@@ -102,7 +102,8 @@ def ingest_item(datas_u8: torch.Tensor, scale: int = 4, want_hr: bool = True):
     L.check(L.load().vsr_clip_ingest_u8(L.dptr(d, torch.uint8), L.dptr(lr), L.optr(hr), T * 3, H, W, h, w, L.stream()), "clip_ingest")
     if hr is None:
         return lr, None, None
-    return lr, hr[:, 1:2], hr   # target = datas[:, 1:2] (main.py:161-163) as a view of the float copy
+    # target = datas[:, 1:2].float() (main.py:161-163): its own tensor -- VSR.forward overwrites high_frames[1] in place (:66)
+    return lr, hr[:, 1:2].clone(), hr
 
 
 @L.on_device

@@ -16,10 +16,12 @@ What differs, on purpose:
     VOS wrapper and the numpy masked-array fill (:58-60) are device kernels / device tensor ops;
   * the depth trunk is evaluated once per distinct frame (the reference evaluates frame 1 of every
     triplet twice and frame 2 again in the second pass: 8 trunk runs, 4-5 distinct inputs);
-  * the loss branch (`train=True`, :67,:71-80) needs the VGG16-perceptual networks of loss_function.py,
-    which are out of this path's scope: with `train=True` the call raises unless a
-    `loss_fn(target, high_frames)` callable has been attached.  Inference (`train=False`) returns
-    `loss=None` exactly like the reference.
+  * the loss branch (`train=True`, :67,:71-80) is evaluated by loss.py (the reference's SR_loss / Flow_loss /
+    GetObjectsForOBJLoss with its own names) under no_grad on the device and returns the reference's 0-d CPU tensor, so the
+    reference driver's call `model(x, y, high_frame, estimated_image)` + `real_loss.data` (main.py:199-203) works as is.
+    What does NOT exist is autograd through the hand-written kernels: main.py:205-210 replaces `loss.data` by the running mean
+    and calls `loss.backward()` on a graph that starts at `output.cpu()`, which here carries no grad_fn -- training the SR
+    net needs backward kernels (not built).  Inference (`train=False`) returns `loss=None`.
 """
 from __future__ import annotations
 
@@ -30,6 +32,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .depth import DepthProjectionModule
+from .loss import Flow_loss, GetObjectsForOBJLoss, SR_loss, loss_calculate
 from .flownet import FlowProjectionModule
 from .sr import SRProjectionModule
 from .trunk_exec import FlowNet2Exec, HourglassExec, OSVOSExec, TrunkExecCache
@@ -53,11 +56,16 @@ class VSR(nn.Module):
         self.FlowModule = FlowProjectionModule().eval()
         self.DepthModule = DepthProjectionModule().eval()
         self.VOSModule = VOSProjectionModule().eval()
-        self.loss_fn: Optional[Callable] = None
+        # the train=True branch (video_super_resolution.py:19-21,67,71-80): same sub-module names as the reference
+        self.SR_loss = SR_loss().eval()
+        self.Flow_loss = Flow_loss().eval()
+        self.loss4object = GetObjectsForOBJLoss().eval()
+        self.loss_fn: Optional[Callable] = None   # optional override: loss_fn(target, high_frames) instead of loss_calculate
         # "fp16": the headline configuration -- SR stack on the MFMA path, guidance trunks on the hand-written NHWC fp16
         #         MFMA convolution (trunk_exec.py: BatchNorm folded, concatenations written in place, frames batched);
         # "fp32": SR stack in exact float32 kernels, trunks on stock float32 convolutions (the parity configuration).
         self.precision = "fp16"
+        self.share_planes = True   # evaluate the three LR-frame planes once per forward (both SR passes read them)
         self._flow_exec = TrunkExecCache(self.FlowModule.net, FlowNet2Exec)
         self._depth_exec = TrunkExecCache(self.DepthModule.model.netG, HourglassExec)
         self._vos_exec = TrunkExecCache(self.VOSModule.net, OSVOSExec)
@@ -66,10 +74,13 @@ class VSR(nn.Module):
         # main.py:178 calls model.train(), which would flip the frozen guidance networks (HG BatchNorm!)
         # out of eval mode; the reference's constructor intends them frozen (:16-21).  Keep them in eval.
         super().train(mode)
-        self.FlowModule.eval()
-        self.DepthModule.eval()
-        self.VOSModule.eval()
+        for m in (self.FlowModule, self.DepthModule, self.VOSModule, self.SR_loss, self.Flow_loss, self.loss4object):
+            m.eval()
         return self
+
+    def loss_calculate(self, target, outputs):
+        """video_super_resolution.py:71-80 (a 0-d CPU tensor, computed under no_grad like the reference)."""
+        return loss_calculate(self, target, outputs)
 
     # ------------------------------------------------------------------------------------------
     def _fast(self) -> bool:
@@ -156,22 +167,26 @@ class VSR(nn.Module):
             self.model.precision = self.precision
             # pass 1's frame is only ever read through the nearest x1/4 resize of :44, i.e. at its pixels (4i,4j): the SR
             # stack evaluates its tail and fusion MLP at exactly those (identical values, 1/16 of the tail work)
-            mid = self.model(torch.cat((frames, pics, depth, est), 0), decimate=True)[0]  # [3,h,w] = F.interpolate(out1,(h,w))[0]
+            # planes 0-2 (the LR frames) are the same in both SR calls (:40, :62): their FeedbackBlock maps are computed here
+            # and kept for pass 2 (sr.py:_forward_f16 `shared`; identical values, 3/8 of pass 2's trunk not recomputed)
+            shared = {"n": 3} if self.share_planes else None
+            mid = self.model(torch.cat((frames, pics, depth, est), 0), decimate=True, shared=shared)[0]  # [3,h,w] = F.interpolate(out1,(h,w))[0]
 
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
             mid_hw3 = mid.permute(1, 2, 0).contiguous()
             pics2, depth2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3))
             masked = torch.where(maskprocess(mask) != 0, torch.zeros_like(mid), mid).unsqueeze(0)  # :58-60
 
-            # ---- pass 2 SR (:62-64)
-            out = self.model(torch.cat((frames, pics2, depth2, masked), 0)).permute(0, 2, 3, 1)
+            x8 = torch.cat((frames, pics2, depth2, masked), 0)
+        # ---- pass 2 SR (:62-64): the reference's only call outside no_grad.  Under the caller's no_grad or in eval mode it
+        # runs the kernels; in training mode with autograd on it is differentiable (SRProjectionModule.forward)
+        out = self.model(x8, shared=shared).permute(0, 2, 3, 1)
+        with torch.no_grad():
             if high_frames is not None:
-                high_frames[1] = out  # :66
+                high_frames[1] = out.detach()  # :66
         loss = None
-        if train:
-            if self.loss_fn is None:
-                raise NotImplementedError("train=True needs the reference's VGG16-perceptual loss networks "
-                                          "(loss_function.py), which are outside this path; attach `loss_fn` "
-                                          "or call with train=False (inference returns loss=None like the reference)")
-            loss = self.loss_fn(target, high_frames)
+        if train:   # :67 `loss = self.loss_calculate(target, high_frames) if train else None`
+            if high_frames is None or target is None:
+                raise ValueError("train=True needs `target` [1,H,W,3] and `high_frames` [3,H,W,3] (video_super_resolution.py:67,71-80)")
+            loss = self.loss_fn(target, high_frames) if self.loss_fn is not None else self.loss_calculate(target, high_frames)
         return out, loss
