@@ -81,6 +81,35 @@ int vsr_flownet_warp_norms_f32(const float* x6, const float* flow, float* norm_f
  * values.  workspace: >= 16 bytes, zeroed by this call.  float64 math like numpy. */
 int vsr_flow2img_f32(const float* flow, float* out_hwc, void* workspace, int H, int W, vsr_stream_t stream);
 
+/* flow2img on channels 0,1 of an NHWC half map with `ld` channels per pixel (the fusion network's output as the MFMA
+ * convolution leaves it): same arithmetic as vsr_flow2img_f32 (half -> float is exact). */
+int vsr_flow2img_nhwc_f16(const void* flow_nhwc, int ld, float* out_hwc, void* workspace, int H, int W, vsr_stream_t stream);
+
+/* FlowNet2.forward's glue around the sub-networks (models.py:73-125), fused (fp16 configuration):
+ *  prepare_pairs   :74-79  rgb_mean over both frames of each pair, (x - mean) / 255, for B <= 4 pairs taken from `frames`
+ *                  [F,h,w,3] float32 by index, centre crop (y0, x0, H, W) = StaticCenterCrop (tools.py:8-14).  Writes x
+ *                  [B,6,H,W] float32, x6h [B,H,W,32] half (6 live) and both4 [2B,H,W,4] half (frame a of every pair, then
+ *                  frame b: FlowNetC's batched stem input); partial_ws: B*128*3 floats.
+ *  up_warp_concat16 :83-91,95-103  x4 upsample (bilinear != 0: nn.Upsample bilinear, else nearest) of a sub-network's flow
+ *                  (channels 0,1 of an NHWC half map) times `mul`, warp, concat -> [B,H,W,16] half (12 live channels).
+ *  fusion_input    :106-125  nearest x4 of FlowNetS#2's flow (x div_flow) and FlowNetSD's (/ div_flow), norms, brightness
+ *                  errors, concat with frame a -> [B,H,W,32] half (11 live channels). */
+int vsr_flownet_prepare_pairs(const float* frames, int F, int h, int w, const int* pair_a, const int* pair_b, int B, int y0, int x0, int H,
+                              int W, float* partial_ws, float* x, void* x6h, void* both4, vsr_stream_t stream);
+int vsr_flownet_up_warp_concat16_f16(const float* x6, const void* flow2_nhwc, int ld, int bilinear, float mul, float inv_div, void* out16,
+                                     int B, int H, int W, vsr_stream_t stream);
+int vsr_flownet_fusion_input_f16(const float* x6, const void* flow_sd2, int ld_sd, const void* flow_s22, int ld_s2, float div_flow,
+                                 void* out32, int B, int H, int W, vsr_stream_t stream);
+
+/* VSR.forward's plane assembly (video_super_resolution.py:33-40, :57-62) in one pass: frames [3,h,w,3], the two flow pictures
+ * [2,Hc,Wc,3] resized to h x w (nearest), depth = mean of the predictions (za, zb) and (zb, zc) replicated x3, estimate plane =
+ * est_chw [3,h,w] or frame 0 when null, zeroed where mask [h,w] != 0 (null: no mask) -> out8 [8,3,h,w]. */
+int vsr_assemble_planes_f32(const float* frames_nhwc, const float* pics_hwc, int Hc, int Wc, const float* za, const float* zb,
+                            const float* zc, const float* est_chw_or_null, const float* mask_or_null, float* out8, int h, int w,
+                            vsr_stream_t stream);
+/* :37 the previous output [1,H,W,3] at h x w (nearest) as a [3,h,w] plane and as an [h,w,3] frame. */
+int vsr_resize_estimate_f32(const float* prev_hwc, int H, int W, float* est_chw, float* est_hwc, int h, int w, vsr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * SRProjectionModule (SRProjectionModule.py:96-150, blocks.py:7-74): exact-fp32 building blocks.
  * NCHW float32, 32 feature channels ("nf"), x4 geometry (kernel 8, stride 4, pad 2).
@@ -240,6 +269,15 @@ int vsr_sr_tail3_fold_f16(const void* lr_a, const void* lr_b, const float* cmap_
 int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tail_params, const float* w1, const float* b1,
                               const float* w2, const float* b2, int nplanes, int hidden, float* out, int h, int w, int decimate,
                               vsr_stream_t stream);
+
+/* The fused up -> tran -> down stage for the scale-2 extension (k6 s2 p2; csrc/sr_utd_s2.hip): vsr_sr_utd_f16's x2 sibling.
+ * in / out [N,h,w,32] fp16 NHWC; blob = vsr_sr_utd_s2_blob_bytes() bytes packed by sr.py:pack_utd_s2_blob
+ * ([wave 4][tap 9][mt 2] deconv fragments, [wave 4][kernel-row slot 3][shift 3][mt 2] conv fragments, 2 fragments of the 1x1,
+ * then b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn as fp32); strips of vsr_sr_utd_s2_strip_width() = 30 LR columns. */
+size_t vsr_sr_utd_s2_blob_bytes(void);
+int vsr_sr_utd_s2_strip_width(void);
+int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                      vsr_stream_t stream);
 
 /* Tail of the fp16 path for upscale factors other than the reference's x4 (scale extension, see vsr_sr_deconv_f32):
  * conv_out 3x3 (32->3, :121-123,142) over the `out` DeconvBlock's HR map [N,H,W,32] fp16 -> raw planes [N,3,Ho,Wo] fp32

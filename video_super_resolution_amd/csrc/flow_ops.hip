@@ -220,12 +220,26 @@ __global__ void __launch_bounds__(256) k_correlation(const float* __restrict__ f
 // because python's max(-1, nan) is -1, flow_utils.py:15).  Pass 2: per-pixel colour in float64.
 // workspace: [0] = max radius bits (uint32 of a non-negative float), [1] = NaN flag.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_flow_maxrad(const float* __restrict__ flow, unsigned* __restrict__ ws,
-                                                        size_t hw) {
+// where a flow field comes from: planar float32 [2,H,W] (the reference's layout) or channels 0,1 of an NHWC half map
+// (the fusion network's output as the MFMA convolution leaves it; half -> float is exact)
+struct FlowPlanar {
+    const float* f;
+    size_t hw;
+    __device__ __forceinline__ void get(size_t p, float& u, float& v) const { u = f[p]; v = f[hw + p]; }
+};
+struct FlowNhwcHalf {
+    const _Float16* f;
+    int ld;
+    __device__ __forceinline__ void get(size_t p, float& u, float& v) const { u = (float)f[p * ld]; v = (float)f[p * ld + 1]; }
+};
+
+template <class FL>
+__global__ void __launch_bounds__(kBlock) k_flow_maxrad(const FL flow, unsigned* __restrict__ ws, size_t hw) {
     float m = 0.0f;
     unsigned nanflag = 0;
     for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < hw; p += (size_t)gridDim.x * kBlock) {
-        float u = flow[p], v = flow[hw + p];
+        float u, v;
+        flow.get(p, u, v);
         if (fabsf(u) > 1e7f || fabsf(v) > 1e7f) u = v = 0.0f;  // :8-12 (NaN compares false: stays NaN)
         const float r = sqrtf(u * u + v * v);
         if (r != r) nanflag = 1; else m = fmaxf(m, r);
@@ -249,12 +263,14 @@ __global__ void __launch_bounds__(kBlock) k_flow_maxrad(const float* __restrict_
 // 55-entry Middlebury wheel, flow_utils.py:65-112, as channel-major tables of the 0..255 values.
 __constant__ double c_wheel[3][55];
 
-__global__ void __launch_bounds__(kBlock) k_flow_color(const float* __restrict__ flow, const unsigned* __restrict__ ws,
+template <class FL>
+__global__ void __launch_bounds__(kBlock) k_flow_color(const FL flow, const unsigned* __restrict__ ws,
                                                        float* __restrict__ out, size_t hw) {
     const float maxrad = ws[1] ? -1.0f : __uint_as_float(ws[0]);  // max(-1, np.max(rad)) with rad >= 0
     const double eps = 2.220446049250313e-16;                     // np.finfo(float).eps
     for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < hw; p += (size_t)gridDim.x * kBlock) {
-        float u = flow[p], v = flow[hw + p];
+        float u, v;
+        flow.get(p, u, v);
         const bool unknown = fabsf(u) > 1e7f || fabsf(v) > 1e7f;
         if (unknown) u = v = 0.0f;
         // float32 divide, then float64 (+eps): numpy >= 2 promotion of `u / maxrad + eps`
@@ -286,10 +302,10 @@ __global__ void __launch_bounds__(kBlock) k_flow_color(const float* __restrict__
     }
 }
 
-bool g_wheel_ready = false;
+unsigned long long g_wheel_devs = 0;   // __constant__ memory is per device: one bit per device ordinal
 
 int upload_wheel() {
-    if (g_wheel_ready) return VSR_OK;
+    if (vsr::device_marked(g_wheel_devs)) return VSR_OK;
     static double wheel[3][55];
     // segment lengths RY=15, YG=6, GC=4, CB=11, BM=13, MR=6 (flow_utils.py:70-76); in every segment one
     // channel is saturated and one ramps floor(255*i/n) up or down.
@@ -307,9 +323,246 @@ int upload_wheel() {
         }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_wheel), wheel, sizeof(wheel)) != hipSuccess)
         return vsr::fail(VSR_E_LAUNCH, "flow2img: colour wheel upload failed");
-    g_wheel_ready = true;
+    vsr::mark_device(g_wheel_devs);
     return VSR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Frame glue of FlowNet2.forward fused around the kernels above (round 2): every launch below stands for a chain of
+// stock elementwise / cat / interpolate / layout launches that sat on the critical path between two sub-networks.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h8g __attribute__((ext_vector_type(8)));
+typedef _Float16 h4g __attribute__((ext_vector_type(4)));
+
+struct PairIdx {
+    int a[4], b[4];   // frame indices of up to four pairs
+};
+
+// models.py:74: rgb_mean over both frames and all (cropped) pixels, per pair and colour.  Stage 1: per-workgroup sums
+// in a fixed order (grid (kSumBlocks, B)); stage 2 (inside k_pair_normalise) adds the kSumBlocks partials in order.
+constexpr int kSumBlocks = 128;
+__global__ void __launch_bounds__(kBlock) k_pair_sums(const float* __restrict__ frames, PairIdx idx, int h, int w, int y0, int x0,
+                                                      int H, int W, float* __restrict__ partial) {
+    const int b = blockIdx.y;
+    const size_t hw = (size_t)H * W, fstride = (size_t)h * w * 3;
+    const float* fa = frames + (size_t)idx.a[b] * fstride;
+    const float* fb = frames + (size_t)idx.b[b] * fstride;
+    float s[3] = {0.0f, 0.0f, 0.0f};
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < hw; p += (size_t)gridDim.x * kBlock) {
+        const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+        const size_t o = ((size_t)(y0 + y) * w + x0 + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s[c] += fa[o + c]; s[c] += fb[o + c]; }
+    }
+    __shared__ float sm[3][kBlock];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sm[c][threadIdx.x] = s[c];
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sm[c][threadIdx.x] += sm[c][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) partial[((size_t)b * kSumBlocks + blockIdx.x) * 3 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
+// models.py:74-79: x = (inputs - rgb_mean) / 255, the two frames of a pair on the channel axis.  Emits the three forms
+// the sub-networks read: x [B,6,H,W] float (warp kernels), x6h [B,H,W,32] half (FlowNetSD conv0; 6 live channels) and
+// both4 [2B,H,W,4] half (FlowNetC's batched two-frame stem: frame a of every pair, then frame b).
+__global__ void __launch_bounds__(kBlock) k_pair_normalise(const float* __restrict__ frames, PairIdx idx, int h, int w, int y0, int x0,
+                                                           int H, int W, const float* __restrict__ partial, float* __restrict__ x,
+                                                           _Float16* __restrict__ x6h, _Float16* __restrict__ both4, int B) {
+    const int b = blockIdx.y;
+    __shared__ float mean[3];
+    if (threadIdx.x < 3) {
+        float t = 0.0f;
+        for (int k = 0; k < kSumBlocks; ++k) t += partial[((size_t)b * kSumBlocks + k) * 3 + threadIdx.x];
+        mean[threadIdx.x] = t / (float)(2 * (size_t)H * W);
+    }
+    __syncthreads();
+    const size_t hw = (size_t)H * W, fstride = (size_t)h * w * 3;
+    const float* fa = frames + (size_t)idx.a[b] * fstride;
+    const float* fb = frames + (size_t)idx.b[b] * fstride;
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < hw; p += (size_t)gridDim.x * kBlock) {
+        const int y = (int)(p / W), xx = (int)(p - (size_t)y * W);
+        const size_t o = ((size_t)(y0 + y) * w + x0 + xx) * 3;
+        float v[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = (fa[o + c] - mean[c]) / 255.0f;
+            v[3 + c] = (fb[o + c] - mean[c]) / 255.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) x[((size_t)b * 6 + c) * hw + p] = v[c];
+        _Float16* xr = x6h + ((size_t)b * hw + p) * 32;
+        const h8g lo = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)0.0f, (_Float16)0.0f};
+        const h8g z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+        *reinterpret_cast<h8g*>(xr) = lo;
+        *reinterpret_cast<h8g*>(xr + 8) = z;
+        *reinterpret_cast<h8g*>(xr + 16) = z;
+        *reinterpret_cast<h8g*>(xr + 24) = z;
+        *reinterpret_cast<h4g*>(both4 + ((size_t)b * hw + p) * 4) = h4g{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)0.0f};
+        *reinterpret_cast<h4g*>(both4 + ((size_t)(B + b) * hw + p) * 4) = h4g{(_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)0.0f};
+    }
+}
+
+// x4 upsampling of a sub-network's quarter-resolution flow (channels 0,1 of an NHWC half map with `ld` channels) at HR pixel
+// (y, x): nn.Upsample(scale_factor=4, mode='bilinear') (align_corners False; models.py:38,44) or 'nearest' (:53-54), as
+// ATen's upsample kernels form them in float.
+__device__ __forceinline__ void flow_up4(const _Float16* __restrict__ fl, int ld, int h4, int w4, int y, int x, int bilinear,
+                                         float& u, float& v) {
+    if (!bilinear) {
+        const int ys = min((int)floorf((float)y * 0.25f), h4 - 1), xs = min((int)floorf((float)x * 0.25f), w4 - 1);
+        const _Float16* p = fl + ((size_t)ys * w4 + xs) * ld;
+        u = (float)p[0];
+        v = (float)p[1];
+        return;
+    }
+    float sy = ((float)y + 0.5f) * 0.25f - 0.5f, sx = ((float)x + 0.5f) * 0.25f - 0.5f;
+    sy = sy < 0.0f ? 0.0f : sy;
+    sx = sx < 0.0f ? 0.0f : sx;
+    const int ya = (int)sy, xa = (int)sx;
+    const int yb = ya + (ya < h4 - 1 ? 1 : 0), xb = xa + (xa < w4 - 1 ? 1 : 0);
+    const float ly = sy - (float)ya, lx = sx - (float)xa, ly0 = 1.0f - ly, lx0 = 1.0f - lx;
+    const _Float16* p00 = fl + ((size_t)ya * w4 + xa) * ld;
+    const _Float16* p01 = fl + ((size_t)ya * w4 + xb) * ld;
+    const _Float16* p10 = fl + ((size_t)yb * w4 + xa) * ld;
+    const _Float16* p11 = fl + ((size_t)yb * w4 + xb) * ld;
+    u = ly0 * (lx0 * (float)p00[0] + lx * (float)p01[0]) + ly * (lx0 * (float)p10[0] + lx * (float)p11[0]);
+    v = ly0 * (lx0 * (float)p00[1] + lx * (float)p01[1]) + ly * (lx0 * (float)p10[1] + lx * (float)p11[1]);
+}
+
+// models.py:83-91 / :95-103 in one pass: upsample the sub-network's flow (x div_flow), warp frame b, concatenate
+// (x, warped, flow / div_flow, |a - warped|) -- straight into the NHWC half map [B,H,W,16] FlowNetS's pair-convolution stem
+// reads (12 live channels).  Replaces slice/permute/float, interpolate, scale, k_warp_concat and the layout conversion.
+__global__ void __launch_bounds__(kBlock) k_flow_up_warp_concat16(const float* __restrict__ x6, const _Float16* __restrict__ flow2, int ld,
+                                                                  int bilinear, float mul, float inv_div, _Float16* __restrict__ out16,
+                                                                  int H, int W) {
+    const int b = blockIdx.y;
+    const size_t hw = (size_t)H * W;
+    const int h4 = H / 4, w4 = W / 4;
+    const float* xb = x6 + (size_t)b * 6 * hw;
+    const _Float16* fl = flow2 + (size_t)b * h4 * w4 * ld;
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < hw; p += (size_t)gridDim.x * kBlock) {
+        const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+        float u, v;
+        flow_up4(fl, ld, h4, w4, y, x, bilinear, u, v);
+        const float dx = u * mul, dy = v * mul;
+        const Bilerp s = bilerp_setup(x, y, dx, dy, H, W);
+        float acc = 0.0f, a[3], bb[3], wv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[c] = xb[(size_t)c * hw + p];
+            bb[c] = xb[(size_t)(3 + c) * hw + p];
+            wv[c] = bilerp_sample(xb + (size_t)(3 + c) * hw, s, W);
+            const float d = a[c] - wv[c];
+            acc += d * d;
+        }
+        _Float16* o = out16 + ((size_t)b * hw + p) * 16;
+        *reinterpret_cast<h8g*>(o) = h8g{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)bb[0], (_Float16)bb[1], (_Float16)bb[2],
+                                         (_Float16)wv[0], (_Float16)wv[1]};
+        *reinterpret_cast<h8g*>(o + 8) = h8g{(_Float16)wv[2], (_Float16)(dx * inv_div), (_Float16)(dy * inv_div), (_Float16)sqrtf(acc),
+                                             (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+    }
+}
+
+// models.py:106-125 in one pass: the two nearest-upsampled flows (FlowNetS #2 x div_flow, FlowNetSD / div_flow), their norms,
+// the two brightness errors of the warps, concatenated with frame a -- straight into the NHWC half map [B,H,W,32] the fusion
+// network reads (11 live channels: img0 3, flow_sd 2, flow_s2 2, |flow_sd|, |flow_s2|, diff_sd, diff_s2).
+__global__ void __launch_bounds__(kBlock) k_flow_fusion_input(const float* __restrict__ x6, const _Float16* __restrict__ flow_sd2, int ld_sd,
+                                                              const _Float16* __restrict__ flow_s22, int ld_s2, float div_flow,
+                                                              _Float16* __restrict__ out32, int H, int W) {
+    const int b = blockIdx.y;
+    const size_t hw = (size_t)H * W;
+    const int h4 = H / 4, w4 = W / 4;
+    const float* xb = x6 + (size_t)b * 6 * hw;
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < hw; p += (size_t)gridDim.x * kBlock) {
+        const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+        float fl[2][2], nrm[2], dif[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float u, v;
+            flow_up4((k == 0 ? flow_sd2 + (size_t)b * h4 * w4 * ld_sd : flow_s22 + (size_t)b * h4 * w4 * ld_s2), k == 0 ? ld_sd : ld_s2, h4, w4,
+                     y, x, 0, u, v);
+            const float dx = k == 0 ? u / div_flow : u * div_flow, dy = k == 0 ? v / div_flow : v * div_flow;
+            const Bilerp s = bilerp_setup(x, y, dx, dy, H, W);
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float d = xb[(size_t)c * hw + p] - bilerp_sample(xb + (size_t)(3 + c) * hw, s, W);
+                acc += d * d;
+            }
+            float f2 = 0.0f;
+            f2 += dx * dx;
+            f2 += dy * dy;
+            fl[k][0] = dx; fl[k][1] = dy; nrm[k] = sqrtf(f2); dif[k] = sqrtf(acc);
+        }
+        _Float16* o = out32 + ((size_t)b * hw + p) * 32;
+        const h8g z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+        *reinterpret_cast<h8g*>(o) = h8g{(_Float16)xb[p], (_Float16)xb[hw + p], (_Float16)xb[2 * hw + p], (_Float16)fl[0][0], (_Float16)fl[0][1],
+                                         (_Float16)fl[1][0], (_Float16)fl[1][1], (_Float16)nrm[0]};
+        *reinterpret_cast<h8g*>(o + 8) = h8g{(_Float16)nrm[1], (_Float16)dif[0], (_Float16)dif[1], (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f,
+                                             (_Float16)0.0f, (_Float16)0.0f};
+        *reinterpret_cast<h8g*>(o + 16) = z;
+        *reinterpret_cast<h8g*>(o + 24) = z;
+    }
+}
+
+// video_super_resolution.py:33-40 / :57-62: the 8-plane SR input [8,3,h,w] in one pass -- the three frames (NHWC -> NCHW),
+// the two flow pictures resized to h x w (default-mode `interpolate`: nearest, ATen's index rule), the two depth planes
+// (mean of two single-frame predictions, DepthProjectionModule.py:16, replicated to three channels by maskprocess), and the
+// estimate plane: frame 0 (first call), a given [3,h,w] plane, or the pass-1 frame with the VOS mask applied (:58-60).
+__global__ void __launch_bounds__(kBlock) k_assemble_planes(const float* __restrict__ frames, const float* __restrict__ pics, int Hc, int Wc,
+                                                            const float* __restrict__ za, const float* __restrict__ zb,
+                                                            const float* __restrict__ zc, const float* __restrict__ est,
+                                                            const float* __restrict__ mask, float* __restrict__ out, int h, int w) {
+    const size_t hw = (size_t)h * w;
+    const float sy = (float)Hc / (float)h, sx = (float)Wc / (float)w;
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < hw; p += (size_t)gridDim.x * kBlock) {
+        const int y = (int)(p / w), x = (int)(p - (size_t)y * w);
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[((size_t)f * 3 + c) * hw + p] = frames[((size_t)f * hw + p) * 3 + c];
+        const int ys = min((int)floorf((float)y * sy), Hc - 1), xs = min((int)floorf((float)x * sx), Wc - 1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[((size_t)(3 + k) * 3 + c) * hw + p] = pics[(((size_t)k * Hc + ys) * Wc + xs) * 3 + c];
+        const float d0 = (za[p] + zb[p]) / 2.0f, d1 = (zb[p] + zc[p]) / 2.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            out[((size_t)5 * 3 + c) * hw + p] = d0;
+            out[((size_t)6 * 3 + c) * hw + p] = d1;
+        }
+        const bool masked = mask && mask[p] != 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float e = est ? est[(size_t)c * hw + p] : frames[p * 3 + c];
+            out[((size_t)7 * 3 + c) * hw + p] = masked ? 0.0f : e;
+        }
+    }
+}
+
+// video_super_resolution.py:37: the previous output [1,H,W,3] at h x w (nearest), as the NCHW plane the SR input takes and
+// as the HWC frame the guidance networks take.
+__global__ void __launch_bounds__(kBlock) k_resize_estimate(const float* __restrict__ prev, int H, int W, float* __restrict__ est_chw,
+                                                            float* __restrict__ est_hwc, int h, int w) {
+    const size_t hw = (size_t)h * w;
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < hw; p += (size_t)gridDim.x * kBlock) {
+        const int y = (int)(p / w), x = (int)(p - (size_t)y * w);
+        const int ys = min((int)floorf((float)y * sy), H - 1), xs = min((int)floorf((float)x * sx), W - 1);
+        const float* s = prev + ((size_t)ys * W + xs) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            est_chw[(size_t)c * hw + p] = s[c];
+            est_hwc[p * 3 + c] = s[c];
+        }
+    }
+}
+
 
 inline unsigned grid_for(size_t n) {
     size_t g = (n + kBlock - 1) / kBlock;
@@ -400,12 +653,85 @@ int vsr_flow2img_f32(const float* flow, float* out_hwc, void* workspace, int H, 
     const size_t hw = (size_t)H * W;
     if (hipMemsetAsync(workspace, 0, 16, vsr::S(stream)) != hipSuccess) return vsr::fail(VSR_E_LAUNCH, "flow2img: memset");
     const unsigned g_max = grid_for(hw) < 256u ? grid_for(hw) : 256u;   // grid-stride: few workgroups, few atomics
-    hipLaunchKernelGGL(k_flow_maxrad, dim3(g_max), dim3(kBlock), 0, vsr::S(stream), flow, (unsigned*)workspace, hw);
+    const FlowPlanar fl{flow, hw};
+    hipLaunchKernelGGL(k_flow_maxrad<FlowPlanar>, dim3(g_max), dim3(kBlock), 0, vsr::S(stream), fl, (unsigned*)workspace, hw);
     rc = vsr::launched("flow2img/maxrad");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_flow_color, dim3(grid_for(hw)), dim3(kBlock), 0, vsr::S(stream), flow,
+    hipLaunchKernelGGL(k_flow_color<FlowPlanar>, dim3(grid_for(hw)), dim3(kBlock), 0, vsr::S(stream), fl,
                        (const unsigned*)workspace, out_hwc, hw);
     return vsr::launched("flow2img/color");
+}
+
+int vsr_flow2img_nhwc_f16(const void* flow_nhwc, int ld, float* out_hwc, void* workspace, int H, int W, vsr_stream_t stream) {
+    VSR_REQUIRE(flow_nhwc && out_hwc && workspace, "flow2img_nhwc: null pointer");
+    VSR_REQUIRE(H > 0 && W > 0 && ld >= 2, "flow2img_nhwc: bad shape");
+    int rc = upload_wheel();
+    if (rc) return rc;
+    const size_t hw = (size_t)H * W;
+    if (hipMemsetAsync(workspace, 0, 16, vsr::S(stream)) != hipSuccess) return vsr::fail(VSR_E_LAUNCH, "flow2img: memset");
+    const unsigned g_max = grid_for(hw) < 256u ? grid_for(hw) : 256u;
+    const FlowNhwcHalf fl{(const _Float16*)flow_nhwc, ld};
+    hipLaunchKernelGGL(k_flow_maxrad<FlowNhwcHalf>, dim3(g_max), dim3(kBlock), 0, vsr::S(stream), fl, (unsigned*)workspace, hw);
+    rc = vsr::launched("flow2img_nhwc/maxrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_flow_color<FlowNhwcHalf>, dim3(grid_for(hw)), dim3(kBlock), 0, vsr::S(stream), fl,
+                       (const unsigned*)workspace, out_hwc, hw);
+    return vsr::launched("flow2img_nhwc/color");
+}
+
+int vsr_flownet_prepare_pairs(const float* frames, int F, int h, int w, const int* pair_a, const int* pair_b, int B, int y0, int x0, int H,
+                              int W, float* partial_ws, float* x, void* x6h, void* both4, vsr_stream_t stream) {
+    VSR_REQUIRE(frames && pair_a && pair_b && partial_ws && x && x6h && both4, "flownet_prepare_pairs: null pointer");
+    VSR_REQUIRE(B > 0 && B <= 4 && F > 0 && h > 0 && w > 0 && H > 0 && W > 0 && y0 >= 0 && x0 >= 0 && y0 + H <= h && x0 + W <= w,
+                "flownet_prepare_pairs: bad shape / crop (at most four pairs per call)");
+    PairIdx idx;
+    for (int b = 0; b < 4; ++b) {
+        idx.a[b] = b < B ? pair_a[b] : 0;
+        idx.b[b] = b < B ? pair_b[b] : 0;
+        VSR_REQUIRE(idx.a[b] >= 0 && idx.a[b] < F && idx.b[b] >= 0 && idx.b[b] < F, "flownet_prepare_pairs: frame index out of range");
+    }
+    hipLaunchKernelGGL(k_pair_sums, dim3(kSumBlocks, B), dim3(kBlock), 0, vsr::S(stream), frames, idx, h, w, y0, x0, H, W, partial_ws);
+    int rc = vsr::launched("flownet_prepare_pairs/sums");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pair_normalise, dim3(grid_for((size_t)H * W), B), dim3(kBlock), 0, vsr::S(stream), frames, idx, h, w, y0, x0, H, W,
+                       partial_ws, x, (_Float16*)x6h, (_Float16*)both4, B);
+    return vsr::launched("flownet_prepare_pairs/normalise");
+}
+
+int vsr_flownet_up_warp_concat16_f16(const float* x6, const void* flow2_nhwc, int ld, int bilinear, float mul, float inv_div, void* out16,
+                                     int B, int H, int W, vsr_stream_t stream) {
+    VSR_REQUIRE(x6 && flow2_nhwc && out16, "up_warp_concat16: null pointer");
+    VSR_REQUIRE(B > 0 && H >= 4 && W >= 4 && (H & 3) == 0 && (W & 3) == 0 && ld >= 2, "up_warp_concat16: bad shape (H, W multiples of 4)");
+    hipLaunchKernelGGL(k_flow_up_warp_concat16, dim3(grid_for((size_t)H * W), B), dim3(kBlock), 0, vsr::S(stream), x6,
+                       (const _Float16*)flow2_nhwc, ld, bilinear, mul, inv_div, (_Float16*)out16, H, W);
+    return vsr::launched("up_warp_concat16");
+}
+
+int vsr_flownet_fusion_input_f16(const float* x6, const void* flow_sd2, int ld_sd, const void* flow_s22, int ld_s2, float div_flow,
+                                 void* out32, int B, int H, int W, vsr_stream_t stream) {
+    VSR_REQUIRE(x6 && flow_sd2 && flow_s22 && out32, "fusion_input: null pointer");
+    VSR_REQUIRE(B > 0 && H >= 4 && W >= 4 && (H & 3) == 0 && (W & 3) == 0 && ld_sd >= 2 && ld_s2 >= 2, "fusion_input: bad shape");
+    hipLaunchKernelGGL(k_flow_fusion_input, dim3(grid_for((size_t)H * W), B), dim3(kBlock), 0, vsr::S(stream), x6,
+                       (const _Float16*)flow_sd2, ld_sd, (const _Float16*)flow_s22, ld_s2, div_flow, (_Float16*)out32, H, W);
+    return vsr::launched("fusion_input");
+}
+
+int vsr_assemble_planes_f32(const float* frames_nhwc, const float* pics_hwc, int Hc, int Wc, const float* za, const float* zb,
+                            const float* zc, const float* est_chw_or_null, const float* mask_or_null, float* out8, int h, int w,
+                            vsr_stream_t stream) {
+    VSR_REQUIRE(frames_nhwc && pics_hwc && za && zb && zc && out8, "assemble_planes: null pointer");
+    VSR_REQUIRE(h > 0 && w > 0 && Hc > 0 && Wc > 0, "assemble_planes: bad shape");
+    hipLaunchKernelGGL(k_assemble_planes, dim3(grid_for((size_t)h * w)), dim3(kBlock), 0, vsr::S(stream), frames_nhwc, pics_hwc, Hc, Wc,
+                       za, zb, zc, est_chw_or_null, mask_or_null, out8, h, w);
+    return vsr::launched("assemble_planes");
+}
+
+int vsr_resize_estimate_f32(const float* prev_hwc, int H, int W, float* est_chw, float* est_hwc, int h, int w, vsr_stream_t stream) {
+    VSR_REQUIRE(prev_hwc && est_chw && est_hwc, "resize_estimate: null pointer");
+    VSR_REQUIRE(h > 0 && w > 0 && H > 0 && W > 0, "resize_estimate: bad shape");
+    hipLaunchKernelGGL(k_resize_estimate, dim3(grid_for((size_t)h * w)), dim3(kBlock), 0, vsr::S(stream), prev_hwc, H, W, est_chw,
+                       est_hwc, h, w);
+    return vsr::launched("resize_estimate");
 }
 
 }  // extern "C"

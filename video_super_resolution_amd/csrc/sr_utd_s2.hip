@@ -1,0 +1,280 @@
+// sr_utd_s2.hip -- k_utd_s2: the fused  up (deconv k6 s2 p2 + PReLU) -> tran (1x1 + PReLU) -> down (conv k6 s2 p2 + PReLU)
+// stage of the FeedbackBlock for the scale-2 extension (SRFBN's (6, 2, 2) row in place of the reference's literal (8, 4, 2),
+// SRProjectionModule.py:10-12,62-65,77-80 under the zero-fill semantic).  The x2 feature map (4.25 GB per tensor at LR
+// 1080x1920 x 8 planes in fp16, 17 GB at 4K -> 8K) never leaves the registers; the unfused build (sr.py:_UnfusedStage: phase
+// deconvolutions, in-place 1x1, strided convolution on the generic kernel) moves it through HBM three times and is kept as
+// the cross-check.
+//
+// Design = k_utd3's register hand-over (sr_utd3.hip) with the x2 geometry:
+//   * a workgroup of 4 waves marches down a strip of 30 LR columns; step m handles the HR row PAIR m (rows 2m, 2m+1).
+//   * wave (r, c) = (HR row parity, HR column parity) deconvolves HR row 2m+r at the 32 columns 2q+c, q = x0-1 .. x0+30:
+//     HR (2m+r, 2q+c) = b + sum_{dy,dx<3} W_up[ky = r+2dy][kx = c+2dx] . LR(m+1-dy, q+1-dx)     -> 9 taps x 2 x 2 MFMA 16x16x32
+//     (K = 32 channels per tap, B operand = LR pixels from a 4-row LDS ring, A = weights in registers), PReLU, the 1x1 with the
+//     accumulator tile re-used in place as its B operand (channel order permuted consistently in the packed weights), PReLU.
+//   * the same wave convolves its tile as it lies in registers: HR row 2m+r is kernel row r, r+2, r+4 of the output rows m+1,
+//     m, m-1 (three accumulator sets in flight), and HR column 2q+c is kernel column c+2s of output pixel j = q+1-s, i.e. the
+//     tile shifted by s = 0, 1, 2 lanes (DPP row shifts; lane 15 / 14 of pixel tile 0 take lanes 0 / 1 of tile 1).
+//   * the output row whose last kernel row was just added leaves as 4 partial tiles (one per wave) through LDS, summed in a
+//     fixed order + bias + PReLU by all 256 threads.  One barrier per step.
+// Per wave and step: 36 + 4 + 36 MFMA against ~48 activation VALU + 24 DPP: a better MFMA : VALU ratio than the x4 kernel
+// (144 : 316), and 38 weight fragments (152 registers) instead of 64, so two workgroups share a CU.
+#include "sr_f16_common.h"
+
+namespace {
+
+constexpr int S2_TX = 30;                    // LR output columns per strip (32 deconv positions = 2 MFMA pixel tiles)
+constexpr int S2_LRC = 34;                   // staged LR columns x0-2 .. x0+31
+constexpr int S2_LR_SLOT = S2_LRC * 64;
+constexpr int S2_LR_BYTES = 4 * S2_LR_SLOT;  // rows m-1, m, m+1 + the row being loaded
+constexpr int S2_PART_W = 32 * PART_PX_PITCH;
+constexpr int S2_PART_BUF = 4 * S2_PART_W;
+constexpr int S2_BIAS_BYTES = 256;           // b_up[32], b_dt[32] fp32 (read at use: the kernel sits at the 256-register line)
+constexpr int S2_LDS = S2_LR_BYTES + 2 * S2_PART_BUF + S2_BIAS_BYTES;
+
+constexpr int S2_BLOB_UP = 0;                           // [wave 4][tap 9 = dy*3+dx][mt 2][lane 64][8] fp16
+constexpr int S2_BLOB_DN = 4 * 18 * 1024;               // [wave 4][kernel-row slot 3][shift 3][mt 2][lane 64][8] fp16
+constexpr int S2_BLOB_DT = S2_BLOB_DN + 4 * 18 * 1024;  // [mt 2][lane 64][8] fp16
+constexpr int S2_BLOB_F32 = S2_BLOB_DT + 2 * 1024;      // b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn
+constexpr int S2_BLOB_BYTES = S2_BLOB_F32 + 512;
+
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+
+// tile pair T (pixel tiles 0, 1: deconv positions n = 16 nt + lane&15) moved down SH lanes: B[nt] lane <- position n + SH
+template <int SH>
+__device__ __forceinline__ void shift_tiles(const h8 (&T)[2], h8 (&B)[2]) {
+    if (SH == 0) {
+        B[0] = T[0];
+        B[1] = T[1];
+        return;
+    }
+    const u4v v0 = __builtin_bit_cast(u4v, T[0]), v1 = __builtin_bit_cast(u4v, T[1]);
+    u4v b0, b1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // lanes 16-SH .. 15 of tile 0 take lanes 0 .. SH-1 of tile 1 (row_ror:16-SH), the others their right neighbour (row_shl:SH)
+        const unsigned ror = (unsigned)__builtin_amdgcn_mov_dpp((int)v1[q], 0x120 + (16 - SH), 0xF, 0xF, false);
+        b0[q] = (unsigned)__builtin_amdgcn_update_dpp((int)ror, (int)v0[q], 0x100 + SH, 0xF, 0xF, false);
+        b1[q] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v1[q], 0x100 + SH, 0xF, 0xF, true);   // positions >= 32: zeros (discarded outputs)
+    }
+    B[0] = __builtin_bit_cast(h8, b0);
+    B[1] = __builtin_bit_cast(h8, b1);
+}
+
+template <bool ALLMAX>
+__global__ void __launch_bounds__(256, 2)
+k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _Float16* __restrict__ out, int h, int w,
+         int rows_per_seg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const lrr = smem;
+    unsigned char* const part = smem + S2_LR_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int r = wv >> 1, c = wv & 1;          // HR row parity / HR column parity this wave owns
+    const int x0 = blockIdx.x * S2_TX;
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_seg;
+    const int r1 = min(h, r0 + rows_per_seg);
+    if (r0 >= r1) return;   // uniform per workgroup
+
+    // ---- weights -> registers, once per workgroup
+    h8 Aup[9][2], Adn[3][3][2], adt[2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            Aup[t][mt] = *reinterpret_cast<const h8*>(blob + S2_BLOB_UP + (((wv * 9 + t) * 2 + mt) * 64 + lane) * 16);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                Adn[k][s][mt] = *reinterpret_cast<const h8*>(blob + S2_BLOB_DN + ((((wv * 3 + k) * 3 + s) * 2 + mt) * 64 + lane) * 16);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) adt[mt] = *reinterpret_cast<const h8*>(blob + S2_BLOB_DT + (mt * 64 + lane) * 16);
+    const float* fpar = reinterpret_cast<const float*>(blob + S2_BLOB_F32);
+    float* const bias_s = reinterpret_cast<float*>(smem + S2_LR_BYTES + 2 * S2_PART_BUF);
+    if (tid < 64) bias_s[tid] = fpar[tid];   // (visible after the prologue's barrier)
+    // this lane's accumulator rows are channels {4g..4g+3} of tile mt
+    auto bup = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f4*>(bias_s + 16 * mt + 4 * g); };
+    auto bdt = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f4*>(bias_s + 32 + 16 * mt + 4 * g); };
+    const float a_up = fpar[96], a_dt = fpar[97], a_dn = fpar[98];
+    const h2 a_up2 = {(_Float16)a_up, (_Float16)a_up}, a_dt2 = {(_Float16)a_dt, (_Float16)a_dt};
+    const bool up_max = ALLMAX || a_up <= 1.0f, dt_max = ALLMAX || a_dt <= 1.0f;
+
+    // ---- LR loader: 34 columns x 4 chunks of 16 bytes per row; out-of-image pieces read zeros (out-of-range buffer offset)
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    const bool lr_loader = tid < S2_LRC * 4;
+    const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 2 + lr_px;
+    const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
+    const int lr_st = lr_off(lr_px, lr_ch);
+    auto fetch_lr = [&](int row) __attribute__((always_inline)) -> u4v {
+        const unsigned off = (lr_col_ok && row >= 0 && row < h) ? (unsigned)(((((size_t)n * h + row) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
+        return __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+    };
+    auto lr_slot = [&](int row) __attribute__((always_inline)) { return ((row + 4) & 3) * S2_LR_SLOT; };   // (row >= -3)
+
+    // ---- reduce role: output pixel tid>>3 (32 of them, 30 live), channels 4*(tid&7) .. +3
+    const int rj = tid >> 3, rc4 = tid & 7;
+    const f4 bdn = *reinterpret_cast<const f4*>(fpar + 64 + 4 * rc4);
+    const bool red_ok = (rj < S2_TX) && (x0 + rj < w);
+    const __amdgpu_buffer_rsrc_t out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const int part_wr = wv * S2_PART_W + l15 * PART_PX_PITCH + 4 * g * 4;   // + 64 mt + 16 nt PART_PX_PITCH
+    const int part_rd = rj * PART_PX_PITCH + rc4 * 16;                       // + k S2_PART_W
+    auto reduce_store = [&](int i, const unsigned char* pbase) __attribute__((always_inline)) {
+        f4 s = *reinterpret_cast<const f4*>(pbase + part_rd);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) s += *reinterpret_cast<const f4*>(pbase + part_rd + k * S2_PART_W);
+        s += bdn;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = s[e] >= 0.0f ? s[e] : s[e] * a_dn;
+        const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{v[0], v[1]}, h2));
+        const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{v[2], v[3]}, h2));
+        const unsigned off = red_ok ? (unsigned)(((((size_t)n * h + i) * w + x0 + rj) * NF + 4 * rc4) * 2) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b64(u2v{lo, hi}, out_rsrc, off, 0, 0);
+    };
+
+    // ---- prologue: LR rows r0-2, r0-1, r0 (the first pair, m = r0-1, reads them)
+    if (lr_loader) {
+        *reinterpret_cast<u4v*>(lrr + lr_slot(r0 - 2) + lr_st) = fetch_lr(r0 - 2);
+        *reinterpret_cast<u4v*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
+        *reinterpret_cast<u4v*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
+    }
+    __syncthreads();
+
+    // accumulators of the three output rows in flight: [0] row m-1 (gets its last kernel row in step m), [1] row m, [2] row m+1
+    f4 acc[3][2][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[a][mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // lanes whose HR column 2q+c lies outside the image hold the conv's zero padding
+    bool col_ok[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int X = 2 * (x0 - 1 + 16 * nt + l15) + c;
+        col_ok[nt] = X >= 0 && X < 2 * w;
+    }
+
+    for (int m = r0 - 1; m <= r1; ++m) {
+        const u4v nxt = fetch_lr(m + 2);
+        if (m >= 0 && m < h) {   // (uniform) pairs outside the image are zero padding: nothing to add
+            // ---- deconv of HR row 2m+r, columns 2q+c: 9 taps
+            f4 d[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) d[mt][nt] = bup(mt);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const unsigned char* rowp = lrr + lr_slot(m + 1 - dy);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    h8 B[2];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) B[nt] = *reinterpret_cast<const h8*>(rowp + lr_off(16 * nt + l15 + 2 - dx, g));
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) d[mt][nt] = mfma16(Aup[dy * 3 + dx][mt], B[nt], d[mt][nt]);
+                }
+            }
+            // ---- PReLU -> 1x1 (accumulator tile as B operand) -> PReLU
+            h8 T[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const h8 a1 = act_pack(d[0][nt], d[1][nt], a_up2, up_max);
+                const f4 e0 = mfma16(adt[0], a1, bdt(0));
+                const f4 e1 = mfma16(adt[1], a1, bdt(1));
+                h8 t = act_pack(e0, e1, a_dt2, dt_max);
+                if (!col_ok[nt]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (_Float16)0.0f;
+                }
+                T[nt] = t;
+            }
+            // ---- down conv from registers: kernel rows r, r+2, r+4 (output rows m+1, m, m-1), kernel columns c + 2 s
+            h8 B[2];
+            shift_tiles<0>(T, B);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[2 - k][mt][nt] = mfma16(Adn[k][0][mt], B[nt], acc[2 - k][mt][nt]);
+            shift_tiles<1>(T, B);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[2 - k][mt][nt] = mfma16(Adn[k][1][mt], B[nt], acc[2 - k][mt][nt]);
+            shift_tiles<2>(T, B);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[2 - k][mt][nt] = mfma16(Adn[k][2][mt], B[nt], acc[2 - k][mt][nt]);
+        }
+        // ---- output row m-1 has all its kernel rows: partial tile of this wave -> LDS; rotate the accumulator sets
+        const bool row_out = (m - 1 >= r0) && (m - 1 < r1);
+        unsigned char* const pbase = part + (m & 1) * S2_PART_BUF;
+        if (row_out) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    *reinterpret_cast<f4*>(pbase + part_wr + 64 * mt + 16 * nt * PART_PX_PITCH) = acc[0][mt][nt];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[0][mt][nt] = acc[1][mt][nt];
+                acc[1][mt][nt] = acc[2][mt][nt];
+                acc[2][mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        if (lr_loader) *reinterpret_cast<u4v*>(lrr + lr_slot(m + 2) + lr_st) = nxt;   // over row m-2 (last read in step m-1)
+        __syncthreads();
+        if (row_out) reduce_store(m - 1, pbase);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vsr_sr_utd_s2_blob_bytes(void) { return S2_BLOB_BYTES; }
+int vsr_sr_utd_s2_strip_width(void) { return S2_TX; }
+
+int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                      vsr_stream_t stream) {
+    VSR_REQUIRE(in && blob && out, "sr_utd_s2: null pointer");
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_utd_s2: bad shape");
+    VSR_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0, "sr_utd_s2: pointers must be 16-byte aligned");
+    if ((size_t)N * h * w * NF * 2 >= (1ull << 32) - 16) return vsr::fail(VSR_E_UNSUPPORTED, "sr_utd_s2: tensors beyond 4 GiB");
+    const unsigned strips = vsr::cdiv(w, S2_TX), segs = vsr::cdiv(h, rows_per_seg);
+    VSR_REQUIRE(segs <= 65535, "sr_utd_s2: too many row segments");
+    if (slopes_le_one)
+        hipLaunchKernelGGL(k_utd_s2<true>, dim3(strips, segs, N), dim3(256), S2_LDS, vsr::S(stream), (const _Float16*)in,
+                           (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
+    else
+        hipLaunchKernelGGL(k_utd_s2<false>, dim3(strips, segs, N), dim3(256), S2_LDS, vsr::S(stream), (const _Float16*)in,
+                           (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
+    return vsr::launched("sr_utd_s2");
+}
+
+}  // extern "C"

@@ -267,10 +267,30 @@ class FlowProjectionModule(nn.Module):
     @torch.no_grad()
     def forward_pairs(self, pairs, net=None):
         """Several frame pairs as ONE FlowNet2 batch (independent samples: same arithmetic per pair, fewer and
-        better filled launches) -> list of colour pictures.  `net`: an execution copy of self.net (e.g. fp16)."""
+        better filled launches) -> colour pictures [B,h',w',3].  `net`: an execution copy of self.net (e.g. fp16)."""
+        if net is not None and hasattr(net, "run_pairs"):
+            # fp16 executor: the frames go in as they are (crop, normalisation and layout inside prepare_pairs), the flow
+            # comes back as the fusion network's NHWC half map and is colour-coded from there
+            distinct, keys = [], []
+            for t in (t for pr in pairs for t in pr):
+                k = (t.data_ptr(), tuple(t.shape))
+                if k not in keys:
+                    keys.append(k)
+                    distinct.append(t)
+            h, w = distinct[0].shape[:2]
+            th, tw = (h // 64) * 64, (w // 64) * 64
+            if th == 0 or tw == 0:
+                raise ValueError("FlowNet2 needs frames of at least 64x64 (centre crop to multiples of 64)")
+            self.image_size, self.render_size = (h, w), [th, tw]
+            idx = [(keys.index((a.data_ptr(), tuple(a.shape))), keys.index((b.data_ptr(), tuple(b.shape)))) for a, b in pairs]
+            out = net.run_pairs(torch.stack(distinct), idx, ((h - th) // 2, (w - tw) // 2, th, tw))   # StaticCenterCrop, tools.py:8-14
+            pics = torch.empty((len(pairs), th, tw, 3), dtype=torch.float32, device=out.device)
+            for b in range(len(pairs)):
+                ops.flow2img_nhwc(out[b], out=pics[b])   # the colour coding normalises by a per-picture maximum
+            return pics
         batch = torch.stack([self._crop_pair(a, b) for a, b in pairs])  # [B,3,2,h',w']
         flows = (net or self.net)(batch)
-        return [ops.flow2img(f) for f in flows]  # the colour coding normalises by a per-picture maximum
+        return torch.stack([ops.flow2img(f) for f in flows])  # the colour coding normalises by a per-picture maximum
 
     @torch.no_grad()
     def forward(self, input1, input2):

@@ -104,6 +104,19 @@ def flow2img(flow_2hw: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@L.on_device
+def flow2img_nhwc(flow_hwc_half: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """[h,w,ld] float16 map whose channels 0,1 are the flow (the fusion network's output as the MFMA convolution leaves it)
+    -> [h,w,3] float32 picture; same arithmetic as flow2img (half -> float is exact)."""
+    H, W, ld = flow_hwc_half.shape
+    if out is None:
+        out = torch.empty((H, W, 3), dtype=torch.float32, device=flow_hwc_half.device)
+    ws = torch.empty(4, dtype=torch.int32, device=flow_hwc_half.device)
+    L.check(L.load().vsr_flow2img_nhwc_f16(L.dptr(flow_hwc_half, torch.float16), ld, L.dptr(out), L.dptr(ws, torch.int32), H, W,
+                                           L.stream()), "flow2img_nhwc")
+    return out
+
+
 class Resample2d(nn.Module):
     def __init__(self, kernel_size=1, bilinear=True):
         super().__init__()

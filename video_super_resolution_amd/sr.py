@@ -176,8 +176,12 @@ class SRProjectionModule(nn.Module):
         P["tail_par"] = torch.cat((P["cv_b"], P["sub_s"], P["sub_b"], P["add_s"], P["add_b"])).contiguous()
         if self.upscale_factor != 4:
             # scale extension: the stage as separate launches on the generic NHWC fp16 MFMA convolution (igemm.py)
-            P["stage"] = {j: _UnfusedStage(b.upBlocks[j + 1], P["dt_w"][j + 1], _NF * (j + 2), P["dt_b"][j + 1], P["dt_a"][j + 1],
-                                           b.downBlocks[j + 2], self.upscale_factor) for j in range(0, G - 2, 3)}
+            def stage(j):
+                args = (b.upBlocks[j + 1], P["dt_w"][j + 1], _NF * (j + 2), P["dt_b"][j + 1], P["dt_a"][j + 1], b.downBlocks[j + 2])
+                if self.upscale_factor == 2 and self.fused_s2:
+                    return _FusedStageS2(*args, slopes_le_one=P["slopes_le_one"], rows_fn=self._rows_per_segment)
+                return _UnfusedStage(*args, self.upscale_factor)
+            P["stage"] = {j: stage(j) for j in range(0, G - 2, 3)}
             P["out_deconv"] = _PhaseDeconv(self.out[0].weight, self.out[0].bias, P["out_a"], self.upscale_factor)
             self._pack, self._pack_key = P, key
             self._const.clear()
@@ -457,14 +461,14 @@ class SRProjectionModule(nn.Module):
         return outs
 
     @staticmethod
-    def _rows_per_segment(N, h, w, cus=256):
+    def _rows_per_segment(N, h, w, cus=256, strip=None):
         """Rows one workgroup of the strip-marching kernels walks.  A launch has strips x N x segments workgroups of one
         wave per SIMD (one workgroup per CU at a time); its duration is about ceil(workgroups / CUs) rounds of
         (rows per segment + ~6 rows: the recomputed halo group and the three cold first steps of a segment).  One march per
         (strip, plane) wins when that already fills the chip (8 planes of 960 columns: 248 workgroups); with fewer planes
         (5 x 31 = 155: 61 % of the CUs for the full 540 rows) cutting the rows balances the load (3 segments: 465
         workgroups, 2 rounds of 186 rows)."""
-        strips = -(-w // L.load().vsr_sr_utd_strip_width())
+        strips = -(-w // (strip or L.load().vsr_sr_utd_strip_width()))
         wgs = strips * N
         best, best_cost = 1, None
         for segs in range(1, max(1, min(-(-h // 8), 32)) + 1):
@@ -485,6 +489,8 @@ class SRProjectionModule(nn.Module):
         return out
 
     fold_tail = True   # the last compress_out inside k_tail3's LR path (False: its own chain launch; cross-check)
+    fused_s2 = True    # scale 2: the stage on k_utd_s2 (csrc/sr_utd_s2.hip); False: the unfused launches (cross-check).
+                       # (read when the weights are packed: change it before the first forward or bump a parameter)
 
     def _utd(self, a, blob, N, h, w, deconv_only=False, out=None):
         if out is None:
@@ -695,6 +701,68 @@ class _PhaseDeconv:
         out = torch.empty((N, self.S * h, self.S * w, _NF), dtype=torch.float16, device=x.device)
         for c in self.phases:
             c(x, out=out, out_hw=(h, w))
+        return out
+
+
+def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a) -> torch.Tensor:
+    """Weights of one fused x2 stage in the per-wave MFMA fragment order of csrc/sr_utd_s2.hip.  Wave (r, c) = (HR row parity,
+    HR column parity): deconv tap (dy, dx) is kernel element (r + 2 dy, c + 2 dx) of the ConvTranspose2d weight
+    [32(in),32(out),6,6]; conv slot (k, s) is kernel element (r + 2 k, c + 2 s) of the Conv2d weight [32(out),32(in),6,6]."""
+    dev = up_w.device
+    nbytes = int(L.load().vsr_sr_utd_s2_blob_bytes())
+    lane = torch.arange(64, device=dev)
+    col_l, g = lane & 15, lane >> 4
+    j8 = torch.arange(8, device=dev)
+    perm = _chunk_channel_order(dev)
+    W = torch.arange(4, device=dev).view(4, 1, 1, 1, 1, 1)
+    A3 = torch.arange(3, device=dev).view(1, 3, 1, 1, 1, 1)
+    B3 = torch.arange(3, device=dev).view(1, 1, 3, 1, 1, 1)
+    MT = torch.arange(2, device=dev).view(1, 1, 1, 2, 1, 1)
+    LN = lane.view(1, 1, 1, 1, 64, 1)
+    J = j8.view(1, 1, 1, 1, 1, 8)
+    ky, kx = (W >> 1) + 2 * A3, (W & 1) + 2 * B3
+    co = 16 * MT + (LN & 15)
+    # deconv: A[co][k = 8 g + j] in natural channel order (the B operand comes straight from the LR rows)
+    ci, co_, ky_, kx_ = torch.broadcast_tensors(8 * (LN >> 4) + J, co, ky, kx)
+    up_frag = up_w.detach().float()[ci, co_, ky_, kx_].to(torch.float16).contiguous()        # [4,3,3,2,64,8]
+    # conv: A[co][k = (g, j)] in the accumulator-derived channel order of the operand tiles
+    ci, co_, ky_, kx_ = torch.broadcast_tensors(perm[LN >> 4, J], co, ky, kx)
+    dn_frag = dn_w.detach().float()[co_, ci, ky_, kx_].to(torch.float16).contiguous()
+    MT2 = torch.arange(2, device=dev).view(2, 1, 1)
+    co2, ci2 = torch.broadcast_tensors(16 * MT2 + col_l.view(1, 64, 1), tr_col0 + perm[g].view(1, 64, 8))
+    dt_frag = tr_w.detach().float()[co2, ci2].to(torch.float16).contiguous()
+    blob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    o_dn, o_dt = 4 * 18 * 1024, 8 * 18 * 1024
+    o_f = o_dt + 2 * 1024
+    blob[0:o_dn] = up_frag.view(torch.uint8).reshape(-1)
+    blob[o_dn:o_dt] = dn_frag.view(torch.uint8).reshape(-1)
+    blob[o_dt:o_f] = dt_frag.view(torch.uint8).reshape(-1)
+    fpar = torch.zeros(128, dtype=torch.float32, device=dev)
+    fpar[0:32], fpar[32:64], fpar[64:96] = up_b.detach().float(), tr_b.detach().float(), dn_b.detach().float()
+    fpar[96], fpar[97], fpar[98] = float(up_a), float(tr_a), float(dn_a)
+    blob[o_f:o_f + 512] = fpar.view(torch.uint8)
+    return blob
+
+
+class _FusedStageS2:
+    """up_i -> downtran slice -> down_j for upscale factor 2 in ONE launch (csrc/sr_utd_s2.hip: the x2 map stays in registers)."""
+
+    def __init__(self, up, dt_w, dt_col, dt_b, dt_a, dn, slopes_le_one, rows_fn):
+        self.blob = pack_utd_s2_blob(up[0].weight, up[0].bias, float(up[1].weight.detach()), dt_w, dt_col, dt_b, dt_a,
+                                     dn[0].weight, dn[0].bias, float(dn[1].weight.detach()))
+        self.slopes_le_one = bool(slopes_le_one)
+        self.rows_fn = rows_fn
+
+    def __call__(self, a, chain, out=None):
+        N, h, w, _ = a.shape
+        if out is None:
+            out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
+        tok = L.TIMER.start("sr_utd_s2_f16" if N == 8 else f"sr_utd_s2_f16_p{N}")
+        # two workgroups share a CU (256 registers per wave): twice the slots of the x4 kernel per round
+        rows = self.rows_fn(N, h, w, cus=512, strip=int(L.load().vsr_sr_utd_s2_strip_width()))
+        L.check(L.load().vsr_sr_utd_s2_f16(L.dptr(a, torch.float16), L.dptr(self.blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
+                                           rows, int(self.slopes_le_one), L.stream()), "sr_utd_s2_f16")
+        L.TIMER.stop(tok)
         return out
 
 

@@ -279,13 +279,15 @@ class _FlowNetCExec:
         self.convs = {n: _cv(getattr(net, n)) for n in self.names}
         self.refine = _Refine(net, with_inter=False)
 
-    def __call__(self, x6):
-        """x6: [B,H,W,32] with the two normalised frames in channels 0-2 and 3-5."""
+    def __call__(self, x6, both=None):
+        """x6: [B,H,W,32] with the two normalised frames in channels 0-2 and 3-5; `both` [2B,H,W,4]: the same frames as
+        4-channel pixels (frame a of every pair, then frame b), as vsr_flownet_prepare_pairs writes them."""
         B, H, W, _ = x6.shape
         dev = x6.device
-        both = cached_zeros(self, "both", (2 * B, H, W, 4), dev)   # 4-channel pixels for the dense-K stem
-        both[:B, ..., :3] = x6[..., 0:3]
-        both[B:, ..., :3] = x6[..., 3:6]
+        if both is None:
+            both = cached_zeros(self, "both", (2 * B, H, W, 4), dev)   # 4-channel pixels for the dense-K stem
+            both[:B, ..., :3] = x6[..., 0:3]
+            both[B:, ..., :3] = x6[..., 3:6]
         c2 = self.conv2(self.conv1(both))           # [2B,H/4,W/4,128]
         c3 = self.conv3(c2)                         # [2B,H/8,W/8,256]
         a3, b3 = c3[:B], c3[B:]                     # contiguous halves of the batched encoder output
@@ -382,40 +384,62 @@ class FlowNet2Exec:
     @torch.no_grad()
     def __call__(self, inputs):
         """inputs [B,3,2,H,W] (0..255) -> flow [B,2,H,W] float32; mirrors flownet.FlowNet2.forward."""
-        inputs = inputs.float()
-        # per-(pair, colour) mean over both frames (FlowNet2.forward's rgb_mean).  Six rows of ~10^6 elements leave a
-        # row-wise reduction on six workgroups (0.2 ms); split every row into 256 segments first.
-        flat = inputs.contiguous().view(inputs.shape[0] * inputs.shape[1], -1)
-        if flat.shape[1] % 256 == 0:
-            mean = (flat.view(flat.shape[0], 256, -1).sum(dim=-1).sum(dim=-1) / flat.shape[1]).view(inputs.shape[:2] + (1, 1, 1))
-        else:
-            mean = flat.mean(dim=-1).view(inputs.shape[:2] + (1, 1, 1))
-        x = (inputs - mean) / 255.0
-        x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1).contiguous()  # [B,6,H,W] float32
-        x6 = to_nhwc_half(x)
-        up_bil = lambda t: F.interpolate(self._flow_nchw(t), scale_factor=4, mode="bilinear")
-        up_nn = lambda t: F.interpolate(self._flow_nchw(t), scale_factor=4, mode="nearest")
+        B, _, _, H, W = inputs.shape
+        frames = inputs.float().permute(0, 2, 3, 4, 1).reshape(2 * B, H, W, 3).contiguous()   # frame a, frame b of every pair
+        out = []
+        for b0 in range(0, B, 4):   # (the glue kernels take up to four pairs per launch)
+            nb = min(4, B - b0)
+            out.append(self.run_pairs(frames[2 * b0:2 * (b0 + nb)], [(2 * i, 2 * i + 1) for i in range(nb)]))
+        return self._flow_nchw(out[0] if len(out) == 1 else torch.cat(out, 0))
+
+    @L.on_device
+    @torch.no_grad()
+    def run_pairs(self, frames, pairs, crop=None):
+        """frames [F,h,w,3] float32 (0..255), pairs [(index a, index b)] (at most four), crop (y0, x0, H, W) or None ->
+        the fusion network's flow as it leaves the MFMA convolution: [B,H,W,32] half, channels 0,1 live (full resolution).
+
+        FlowNet2.forward (models.py:73-128) with the glue between the sub-networks in four fused launches
+        (csrc/flow_ops.hip): prepare_pairs (:74-79), up_warp_concat16 twice (:83-91, :95-103), fusion_input (:106-125)."""
+        lib = L.load()
+        B = len(pairs)
+        F_, h, w, _ = frames.shape
+        y0, x0, H, W = crop or (0, 0, h, w)
+        dev = frames.device
+        frames = frames.contiguous()
+        x = torch.empty((B, 6, H, W), dtype=torch.float32, device=dev)
+        x6 = torch.empty((B, H, W, 32), dtype=torch.float16, device=dev)
+        both = torch.empty((2 * B, H, W, 4), dtype=torch.float16, device=dev)
+        ws = torch.empty(B * 128 * 3, dtype=torch.float32, device=dev)
+        ia = (ctypes.c_int * B)(*[p[0] for p in pairs])
+        ib = (ctypes.c_int * B)(*[p[1] for p in pairs])
+        L.check(lib.vsr_flownet_prepare_pairs(L.dptr(frames), F_, h, w, ia, ib, B, y0, x0, H, W, L.dptr(ws), L.dptr(x),
+                                              L.dptr(x6, torch.float16), L.dptr(both, torch.float16), L.stream()), "flownet_prepare_pairs")
+        if not (self.s1.pair_input and self.s2.pair_input):
+            raise NotImplementedError("FlowNetS stems other than 12 -> 64, stride 2 (the reference's)")
+
+        def warp_cat(flow2):
+            cat = torch.empty((B, H, W, 16), dtype=torch.float16, device=dev)
+            L.check(lib.vsr_flownet_up_warp_concat16_f16(L.dptr(x), L.dptr(flow2, torch.float16), flow2.shape[3], 1, L.cf(self.div_flow),
+                                                         L.cf(1.0 / self.div_flow), L.dptr(cat, torch.float16), B, H, W, L.stream()),
+                    "up_warp_concat16")
+            return cat
         # FlowNetSD depends only on the input pair: it runs on its own HIP stream beside the C -> S1 -> S2 chain (whose
         # 1/16..1/64-resolution layers are latency-bound launches of a few hundred workgroups) and joins at the fusion
-        main = torch.cuda.current_stream(x.device)
-        side = self._sd_stream(x.device) if os.environ.get("VSR_FLOWSD_STREAM", "1") != "0" else main   # (A/B switch)
+        main = torch.cuda.current_stream(dev)
+        side = self._sd_stream(dev) if os.environ.get("VSR_FLOWSD_STREAM", "1") != "0" else main   # (A/B switch)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            flow_sd = up_nn(self.sd(x6)) / self.div_flow
-            n_sd, d_sd = ops.warp_norms(x, flow_sd)
-            for t in (flow_sd, n_sd, d_sd):
-                t.record_stream(main)
-        x.record_stream(side)
+            sd2 = self.sd(x6)
+            sd2.record_stream(main)
         x6.record_stream(side)
-        flow_c = up_bil(self.c(x6)) * self.div_flow
-        concat1 = ops.warp_concat(x, flow_c, self.div_flow)
-        flow_s1 = up_bil(self.s1(to_nhwc_half(concat1, 16 if self.s1.pair_input else None))) * self.div_flow
-        concat2 = ops.warp_concat(x, flow_s1, self.div_flow)
-        flow_s2 = up_nn(self.s2(to_nhwc_half(concat2, 16 if self.s2.pair_input else None))) * self.div_flow
-        n_s2, d_s2 = ops.warp_norms(x, flow_s2)
+        s1_in = warp_cat(self.c(x6, both))
+        s2_in = warp_cat(self.s1(s1_in))
+        s22 = self.s2(s2_in)
         main.wait_stream(side)
-        concat3 = torch.cat((x[:, :3], flow_sd, flow_s2, n_sd, n_s2, d_sd, d_s2), dim=1)
-        return self._flow_nchw(self.fusion(to_nhwc_half(concat3)))
+        x11 = torch.empty((B, H, W, 32), dtype=torch.float16, device=dev)
+        L.check(lib.vsr_flownet_fusion_input_f16(L.dptr(x), L.dptr(sd2, torch.float16), sd2.shape[3], L.dptr(s22, torch.float16), s22.shape[3],
+                                                 L.cf(self.div_flow), L.dptr(x11, torch.float16), B, H, W, L.stream()), "fusion_input")
+        return self.fusion(x11)
 
 
 # ------------------------------------------------------------------------------------------------ OSVOS

@@ -97,7 +97,8 @@ class VSR(nn.Module):
 
     @torch.no_grad()
     def _guidance(self, trip, depth_cache, extra_depth=(), with_vos=None):
-        """trip: three [h,w,3] frames -> (flow pictures [2,3,h,w], depth planes [2,3,h,w][, VOS mask]).
+        """trip: three [h,w,3] frames -> (flow pictures [2,h',w',3], the three single-frame depth predictions [1,1,h,w]
+        [, VOS mask [h,w]]): what `_assemble` turns into planes 3-6 (and the masked plane 7) of the SR input.
 
         The flow, depth and segmentation trunks are independent of each other and individually too small to fill 256
         CUs in their low-resolution layers, so in the fp16 configuration they run concurrently on separate HIP streams
@@ -130,16 +131,26 @@ class VSR(nn.Module):
                 mask = self.VOSModule(with_vos[0], with_vos[1], self._vos_exec.get() if fast else None)  # [h,w] in {0,1}
                 mask.record_stream(main)
         # both frame pairs as one FlowNet2 batch of two (on the main stream)
-        pics = torch.stack(self.FlowModule.forward_pairs([(trip[0], trip[1]), (trip[1], trip[2])],
-                                                         self._flow_exec.get() if fast else None))
-        pics = F.interpolate(pics.permute(0, 3, 1, 2), (h, w))  # nearest back to h x w (:35,:52)
+        pics = self.FlowModule.forward_pairs([(trip[0], trip[1]), (trip[1], trip[2])], self._flow_exec.get() if fast else None)
         if fast:
             main.wait_stream(s_depth)
             main.wait_stream(s_vos)
         z = [depth_cache[f.data_ptr()][1] for f in trip]
-        depth = torch.stack([maskprocess(self.DepthModule.combine(z[0], z[1])),
-                             maskprocess(self.DepthModule.combine(z[1], z[2]))])
-        return pics, depth, mask
+        return pics, z, mask
+
+    @staticmethod
+    def _assemble(frames_nhwc, pics, z, est_chw=None, mask=None):
+        """The 8-plane SR input of :33-40 / :57-62 in one launch (csrc/flow_ops.hip k_assemble_planes): frames NHWC -> NCHW,
+        flow pictures resized to h x w (nearest, :35,:52), depth = mean of two predictions x3 (DepthProjectionModule.py:16,
+        tools.py:76-77), estimate plane (frame 0 | given plane), zeroed under the VOS mask (:58-60)."""
+        from . import _lib as L
+        _, h, w, _ = frames_nhwc.shape
+        out = torch.empty((8, 3, h, w), dtype=torch.float32, device=frames_nhwc.device)
+        zc = [t.reshape(h, w).contiguous() for t in z]
+        L.check(L.load().vsr_assemble_planes_f32(L.dptr(frames_nhwc), L.dptr(pics), pics.shape[1], pics.shape[2], L.dptr(zc[0]),
+                                                 L.dptr(zc[1]), L.dptr(zc[2]), L.optr(est_chw), L.optr(mask), L.dptr(out), h, w,
+                                                 L.stream()), "assemble_planes")
+        return out
 
     @_on_device
     def forward(self, data, target, high_frames, estimated_image, train=True):
@@ -153,31 +164,31 @@ class VSR(nn.Module):
             d = data.detach().to(torch.float32).contiguous()
             f0, f1, f2 = d[0], d[1], d[2]
             depth_cache = {}
-            frames = d.permute(0, 3, 1, 2)  # [3,3,h,w]
 
             # ---- pass 1 (:26-41)
             if estimated_image is None:
-                est = frames[0:1]
-                est_hw3 = f0
-            else:
-                est = F.interpolate(estimated_image.detach().to(torch.float32).permute(0, 3, 1, 2), (h, w))  # :37
-                est_hw3 = est[0].permute(1, 2, 0).contiguous()
+                est, est_hw3 = None, f0   # plane 7 = frame 0 (:38)
+            else:                          # :37 nearest resize of the previous output, as a plane and as a frame
+                prev = estimated_image.detach().to(torch.float32).contiguous()
+                est = torch.empty((3, h, w), dtype=torch.float32, device=d.device)
+                est_hw3 = torch.empty((h, w, 3), dtype=torch.float32, device=d.device)
+                from . import _lib as L
+                L.check(L.load().vsr_resize_estimate_f32(L.dptr(prev), prev.shape[1], prev.shape[2], L.dptr(est), L.dptr(est_hw3), h, w,
+                                                         L.stream()), "resize_estimate")
             # (the estimate's depth is only used in pass 2 but is already known: batched with the three frames)
-            pics, depth, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,))
+            pics, z, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,))
             self.model.precision = self.precision
             # pass 1's frame is only ever read through the nearest x1/4 resize of :44, i.e. at its pixels (4i,4j): the SR
             # stack evaluates its tail and fusion MLP at exactly those (identical values, 1/16 of the tail work)
             # planes 0-2 (the LR frames) are the same in both SR calls (:40, :62): their FeedbackBlock maps are computed here
             # and kept for pass 2 (sr.py:_forward_f16 `shared`; identical values, 3/8 of pass 2's trunk not recomputed)
             shared = {"n": 3} if self.share_planes else None
-            mid = self.model(torch.cat((frames, pics, depth, est), 0), decimate=True, shared=shared)[0]  # [3,h,w] = F.interpolate(out1,(h,w))[0]
+            mid = self.model(self._assemble(d, pics, z, est), decimate=True, shared=shared)[0]  # [3,h,w] = F.interpolate(out1,(h,w))[0]
 
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
             mid_hw3 = mid.permute(1, 2, 0).contiguous()
-            pics2, depth2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3))
-            masked = torch.where(maskprocess(mask) != 0, torch.zeros_like(mid), mid).unsqueeze(0)  # :58-60
-
-            x8 = torch.cat((frames, pics2, depth2, masked), 0)
+            pics2, z2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3))
+            x8 = self._assemble(d, pics2, z2, mid.contiguous(), mask.contiguous())   # plane 7: mid, zero where mask != 0 (:58-60)
         # ---- pass 2 SR (:62-64): the reference's only call outside no_grad.  Under the caller's no_grad or in eval mode it
         # runs the kernels; in training mode with autograd on it is differentiable (SRProjectionModule.forward)
         out = self.model(x8, shared=shared).permute(0, 2, 3, 1)
