@@ -107,3 +107,64 @@ def test_vsr_forward_scale2_vs_oracle(cpu_vsr, precision, bar):
         psnr = 10 * np.log10(255.0 ** 2 / max(float(np.mean(err ** 2)), 1e-20))
         print(f"[x2 e2e {precision}] PSNR(255) {psnr:.2f} dB, p99 {np.percentile(err, 99):.4f}")
         assert psnr > bar, psnr
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# k_utd_s2 (csrc/sr_utd_s2.hip): the fused x2 stage against an fp32 stock-op evaluation of the same three layers, against
+# the unfused launches it replaces, and against itself across row segmentations and plane counts.
+def _stage_reference_x2(m, j, a_nchw):
+    import torch.nn.functional as F
+    b = m.block
+    up, dt, dn = b.upBlocks[j + 1], b.downtranBlocks[j + 1], b.downBlocks[j + 2]
+    hr = F.prelu(F.conv_transpose2d(a_nchw, up[0].weight, up[0].bias, stride=2, padding=2), up[1].weight)
+    c0 = 32 * (j + 2)
+    t = F.prelu(F.conv2d(hr, dt[0].weight[:, c0:c0 + 32], dt[0].bias), dt[1].weight)
+    return F.prelu(F.conv2d(t, dn[0].weight, dn[0].bias, stride=2, padding=2), dn[1].weight)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7), (1, 9, 40), (3, 20, 70), (1, 2, 2), (1, 33, 31), (8, 12, 30), (1, 1, 61), (2, 47, 3)])
+@pytest.mark.parametrize("chain", [0, 3])
+def test_fused_x2_stage(shape, chain):
+    from video_super_resolution_amd import _lib as L
+    from video_super_resolution_amd.sr import _UnfusedStage
+    m, _ = sr_module(2)
+    m.precision = "fp16"
+    N, h, w = shape
+    P = m._packed()
+    st = P["stage"][chain]
+    assert type(st).__name__ == "_FusedStageS2"
+    a = torch.from_numpy((np.random.RandomState(N * 1000 + h * 10 + w + chain).randn(N, h, w, 32) * 20).astype(np.float16)).cuda()
+    with torch.no_grad():
+        ref = _stage_reference_x2(m, chain, a.float().permute(0, 3, 1, 2))
+        got = st(a, m._chain)
+        b = m.block
+        unf = _UnfusedStage(b.upBlocks[chain + 1], P["dt_w"][chain + 1], 32 * (chain + 2), P["dt_b"][chain + 1], P["dt_a"][chain + 1],
+                            b.downBlocks[chain + 2], 2)(a, m._chain)
+    rng = ref.abs().max().item()
+    assert torch.isfinite(got.float()).all()
+    err = (got.float().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= 3e-3 * rng, (err, rng)
+    assert (got.float() - unf.float()).abs().max().item() <= 4e-3 * rng
+    # row segmentations (recomputed halo pairs) are bit-identical
+    lib = L.load()
+    for rps in (1, 3, 16):
+        out = torch.empty_like(got)
+        L.check(lib.vsr_sr_utd_s2_f16(L.dptr(a, torch.float16), L.dptr(st.blob, torch.uint8), L.dptr(out, torch.float16), N, h, w, rps, 1,
+                                      L.stream()))
+        assert torch.equal(out, got), rps
+
+
+def test_fused_and_unfused_x2_networks_agree(golden):
+    import copy
+    g = golden("g8_sr_x2_12x20")
+    m, _ = sr_module(2)
+    m.precision = "fp16"
+    x = torch.from_numpy(g["x"]).cuda()
+    fused = m(x)
+    mu = copy.deepcopy(m)
+    mu.fused_s2 = False
+    mu._pack = None
+    unfused = mu(x)
+    assert type(mu._packed()["stage"][0]).__name__ == "_UnfusedStage"
+    assert rel(fused, g["out"]) < 2e-3 and rel(unfused, g["out"]) < 2e-3
+    assert rel(fused, unfused.cpu().numpy()) < 1e-3

@@ -134,3 +134,35 @@ def test_headline_fp16_configuration_end_to_end(golden, gpu_vsr_f16):
               f"median {p50:.4f}, p99 {p99:.4f}, max {err.max():.3f} grey levels")
         # bars = measured minus a margin for box-to-box differences in the discrete planes
         assert psnr > PSNR255_BAR and psnr_sig > PSNR_SIGNAL_BAR and p99 < P99_BAR, (psnr, psnr_sig, p99)
+
+
+def test_streaming_mode_is_bit_identical(gpu_vsr_f16):
+    """VSR.temporal_cache (opt-in): depth predictions / flow pictures of the two frames consecutive windows share are kept
+    across calls -- the frames must equal those of the default per-window evaluation bit for bit, and an in-place change of
+    a frame must be seen (version counter), not served from the cache."""
+    import copy
+    m = copy.deepcopy(gpu_vsr_f16)
+    clip = torch.from_numpy(np.random.RandomState(5).randint(0, 256, (6, 66, 70, 3)).astype(np.float32)).cuda()
+
+    def run(cache, clip_):
+        m.temporal_cache = cache
+        m.reset_temporal_cache()
+        est, outs = None, []
+        for t in range(4):
+            est, _ = m(clip_[t:t + 3], None, None, est, train=False)
+            outs.append(est.clone())
+        return outs
+    ref = run(False, clip)
+    got = run(True, clip)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert len(m._tcache["depth"]) == 3 and len(m._tcache["flow"]) == 2
+    # a frame changed in place between calls: same storage, new version -> recomputed
+    m.temporal_cache = True
+    m.reset_temporal_cache()
+    est, _ = m(clip[0:3], None, None, None, train=False)
+    clip[2].add_(7.0).clamp_(0, 255)
+    est2, _ = m(clip[1:4], None, None, est, train=False)
+    m.temporal_cache = False
+    want, _ = m(clip[1:4], None, None, est, train=False)
+    assert torch.equal(est2, want)

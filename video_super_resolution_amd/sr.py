@@ -757,12 +757,16 @@ class _FusedStageS2:
         N, h, w, _ = a.shape
         if out is None:
             out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
-        tok = L.TIMER.start("sr_utd_s2_f16" if N == 8 else f"sr_utd_s2_f16_p{N}")
-        # two workgroups share a CU (256 registers per wave): twice the slots of the x4 kernel per round
-        rows = self.rows_fn(N, h, w, cus=512, strip=int(L.load().vsr_sr_utd_s2_strip_width()))
-        L.check(L.load().vsr_sr_utd_s2_f16(L.dptr(a, torch.float16), L.dptr(self.blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
-                                           rows, int(self.slopes_le_one), L.stream()), "sr_utd_s2_f16")
-        L.TIMER.stop(tok)
+        nb = max(1, min(N, ((1 << 32) - 32) // (h * w * _NF * 2)))   # planes per launch: the kernel's 32-bit byte offsets
+        for n0 in range(0, N, nb):
+            n = min(nb, N - n0)
+            tok = L.TIMER.start("sr_utd_s2_f16" if n == 8 else f"sr_utd_s2_f16_p{n}")
+            # two workgroups share a CU (256 registers per wave): twice the slots of the x4 kernel per round
+            rows = self.rows_fn(n, h, w, cus=512, strip=int(L.load().vsr_sr_utd_s2_strip_width()))
+            L.check(L.load().vsr_sr_utd_s2_f16(L.dptr(a[n0:n0 + n], torch.float16), L.dptr(self.blob, torch.uint8),
+                                               L.dptr(out[n0:n0 + n], torch.float16), n, h, w, rows, int(self.slopes_le_one), L.stream()),
+                    "sr_utd_s2_f16")
+            L.TIMER.stop(tok)
         return out
 
 

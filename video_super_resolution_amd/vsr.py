@@ -66,6 +66,15 @@ class VSR(nn.Module):
         # "fp32": SR stack in exact float32 kernels, trunks on stock float32 convolutions (the parity configuration).
         self.precision = "fp16"
         self.share_planes = True   # evaluate the three LR-frame planes once per forward (both SR passes read them)
+        # Opt-in streaming mode (OFF by default; the headline benchmark leaves it off): consecutive windows of a clip share
+        # two of their three LR frames (utils/video_utils.py:25), so the depth prediction of a frame and the flow picture of a
+        # frame pair computed for window t are what window t+1 computes again.  With temporal_cache = True they are kept
+        # across calls, keyed by the identity AND version counter of the frame tensors (views of one clip tensor, as
+        # main.py:196-199 / driver.run_item hand them over): identical outputs, about two of G1's four hourglass runs and one
+        # of its two FlowNet2 runs saved per window.  The caller must not free and refill frame storage between calls without
+        # going through tensor operations (the version counter is how a change is seen); `reset_temporal_cache()` drops it.
+        self.temporal_cache = False
+        self._tcache = {"depth": {}, "flow": {}}
         self._flow_exec = TrunkExecCache(self.FlowModule.net, FlowNet2Exec)
         self._depth_exec = TrunkExecCache(self.DepthModule.model.netG, HourglassExec)
         self._vos_exec = TrunkExecCache(self.VOSModule.net, OSVOSExec)
@@ -82,6 +91,29 @@ class VSR(nn.Module):
         """video_super_resolution.py:71-80 (a 0-d CPU tensor, computed under no_grad like the reference)."""
         return loss_calculate(self, target, outputs)
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy of a module that has run: HIP streams and the executors built on them are per-instance run-time
+        state (not picklable, and not meant to be shared): the copy gets fresh ones."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        runtime = {"_streams", "_streams_key", "_flow_exec", "_depth_exec", "_vos_exec", "_tcache"}
+        for k, v in self.__dict__.items():
+            if k not in runtime:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new._flow_exec = TrunkExecCache(new.FlowModule.net, FlowNet2Exec)
+        new._depth_exec = TrunkExecCache(new.DepthModule.model.netG, HourglassExec)
+        new._vos_exec = TrunkExecCache(new.VOSModule.net, OSVOSExec)
+        new._tcache = {"depth": {}, "flow": {}}
+        return new
+
+    def reset_temporal_cache(self):
+        self._tcache = {"depth": {}, "flow": {}}
+
+    @staticmethod
+    def _tkey(t):
+        return (t.data_ptr(), tuple(t.shape), t._version, t.device.index)
+
     # ------------------------------------------------------------------------------------------
     def _fast(self) -> bool:
         if self.precision not in ("fp16", "fp32"):
@@ -96,7 +128,7 @@ class VSR(nn.Module):
         return self._streams
 
     @torch.no_grad()
-    def _guidance(self, trip, depth_cache, extra_depth=(), with_vos=None):
+    def _guidance(self, trip, depth_cache, extra_depth=(), with_vos=None, cacheable=False):
         """trip: three [h,w,3] frames -> (flow pictures [2,h',w',3], the three single-frame depth predictions [1,1,h,w]
         [, VOS mask [h,w]]): what `_assemble` turns into planes 3-6 (and the masked plane 7) of the SR input.
 
@@ -112,6 +144,12 @@ class VSR(nn.Module):
             s_vos.wait_stream(main)
 
         # depth trunk once per distinct frame, all new frames as one batch
+        tc = self._tcache if (self.temporal_cache and cacheable) else None
+        if tc is not None:   # streaming mode: predictions of frames an earlier window already saw
+            for f in trip:
+                hit = tc["depth"].get(self._tkey(f))
+                if hit is not None and f.data_ptr() not in depth_cache:
+                    depth_cache[f.data_ptr()] = (f, hit)
         new = []
         for f in list(trip) + list(extra_depth):
             if f.data_ptr() not in depth_cache and all(f.data_ptr() != g.data_ptr() for g in new):
@@ -131,11 +169,24 @@ class VSR(nn.Module):
                 mask = self.VOSModule(with_vos[0], with_vos[1], self._vos_exec.get() if fast else None)  # [h,w] in {0,1}
                 mask.record_stream(main)
         # both frame pairs as one FlowNet2 batch of two (on the main stream)
-        pics = self.FlowModule.forward_pairs([(trip[0], trip[1]), (trip[1], trip[2])], self._flow_exec.get() if fast else None)
+        pairs = [(trip[0], trip[1]), (trip[1], trip[2])]
+        net = self._flow_exec.get() if fast else None
+        if tc is not None:
+            keys = [(self._tkey(a), self._tkey(b)) for a, b in pairs]
+            have = [tc["flow"].get(k) for k in keys]
+            todo = [p for p, hv in zip(pairs, have) if hv is None]
+            fresh = iter(self.FlowModule.forward_pairs(todo, net)) if todo else iter(())
+            pics_l = [hv if hv is not None else next(fresh) for hv in have]
+            pics = torch.stack(pics_l)
+            tc["flow"] = {k: p for k, p in zip(keys, pics_l)}                      # keep this window's two pictures only
+        else:
+            pics = self.FlowModule.forward_pairs(pairs, net)
         if fast:
             main.wait_stream(s_depth)
             main.wait_stream(s_vos)
         z = [depth_cache[f.data_ptr()][1] for f in trip]
+        if tc is not None:
+            tc["depth"] = {self._tkey(f): zz for f, zz in zip(trip, z)}             # ... and its three depth predictions
         return pics, z, mask
 
     @staticmethod
@@ -176,7 +227,7 @@ class VSR(nn.Module):
                 L.check(L.load().vsr_resize_estimate_f32(L.dptr(prev), prev.shape[1], prev.shape[2], L.dptr(est), L.dptr(est_hw3), h, w,
                                                          L.stream()), "resize_estimate")
             # (the estimate's depth is only used in pass 2 but is already known: batched with the three frames)
-            pics, z, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,))
+            pics, z, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,), cacheable=True)
             self.model.precision = self.precision
             # pass 1's frame is only ever read through the nearest x1/4 resize of :44, i.e. at its pixels (4i,4j): the SR
             # stack evaluates its tail and fusion MLP at exactly those (identical values, 1/16 of the tail work)
