@@ -279,8 +279,8 @@ def main():
             model.reset_temporal_cache()
             extras["streaming"] = dict(value=round(args.steps / dt, 4), unit="frames/s", ms_per_step=round(1e3 * dt / args.steps, 3),
                                        note="VSR.temporal_cache = True: depth predictions and flow pictures of the two frames "
-                                            "consecutive windows share are reused across calls (identical frames; skips work the "
-                                            "reference's per-window forward repeats) -- NOT the headline value")
+                                            "consecutive windows share are reused across calls (same arithmetic on smaller trunk batches; skips "
+                                            "work the reference's per-window forward repeats) -- NOT the headline value")
             # (2) PCIe-inclusive: a uint8 HR window [3,H,W,3] comes from pinned host memory, is resized / converted on the device
             # (main.py:155-159), and the uint8 HR frame goes back to pinned host memory, all on the compute stream
             win_host = torch.randint(0, 256, (1, 3, H, W, 3), dtype=torch.uint8).pin_memory()

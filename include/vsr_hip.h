@@ -279,6 +279,14 @@ int vsr_sr_utd_s2_strip_width(void);
 int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                       vsr_stream_t stream);
 
+/* The tail for the scale-2 extension in one launch (csrc/sr_tail_s2.hip): `out` DeconvBlock (k6 s2 p2 + PReLU) -> conv_out 3x3
+ * (32 -> 3, bias) -> raw planes [N,3,2h,2w] fp32 (decimate != 0: the pixels (2i, 2j) only -> [N,3,h,w]); the x2 map stays in
+ * LDS.  hid_nhwc [N,h,w,32] fp16; blob = vsr_sr_tail_s2_blob_bytes() bytes packed by sr.py:pack_tail_s2_blob.  Followed by
+ * vsr_sr_fc_planes_skip_scale_f32 (skip + add_mean + fusion MLP). */
+size_t vsr_sr_tail_s2_blob_bytes(void);
+int vsr_sr_tail_s2_f16(const void* hid_nhwc, const void* blob, float* raw, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                       int decimate, vsr_stream_t stream);
+
 /* Tail of the fp16 path for upscale factors other than the reference's x4 (scale extension, see vsr_sr_deconv_f32):
  * conv_out 3x3 (32->3, :121-123,142) over the `out` DeconvBlock's HR map [N,H,W,32] fp16 -> raw planes [N,3,Ho,Wo] fp32
  * at the pixels (step*i, step*j) (step = 1: all; step = scale: what the nearest x1/scale resize of pass 1 reads). */

@@ -168,3 +168,27 @@ def test_fused_and_unfused_x2_networks_agree(golden):
     assert type(mu._packed()["stage"][0]).__name__ == "_UnfusedStage"
     assert rel(fused, g["out"]) < 2e-3 and rel(unfused, g["out"]) < 2e-3
     assert rel(fused, unfused.cpu().numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("hw", [(20, 24), (33, 61), (7, 95)])
+def test_fused_x2_tail_segmentations_and_unfused_build(monkeypatch, hw):
+    """k_tail_s2 (deconvolution + conv_out through an LDS ring): every row segmentation gives the same frame bit for bit
+    (full and decimated), and the frame agrees with the unfused tail (phase deconvolutions + k_convout_planes)."""
+    import copy
+    m, _ = sr_module(2)
+    m.precision = "fp16"
+    x = torch.from_numpy(np.random.RandomState(hw[0] * 3 + hw[1]).randint(0, 256, (8, 3) + hw).astype(np.float32)).cuda()
+    ref, ref_dec = m(x), m(x, decimate=True)
+    assert "tail_s2" in m._packed() and torch.equal(ref_dec, ref[..., ::2, ::2])
+    orig = type(m)._rows_per_segment
+    for rows in (1, 4, 9):
+        monkeypatch.setattr(type(m), "_rows_per_segment", staticmethod(lambda N, h, w, cus=256, strip=None, rows=rows: rows))
+        assert torch.equal(m(x), ref), rows
+        assert torch.equal(m(x, decimate=True), ref_dec), rows
+    monkeypatch.setattr(type(m), "_rows_per_segment", staticmethod(orig))
+    mu = copy.deepcopy(m)
+    mu.fused_s2 = False
+    mu._pack = None
+    unf = mu(x)
+    assert "tail_s2" not in mu._packed()
+    assert (unf - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()

@@ -48,7 +48,7 @@ def load() -> ctypes.CDLL:
                 "(there is no CPU fallback for the device path)")
         lib = ctypes.CDLL(LIB_PATH)
         lib.vsr_last_error.restype = ctypes.c_char_p
-        for fn in ("vsr_sr_utd_blob_bytes", "vsr_sr_utd_s2_blob_bytes"):
+        for fn in ("vsr_sr_utd_blob_bytes", "vsr_sr_utd_s2_blob_bytes", "vsr_sr_tail_s2_blob_bytes"):
             if hasattr(lib, fn):
                 getattr(lib, fn).restype = ctypes.c_size_t
         if lib.vsr_abi_version() != 1:

@@ -183,6 +183,9 @@ class SRProjectionModule(nn.Module):
                 return _UnfusedStage(*args, self.upscale_factor)
             P["stage"] = {j: stage(j) for j in range(0, G - 2, 3)}
             P["out_deconv"] = _PhaseDeconv(self.out[0].weight, self.out[0].bias, P["out_a"], self.upscale_factor)
+            if self.upscale_factor == 2 and self.fused_s2:
+                P["tail_s2"] = pack_tail_s2_blob(self.out[0].weight, self.out[0].bias, P["out_a"], self.conv_out[0].weight,
+                                                 self.conv_out[0].bias)
             self._pack, self._pack_key = P, key
             self._const.clear()
             self._const_nhwc.clear()
@@ -641,7 +644,17 @@ class SRProjectionModule(nn.Module):
         ho, wo = (h, w) if decimate else (S * h, S * w)
         raw = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
         nb = _planes_per_chunk(N, S * h, S * w)
-        for n0 in range(0, N, nb):
+        if "tail_s2" in P:   # scale 2: deconvolution + conv_out in one launch, the x2 map stays in LDS (csrc/sr_tail_s2.hip)
+            nbt = max(1, min(N, ((1 << 32) - 32) // (h * w * _NF * 2)))
+            for n0 in range(0, N, nbt):
+                n = min(nbt, N - n0)
+                tok = L.TIMER.start("sr_tail_s2_dec_f16" if decimate else "sr_tail_s2_f16") if L.TIMER.enabled else None
+                rows = self._rows_per_segment(n, h, w, cus=512, strip=30)
+                L.check(lib.vsr_sr_tail_s2_f16(L.dptr(hid[n0:n0 + n], torch.float16), L.dptr(P["tail_s2"], torch.uint8), L.dptr(raw[n0:n0 + n]),
+                                               n, h, w, rows, int(P["slopes_le_one"]), int(decimate), L.stream()), "sr_tail_s2_f16")
+                L.TIMER.stop(tok)
+            nb = 0
+        for n0 in (range(0, N, nb) if nb else ()):
             hr = P["out_deconv"](hid[n0:n0 + nb])
             tok = L.TIMER.start("sr_convout_planes_f16") if L.TIMER.enabled else None
             L.check(lib.vsr_sr_convout_planes_f16(L.dptr(hr, torch.float16), L.dptr(P["cv_w"]), L.dptr(P["cv_b"]), L.dptr(raw[n0:n0 + nb]),
@@ -740,6 +753,42 @@ def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn
     fpar = torch.zeros(128, dtype=torch.float32, device=dev)
     fpar[0:32], fpar[32:64], fpar[64:96] = up_b.detach().float(), tr_b.detach().float(), dn_b.detach().float()
     fpar[96], fpar[97], fpar[98] = float(up_a), float(tr_a), float(dn_a)
+    blob[o_f:o_f + 512] = fpar.view(torch.uint8)
+    return blob
+
+
+def pack_tail_s2_blob(out_w, out_b, out_a, cv_w, cv_b) -> torch.Tensor:
+    """Weights of the fused x2 tail (csrc/sr_tail_s2.hip): the `out` ConvTranspose2d [32,32,6,6] in k_utd_s2's per-wave
+    fragment order, conv_out [3,32,3,3] as nine A fragments whose rows 0-2 are its output channels (k index in the
+    accumulator-derived channel order of the ring), then b_out[32], b_cv[3] and the PReLU slope."""
+    dev = out_w.device
+    nbytes = int(L.load().vsr_sr_tail_s2_blob_bytes())
+    lane = torch.arange(64, device=dev)
+    perm = _chunk_channel_order(dev)
+    W = torch.arange(4, device=dev).view(4, 1, 1, 1, 1, 1)
+    A3 = torch.arange(3, device=dev).view(1, 3, 1, 1, 1, 1)
+    B3 = torch.arange(3, device=dev).view(1, 1, 3, 1, 1, 1)
+    MT = torch.arange(2, device=dev).view(1, 1, 1, 2, 1, 1)
+    LN = lane.view(1, 1, 1, 1, 64, 1)
+    J = torch.arange(8, device=dev).view(1, 1, 1, 1, 1, 8)
+    ci, co, ky, kx = torch.broadcast_tensors(8 * (LN >> 4) + J, 16 * MT + (LN & 15), (W >> 1) + 2 * A3, (W & 1) + 2 * B3)
+    up_frag = out_w.detach().float()[ci, co, ky, kx].to(torch.float16).contiguous()
+    cv = torch.zeros((3, 3, 64, 8), dtype=torch.float32, device=dev)
+    row, g = lane & 15, lane >> 4
+    live = row < 3
+    w = cv_w.detach().float()
+    for dy in range(3):
+        for dx in range(3):
+            cv[dy, dx, live] = w[row[live].unsqueeze(1), perm[g[live]], dy, dx]
+    blob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    o_cv = 4 * 18 * 1024
+    o_f = o_cv + 9 * 1024
+    blob[0:o_cv] = up_frag.view(torch.uint8).reshape(-1)
+    blob[o_cv:o_f] = cv.to(torch.float16).contiguous().view(torch.uint8).reshape(-1)
+    fpar = torch.zeros(128, dtype=torch.float32, device=dev)
+    fpar[0:32] = out_b.detach().float()
+    fpar[32:35] = cv_b.detach().float()
+    fpar[96] = float(out_a)
     blob[o_f:o_f + 512] = fpar.view(torch.uint8)
     return blob
 

@@ -70,8 +70,9 @@ class VSR(nn.Module):
         # two of their three LR frames (utils/video_utils.py:25), so the depth prediction of a frame and the flow picture of a
         # frame pair computed for window t are what window t+1 computes again.  With temporal_cache = True they are kept
         # across calls, keyed by the identity AND version counter of the frame tensors (views of one clip tensor, as
-        # main.py:196-199 / driver.run_item hand them over): identical outputs, about two of G1's four hourglass runs and one
-        # of its two FlowNet2 runs saved per window.  The caller must not free and refill frame storage between calls without
+        # main.py:196-199 / driver.run_item hand them over): about two of G1's four hourglass runs and one of its two FlowNet2
+        # runs saved per window.  Same networks on the same frames, but on smaller batches -- the MFMA convolution picks its
+        # tile / split-K shape by the pixel count -- so the frames agree with the per-window evaluation to rounding, not bit for bit.  The caller must not free and refill frame storage between calls without
         # going through tensor operations (the version counter is how a change is seen); `reset_temporal_cache()` drops it.
         self.temporal_cache = False
         self._tcache = {"depth": {}, "flow": {}}
