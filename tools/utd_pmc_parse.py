@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recu
             meta.setdefault("dur", []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 med = {k: sorted(v)[len(v) // 2] for k, v in vals.items()}
 waves = meta["grid"] / 64
-steps = 540
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 540   # LR rows one workgroup marches
 s = {"kernel": meta.get("kernel"), "workgroup": meta.get("wg"), "waves": waves,
      "dispatch_ns_under_pmc": sorted(meta["dur"])[len(meta["dur"]) // 2], "counters": med}
 if "SQ_WAVE_CYCLES" in med:

@@ -1,0 +1,24 @@
+"""Runs only the fused x2 stage kernel k_utd_s2 (8 planes of LR h x w, default the C3-B size 1080 x 1920) -- target for
+rocprofv3 --pmc (tools/utd_pmc.sh s2) and a quick timing."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from video_super_resolution_amd import SRProjectionModule
+from video_super_resolution_amd.weights import fill_module_
+torch.set_grad_enabled(False)
+N, h, w = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 1080, int(sys.argv[2]) if len(sys.argv) > 2 else 1920
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+m = fill_module_(SRProjectionModule(upscale_factor=2).eval(), 0, "model.").cuda()
+st = m._packed()["stage"][0]
+a = (torch.randn(N, h, w, 32, device="cuda") * 20).half()
+for _ in range(2): st(a, m._chain)
+torch.cuda.synchronize()
+res = []
+for r in range(4):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): st(a, m._chain)
+    e1.record(); torch.cuda.synchronize()
+    res.append(e0.elapsed_time(e1) / reps)
+ms = sorted(res)[len(res) // 2]
+print(f"k_utd_s2 {N}x{h}x{w}: {ms:.3f} ms  -> {N*h*w*155648/ms/1e9:.1f} TFLOP/s")
