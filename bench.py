@@ -321,9 +321,10 @@ def main():
                 achieved = flop / (ms * 1e-3) / 1e12
                 # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
                 # gfx950 correction applied) -- a committed measurement of the same launch geometry, not taken in this run
-                for pmc in ("r02_k_utd3_pmc.json", "r01_k_utd3_pmc.json"):
+                pmcs = {(540, 960, 4): ("r02_k_utd3_pmc.json", "r01_k_utd3_pmc.json"), (1080, 1920, 2): ("r02_k_utd_s2_pmc.json",)}
+                for pmc in pmcs.get((h, w, scale), ()):
                     path = os.path.join(ROOT, "profiles", pmc)
-                    if (h, w, scale) == (540, 960, 4) and os.path.exists(path):
+                    if os.path.exists(path):
                         with open(path) as f:
                             traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"]
                         traffic_source = f"profiles/{pmc} (rocprofv3 --pmc, separate run of the same launch geometry)"
