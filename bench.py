@@ -260,7 +260,7 @@ def main():
 
     # ---- two extra loops, reported beside the headline value and never part of it (single GPU only)
     extras = {}
-    if world == 1 and args.clips == 0 and not args.no_extras:
+    def run_extras():
         from video_super_resolution_amd import driver
         clip = clips[my_clips[0]]
         with torch.no_grad():
@@ -299,6 +299,12 @@ def main():
                                             h2d_bytes_per_step=int(win_host.numel()), d2h_bytes_per_step=int(out_host.numel()),
                                             note="uint8 HR window host -> device, nearest x1/scale + float on the device, forward, "
                                                  "uint8 HR frame device -> host; serial on one stream -- NOT the headline value")
+
+    if world == 1 and args.clips == 0 and not args.no_extras:
+        try:   # the extras must never cost the headline line
+            run_extras()
+        except Exception as exc:   # noqa: BLE001
+            extras["extras_error"] = repr(exc)[:300]
     if rank == 0:
         assert gathered is not None and gathered.shape[0] * gathered.shape[1] == total_frames
         assert torch.isfinite(gathered[0].float()).all() and torch.isfinite(gathered[-1].float()).all()
@@ -372,6 +378,7 @@ def main():
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             progress("timing the CPU oracle on LR 64x64 / 96x96 / 128x128 tiles (about a minute)")
+            torch.cuda.synchronize()
             cb = cpu_baseline(scale)
             sec_full = cb["intercept_s"] + cb["slope_s_per_px"] * h * w
             pts = ", ".join(f"{int(p ** 0.5)}x{int(p ** 0.5)}: {s} s" for p, s in cb["points"])
