@@ -853,10 +853,10 @@ template <int KH, int MT>
 static void launch_patch_r8(const ConvP& p, int N, hipStream_t stream) {
     const int lds_patch = (P8_H + KH - 1) * (P8_W + p.kw - 1) * 64, lds_out = 4 * P8_R * 16 * 32 * MT;
     const int lds = lds_patch > lds_out ? lds_patch : lds_out;
-    static bool raised = false;   // (per instantiation)
-    if (lds > 64 * 1024 && !raised) {
+    static unsigned long long raised = 0;   // (per instantiation; one bit per device: the attribute is per device)
+    if (lds > 64 * 1024 && !vsr::device_marked(raised)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch_r8<KH, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
+        vsr::mark_device(raised);
     }
     const unsigned tiles = vsr::cdiv(p.Ho, P8_H) * vsr::cdiv(p.Wo, P8_W);
     hipLaunchKernelGGL((k_conv_patch_r8<KH, MT>), dim3(tiles, N, p.cout_pad / (16 * MT)), dim3(256), lds, stream, p);
