@@ -278,6 +278,9 @@ size_t vsr_sr_utd_s2_blob_bytes(void);
 int vsr_sr_utd_s2_strip_width(void);
 int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                       vsr_stream_t stream);
+/* Measurement hook: 0 the step with its uniform branches (pairs outside the image skipped), 1 the branch-free step (one basic
+ * block; bit-identical output).  Returns the previous variant. */
+int vsr_sr_utd_s2_variant(int variant);
 
 /* The tail for the scale-2 extension in one launch (csrc/sr_tail_s2.hip): `out` DeconvBlock (k6 s2 p2 + PReLU) -> conv_out 3x3
  * (32 -> 3, bias) -> raw planes [N,3,2h,2w] fp32 (decimate != 0: the pixels (2i, 2j) only -> [N,3,h,w]); the x2 map stays in

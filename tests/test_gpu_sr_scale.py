@@ -192,3 +192,26 @@ def test_fused_x2_tail_segmentations_and_unfused_build(monkeypatch, hw):
     unf = mu(x)
     assert "tail_s2" not in mu._packed()
     assert (unf - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7), (3, 20, 70), (1, 33, 31)])
+def test_fused_x2_stage_flat_variant_bit_identical(shape):
+    """k_utd_s2's branch-free step (vsr_sr_utd_s2_variant(1): out-of-image pairs computed and zeroed, partial tiles always
+    stored, rows that are not output stored out of range) against the step with its uniform branches."""
+    from video_super_resolution_amd import _lib as L
+    m, _ = sr_module(2)
+    m.precision = "fp16"
+    N, h, w = shape
+    st = m._packed()["stage"][0]
+    a = torch.from_numpy((np.random.RandomState(h * 7 + w).randn(N, h, w, 32) * 20).astype(np.float16)).cuda()
+    lib = L.load()
+    try:
+        lib.vsr_sr_utd_s2_variant(0)
+        ref = st(a, m._chain).clone()
+        lib.vsr_sr_utd_s2_variant(1)
+        got = st(a, m._chain).clone()
+        out = torch.empty_like(got)
+        L.check(lib.vsr_sr_utd_s2_f16(L.dptr(a, torch.float16), L.dptr(st.blob, torch.uint8), L.dptr(out, torch.float16), N, h, w, 4, 1, L.stream()))
+    finally:
+        lib.vsr_sr_utd_s2_variant(0)
+    assert torch.equal(got, ref) and torch.equal(out, ref)

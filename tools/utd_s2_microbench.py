@@ -11,14 +11,24 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 m = fill_module_(SRProjectionModule(upscale_factor=2).eval(), 0, "model.").cuda()
 st = m._packed()["stage"][0]
 a = (torch.randn(N, h, w, 32, device="cuda") * 20).half()
-for _ in range(2): st(a, m._chain)
+from video_super_resolution_amd import _lib as L
+lib = L.load()
+outs = {}
+res = {0: [], 1: []}
+for v in (0, 1):
+    lib.vsr_sr_utd_s2_variant(v)
+    for _ in range(2): outs[v] = st(a, m._chain).clone()
 torch.cuda.synchronize()
-res = []
-for r in range(4):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): st(a, m._chain)
-    e1.record(); torch.cuda.synchronize()
-    res.append(e0.elapsed_time(e1) / reps)
-ms = sorted(res)[len(res) // 2]
-print(f"k_utd_s2 {N}x{h}x{w}: {ms:.3f} ms  -> {N*h*w*155648/ms/1e9:.1f} TFLOP/s")
+for r in range(4):   # interleaved rounds on one device
+    for v in (0, 1):
+        lib.vsr_sr_utd_s2_variant(v)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): st(a, m._chain)
+        e1.record(); torch.cuda.synchronize()
+        res[v].append(e0.elapsed_time(e1) / reps)
+lib.vsr_sr_utd_s2_variant(0)
+for v, name in ((0, "branches"), (1, "flat")):
+    ms = sorted(res[v])[len(res[v]) // 2]
+    print(f"k_utd_s2 [{name:8s}] {N}x{h}x{w}: {ms:.3f} ms  -> {N*h*w*155648/ms/1e9:.1f} TFLOP/s")
+print("bit-identical:", torch.equal(outs[0], outs[1]))

@@ -28,7 +28,7 @@ constexpr int S2_LR_SLOT = S2_LRC * 64;
 constexpr int S2_LR_BYTES = 4 * S2_LR_SLOT;  // rows m-1, m, m+1 + the row being loaded
 constexpr int S2_PART_W = 32 * PART_PX_PITCH;
 constexpr int S2_PART_BUF = 4 * S2_PART_W;
-constexpr int S2_BIAS_BYTES = 256;           // b_up[32], b_dt[32] fp32 (read at use: the kernel sits at the 256-register line)
+constexpr int S2_BIAS_BYTES = 256 + 2048;    // b_up[32], b_dt[32] fp32 + the two 1x1 fragments (read at use: the kernel sits at the 256-register line)
 constexpr int S2_LDS = S2_LR_BYTES + 2 * S2_PART_BUF + S2_BIAS_BYTES;
 
 constexpr int S2_BLOB_UP = 0;                           // [wave 4][tap 9 = dy*3+dx][mt 2][lane 64][8] fp16
@@ -60,7 +60,10 @@ __device__ __forceinline__ void shift_tiles(const h8 (&T)[2], h8 (&B)[2]) {
     B[1] = __builtin_bit_cast(h8, b1);
 }
 
-template <bool ALLMAX>
+// FLAT: one basic block per step -- pairs outside the image are computed and zeroed (two steps per march), the partial tiles
+// are always stored and the reduce of a row that is not output stores to an out-of-range buffer offset -- so that the
+// compiler may schedule across what were branch boundaries (A/B: vsr_sr_utd_s2_variant).
+template <bool ALLMAX, bool FLAT>
 __global__ void __launch_bounds__(256, 2)
 k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _Float16* __restrict__ out, int h, int w,
          int rows_per_seg) {
@@ -80,7 +83,7 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
     if (r0 >= r1) return;   // uniform per workgroup
 
     // ---- weights -> registers, once per workgroup
-    h8 Aup[9][2], Adn[3][3][2], adt[2];
+    h8 Aup[9][2], Adn[3][3][2];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -93,11 +96,12 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
                 Adn[k][s][mt] = *reinterpret_cast<const h8*>(blob + S2_BLOB_DN + ((((wv * 3 + k) * 3 + s) * 2 + mt) * 64 + lane) * 16);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) adt[mt] = *reinterpret_cast<const h8*>(blob + S2_BLOB_DT + (mt * 64 + lane) * 16);
     const float* fpar = reinterpret_cast<const float*>(blob + S2_BLOB_F32);
     float* const bias_s = reinterpret_cast<float*>(smem + S2_LR_BYTES + 2 * S2_PART_BUF);
     if (tid < 64) bias_s[tid] = fpar[tid];   // (visible after the prologue's barrier)
+    unsigned char* const adt_s = smem + S2_LR_BYTES + 2 * S2_PART_BUF + 256;
+    if (tid < 128) *reinterpret_cast<u4v*>(adt_s + tid * 16) = *reinterpret_cast<const u4v*>(blob + S2_BLOB_DT + tid * 16);
+    auto adt = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const h8*>(adt_s + (mt * 64 + lane) * 16); };
     // this lane's accumulator rows are channels {4g..4g+3} of tile mt
     auto bup = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f4*>(bias_s + 16 * mt + 4 * g); };
     auto bdt = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f4*>(bias_s + 32 + 16 * mt + 4 * g); };
@@ -128,7 +132,7 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
     typedef float f2v __attribute__((ext_vector_type(2)));
     const int part_wr = wv * S2_PART_W + l15 * PART_PX_PITCH + 4 * g * 4;   // + 64 mt + 16 nt PART_PX_PITCH
     const int part_rd = rj * PART_PX_PITCH + rc4 * 16;                       // + k S2_PART_W
-    auto reduce_store = [&](int i, const unsigned char* pbase) __attribute__((always_inline)) {
+    auto reduce_store = [&](int i, const unsigned char* pbase, bool ok) __attribute__((always_inline)) {
         f4 s = *reinterpret_cast<const f4*>(pbase + part_rd);
 #pragma unroll
         for (int k = 1; k < 4; ++k) s += *reinterpret_cast<const f4*>(pbase + part_rd + k * S2_PART_W);
@@ -138,7 +142,7 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
         for (int e = 0; e < 4; ++e) v[e] = s[e] >= 0.0f ? s[e] : s[e] * a_dn;
         const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{v[0], v[1]}, h2));
         const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{v[2], v[3]}, h2));
-        const unsigned off = red_ok ? (unsigned)(((((size_t)n * h + i) * w + x0 + rj) * NF + 4 * rc4) * 2) : 0xFFFFFFFFu;
+        const unsigned off = (red_ok && ok) ? (unsigned)(((((size_t)n * h + i) * w + x0 + rj) * NF + 4 * rc4) * 2) : 0xFFFFFFFFu;
         __builtin_amdgcn_raw_buffer_store_b64(u2v{lo, hi}, out_rsrc, off, 0, 0);
     };
 
@@ -169,7 +173,8 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
 
     for (int m = r0 - 1; m <= r1; ++m) {
         const u4v nxt = fetch_lr(m + 2);
-        if (m >= 0 && m < h) {   // (uniform) pairs outside the image are zero padding: nothing to add
+        const bool pair_ok = m >= 0 && m < h;   // (uniform) pairs outside the image are the conv's zero padding
+        if (FLAT || pair_ok) {
             // ---- deconv of HR row 2m+r, columns 2q+c: 9 taps
             f4 d[2][2];
 #pragma unroll
@@ -195,10 +200,10 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const h8 a1 = act_pack(d[0][nt], d[1][nt], a_up2, up_max);
-                const f4 e0 = mfma16(adt[0], a1, bdt(0));
-                const f4 e1 = mfma16(adt[1], a1, bdt(1));
+                const f4 e0 = mfma16(adt(0), a1, bdt(0));
+                const f4 e1 = mfma16(adt(1), a1, bdt(1));
                 h8 t = act_pack(e0, e1, a_dt2, dt_max);
-                if (!col_ok[nt]) {
+                if (!col_ok[nt] || (FLAT && !pair_ok)) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) t[e] = (_Float16)0.0f;
                 }
@@ -231,7 +236,7 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
         // ---- output row m-1 has all its kernel rows: partial tile of this wave -> LDS; rotate the accumulator sets
         const bool row_out = (m - 1 >= r0) && (m - 1 < r1);
         unsigned char* const pbase = part + (m & 1) * S2_PART_BUF;
-        if (row_out) {
+        if (FLAT || row_out) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -248,13 +253,22 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
             }
         if (lr_loader) *reinterpret_cast<u4v*>(lrr + lr_slot(m + 2) + lr_st) = nxt;   // over row m-2 (last read in step m-1)
         __syncthreads();
-        if (row_out) reduce_store(m - 1, pbase);
+        if (FLAT) reduce_store(m - 1, pbase, row_out);
+        else if (row_out) reduce_store(m - 1, pbase, true);
     }
 }
 
 }  // namespace
 
+static int g_utd_s2_variant = 0;
+
 extern "C" {
+
+int vsr_sr_utd_s2_variant(int v) {
+    const int old = g_utd_s2_variant;
+    g_utd_s2_variant = v & 1;
+    return old;
+}
 
 size_t vsr_sr_utd_s2_blob_bytes(void) { return S2_BLOB_BYTES; }
 int vsr_sr_utd_s2_strip_width(void) { return S2_TX; }
@@ -268,12 +282,10 @@ int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h,
     if ((size_t)N * h * w * NF * 2 >= (1ull << 32) - 16) return vsr::fail(VSR_E_UNSUPPORTED, "sr_utd_s2: tensors beyond 4 GiB");
     const unsigned strips = vsr::cdiv(w, S2_TX), segs = vsr::cdiv(h, rows_per_seg);
     VSR_REQUIRE(segs <= 65535, "sr_utd_s2: too many row segments");
-    if (slopes_le_one)
-        hipLaunchKernelGGL(k_utd_s2<true>, dim3(strips, segs, N), dim3(256), S2_LDS, vsr::S(stream), (const _Float16*)in,
-                           (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
-    else
-        hipLaunchKernelGGL(k_utd_s2<false>, dim3(strips, segs, N), dim3(256), S2_LDS, vsr::S(stream), (const _Float16*)in,
-                           (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
+    typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
+    static const kern_t kerns[4] = {k_utd_s2<false, false>, k_utd_s2<true, false>, k_utd_s2<false, true>, k_utd_s2<true, true>};
+    hipLaunchKernelGGL(kerns[2 * g_utd_s2_variant + (slopes_le_one ? 1 : 0)], dim3(strips, segs, N), dim3(256), S2_LDS, vsr::S(stream),
+                       (const _Float16*)in, (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
     return vsr::launched("sr_utd_s2");
 }
 
