@@ -1,0 +1,34 @@
+"""bench.py prints ONE JSON line that keeps the driver's contract (metric, value, unit, n_gpus, steps, warmup, ms_per_step,
+higher_is_better, scaling, vs_baseline, dtype, data, config.workload) plus the `roofline` object; run at a small size so the
+check costs seconds (the CPU baseline and the extra loops are skipped: they have their own switches)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [[], ["--config", "C3B"], ["--clips", "2"]])
+def test_bench_line_contract(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--lr-h", "64", "--lr-w", "96",
+           "--no-cpu-baseline", "--no-extras"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f16"
+    assert "workload" in d["config"] and d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - (2 if "--clips" in extra else 1)) < 0.05 * max(1, d["value"] * d["ms_per_step"] / 1e3)
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "whole_frame"):
+        assert k in r, k
+    assert r["bound"] in ("mfma", "hbm") and 0 < r["frac"] < 1
