@@ -174,3 +174,27 @@ def test_streaming_mode_matches_per_window_evaluation(gpu_vsr_f16):
     est2, _ = m(clip[1:4], None, None, est, train=False)
     assert torch.isfinite(est2).all()
     m.temporal_cache = False
+
+
+def test_reference_driver_call_with_loss_fp16(golden, gpu_vsr_f16):
+    """The same replay in the fp16 configuration: SR net on the MFMA path, and the loss's twelve VGG16 passes and its OSVOS on
+    the MFMA convolution (trunk_exec.VGGFeatExec / OSVOSExec).  fp16 frames and fp16 feature maps against the reference's
+    float32 loss: 5e-3 relative."""
+    import copy
+    from video_super_resolution_amd import driver
+    g = golden("g10_loss")
+    model = copy.deepcopy(gpu_vsr_f16)
+    model.loss4object.reset()
+    data, target, high_frames = driver.ingest_item(torch.from_numpy(g["hr"]).unsqueeze(0).cuda(), 4)
+    estimated_image = None
+    for rep, want in enumerate((g["loss0"], g["loss1"])):
+        hf_item = high_frames.clone()
+        for x, y, high_frame in zip(data, target, hf_item):
+            with torch.no_grad():
+                output, real_loss = model(x, y, high_frame, estimated_image)
+                estimated_image = output
+        rel = abs(float(real_loss) - float(want)) / abs(float(want))
+        print(f"[train=True fp16 call {rep}] loss {float(real_loss):.3f} vs reference {float(want):.3f} (rel {rel:.2e})")
+        assert rel < 5e-3
+    assert model.SR_loss._exec is not None and model.loss4object._exec is not None   # the MFMA executors ran
+    assert (model.loss4object.mask.cpu().numpy() != g["mask"]).mean() < 1e-2

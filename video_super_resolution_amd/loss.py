@@ -12,10 +12,11 @@ Mirrors loss_function.py:9-101 and `VSR.loss_calculate` (network/video_super_res
 
 Sub-module and parameter names are the reference's (`SR_loss.loss_network.<i>`, `Flow_loss.SR_loss.loss_network.<i>`,
 `loss4object.VOS.net.*`), so a full-model `state_dict` interchanges.  Everything runs on the module's device under
-`no_grad` (the reference computes the loss under no_grad too, :72): the VGG16 trunks go through stock PyTorch-ROCm
-convolutions in float32, like the fp32 configuration's guidance trunks -- the loss is not on the inference path the
-benchmark times; it exists so that the reference driver's own call `model(x, y, high_frame, estimated_image)`
-(main.py:201, train defaults to True) works and returns the same number.
+`no_grad` (the reference computes the loss under no_grad too, :72).  Like the guidance trunks, the VGG16 feature networks and
+the loss's own OSVOS follow `VSR.precision`: "fp16" = the hand-written NHWC fp16 MFMA convolution (trunk_exec.VGGFeatExec /
+OSVOSExec), "fp32" = stock float32 convolutions.  The loss is not on the inference path the benchmark times; it exists so that
+the reference driver's own call `model(x, y, high_frame, estimated_image)` (main.py:201, train defaults to True) works and
+returns the same number.
 """
 from __future__ import annotations
 
@@ -63,12 +64,32 @@ class SR_loss(nn.Module):   # noqa: N801 (the reference's class name)
         self.loss_network = vgg16_features31()
         self.mse_loss = nn.MSELoss()
         self.tv_loss = TVLoss()
+        # "fp16": the VGG16 trunk on the hand-written NHWC fp16 MFMA convolution (trunk_exec.VGGFeatExec), like the guidance
+        # trunks of the fp16 configuration; "fp32": stock float32 convolutions.  Set by VSR.forward from VSR.precision.
+        self.precision = "fp32"
+        self._exec = None
+
+    def _features(self, x):
+        if self.precision == "fp16" and x.is_cuda:
+            from .trunk_exec import TrunkExecCache, VGGFeatExec
+            if self._exec is None:
+                self._exec = TrunkExecCache(self.loss_network, VGGFeatExec)
+            return self._exec.get()(x.contiguous())
+        return self.loss_network(x)
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == "_exec" else copy.deepcopy(v, memo)   # (executors hold per-instance buffers)
+        return new
 
     def forward(self, output, target):
         dev = next(self.loss_network.parameters()).device
         output = output.to(dev, torch.float32).permute(0, 3, 1, 2)   # transpose1323
         target = target.to(dev, torch.float32).permute(0, 3, 1, 2)
-        perception_loss = self.mse_loss(self.loss_network(output), self.loss_network(target))
+        perception_loss = self.mse_loss(self._features(output), self._features(target))
         image_loss = self.mse_loss(output, target)
         return image_loss + 0.006 * perception_loss + 2e-8 * self.tv_loss(output)
 
@@ -95,13 +116,29 @@ class GetObjectsForOBJLoss(nn.Module):
         super().__init__()
         self.VOS = VOSProjectionModule().eval()
         self.mask = None   # [3,H,W] bool, cached after the first call like the reference (loss_function.py:69-74, defect D7)
+        self.precision = "fp32"   # "fp16": OSVOS on the MFMA convolution (trunk_exec.OSVOSExec), as in the inference path
+        self._exec = None
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == "_exec" else copy.deepcopy(v, memo)
+        return new
 
     def reset(self):
         self.mask = None
 
     def forward(self, outputs, target=None, SR=False):   # noqa: N803
         if self.mask is None:
-            seg = self.VOS(outputs[0].to(torch.float32), outputs[1].to(torch.float32))   # [H,W] in {0,1}
+            net = None
+            if self.precision == "fp16" and outputs[0].is_cuda:
+                from .trunk_exec import OSVOSExec, TrunkExecCache
+                if self._exec is None:
+                    self._exec = TrunkExecCache(self.VOS.net, OSVOSExec)
+                net = self._exec.get()
+            seg = self.VOS(outputs[0].to(torch.float32), outputs[1].to(torch.float32), net)   # [H,W] in {0,1}
             self.mask = torch.stack((seg == 1,) * 3)                                    # maskprocess(obj_segmentation == 1)
         if SR:
             # np.ma.MaskedArray(data [H,W,3] | [1,H,W,3], mask [3,H,W]): equal sizes -> numpy RESHAPES the mask to the data's shape
@@ -118,6 +155,7 @@ class GetObjectsForOBJLoss(nn.Module):
 def loss_calculate(model, target, outputs) -> torch.Tensor:
     """VSR.loss_calculate (network/video_super_resolution.py:71-80).  target [1,H,W,3], outputs = high_frames [3,H,W,3]."""
     with torch.no_grad():
+        model.SR_loss.precision = model.Flow_loss.SR_loss.precision = model.loss4object.precision = getattr(model, "precision", "fp32")
         gen_sr = model.SR_loss(outputs[0:1], target)
         masked = model.loss4object(outputs[:2], target, SR=True)
         obj_sr = model.SR_loss(masked[0], masked[1])

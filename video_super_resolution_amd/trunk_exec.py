@@ -487,6 +487,29 @@ class OSVOSExec:
         return out
 
 
+# ------------------------------------------------------------------------------------------------ VGG16 features (loss)
+class VGGFeatExec:
+    """`nn.Sequential(*list(vgg16().features)[:31])` (loss_function.py:12-13) on the MFMA convolution: 13 conv3x3 + ReLU (the first
+    one as a dense-K stem on the RGB input), five MaxPool2d(2, 2).  [N,3,H,W] float (0..255) -> [N,512,H/32,W/32] float32."""
+
+    def __init__(self, seq):
+        self.items = []
+        for m in seq:
+            if isinstance(m, nn.MaxPool2d):
+                self.items.append("M")
+            elif isinstance(m, nn.Conv2d):
+                self.items.append(HConvStem(m.weight, m.bias, pad=1, act=ACT_RELU) if m.in_channels == 3 else
+                                  HConv(m.weight, m.bias, pad=1, act=ACT_RELU))
+
+    @L.on_device
+    @torch.no_grad()
+    def __call__(self, x_nchw):
+        x = to_nhwc_half(x_nchw.float().contiguous(), 4)
+        for it in self.items:
+            x = pool2x2(x, 0, x.shape[3], 0) if it == "M" else it(x)   # MaxPool2d(2, 2): floor mode
+        return x.permute(0, 3, 1, 2).float()
+
+
 class TrunkExecCache:
     """Version-checked cache of an executor built from a master module."""
 
