@@ -179,7 +179,7 @@ def test_streaming_mode_matches_per_window_evaluation(gpu_vsr_f16):
 def test_reference_driver_call_with_loss_fp16(golden, gpu_vsr_f16):
     """The same replay in the fp16 configuration: SR net on the MFMA path, and the loss's twelve VGG16 passes and its OSVOS on
     the MFMA convolution (trunk_exec.VGGFeatExec / OSVOSExec).  fp16 frames and fp16 feature maps against the reference's
-    float32 loss: 5e-3 relative."""
+    float32 loss: 2e-3 relative."""
     import copy
     from video_super_resolution_amd import driver
     g = golden("g10_loss")
@@ -195,6 +195,6 @@ def test_reference_driver_call_with_loss_fp16(golden, gpu_vsr_f16):
                 estimated_image = output
         rel = abs(float(real_loss) - float(want)) / abs(float(want))
         print(f"[train=True fp16 call {rep}] loss {float(real_loss):.3f} vs reference {float(want):.3f} (rel {rel:.2e})")
-        assert rel < 5e-3
+        assert rel < 2e-3                                          # measured 1.0e-4 / 6.3e-5
     assert model.SR_loss._exec is not None and model.loss4object._exec is not None   # the MFMA executors ran
     assert (model.loss4object.mask.cpu().numpy() != g["mask"]).mean() < 1e-2
