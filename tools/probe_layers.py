@@ -1,5 +1,5 @@
 """Per-layer time of the three guidance trunks at the bench size (HIP events around every convolution launch,
-one stream): where the trunk milliseconds go.  usage: probe_layers.py [flow|depth|vos] [top]"""
+one stream): where the trunk milliseconds go.  usage: probe_layers.py [flow|depth|vos] [top] [h w]"""
 import os, sys
 os.environ.setdefault('MIOPEN_FIND_MODE', '2'); os.environ.setdefault('MIOPEN_LOG_LEVEL', '2')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ from video_super_resolution_amd.weights import fill_module_
 torch.set_grad_enabled(False)
 which = sys.argv[1] if len(sys.argv) > 1 else "flow"
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-h, w = 540, 960
+h, w = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (540, 960)
 m = fill_module_(VSR().eval(), 0).cuda()
 fr = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (4, h, w, 3)).astype(np.float32)).cuda()
 fx, hx, ox = m._flow_exec.get(), m._depth_exec.get(), m._vos_exec.get()

@@ -628,9 +628,14 @@ constexpr int PT_H = 8, PT_W = 32;
 __device__ __forceinline__ void stage_patch(const ConvP& p, unsigned char* patch, int n, int ch, int iy0, int ix0, int PH, int PW, int tid) {
     constexpr int U = 6;
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-    const size_t img_bytes = (size_t)p.H * p.W * p.in_ld * 2;
+    // the buffer resource starts at the patch's first image row: offsets then span PH rows only, whatever the size of the image
+    // (a 2160 x 3840 x 224-channel map is 3.7 GB; with the resource at the image base the 32-bit offsets capped an image at
+    // 2 GiB and such layers fell back to the gather kernel: 127 ms of a 437 ms frame at 4K -> 8K)
+    const int by = iy0 > 0 ? iy0 : 0;
+    const size_t rem_bytes = (size_t)(p.H - by) * p.W * p.in_ld * 2;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<_Float16*>(p.in) + (size_t)n * p.H * p.W * p.in_ld, 0, (int)(unsigned)img_bytes, 0x00020000);
+        const_cast<_Float16*>(p.in) + ((size_t)n * p.H + by) * p.W * p.in_ld, 0, (int)(rem_bytes < 0x7FFFFFF0ull ? rem_bytes : 0x7FFFFFF0ull),
+        0x00020000);
     const int total = PH * PW * 4;
     const unsigned coff = (unsigned)(p.in_coff + ch * 32) * 2;
     for (int q0 = 0; q0 < total; q0 += 256 * U) {
@@ -643,7 +648,7 @@ __device__ __forceinline__ void stage_patch(const ConvP& p, unsigned char* patch
             const int py = pix / PW, px = pix - py * PW;
             const int iy = iy0 + py, ix = ix0 + px;
             const bool ok = q < total && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.in_ld * 2 + coff + c4 * 16) : 0xFFFFFFFFu;
+            const unsigned off = ok ? ((unsigned)((iy - by) * p.W + ix) * (unsigned)p.in_ld * 2 + coff + c4 * 16) : 0xFFFFFFFFu;
             v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
             dst[u] = q < total ? pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4) : -1;
         }
@@ -1452,7 +1457,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     // 32-channel chunk instead of gathering it kh*kw times from L2).  Measured on MI355X (tools/conv_microbench.py).
     const int patch_lds = (PT_H + kh - 1) * (PT_W + kw - 1) * 64;
     const bool patch_legal = stride == 1 && (stride_x <= 0 || stride_x == 1) && Ho >= 4 && Wo >= 16 && patch_lds <= 64 * 1024 && N <= 65535 && (cout_pad & 15) == 0 &&
-                             (unsigned long long)H * W * in_ld * 2 < (1ull << 31);   // (staging uses 32-bit byte offsets per image)
+                             (unsigned long long)(kh + 16) * W * in_ld * 2 < (1ull << 31);   // (staging: 32-bit byte offsets from the patch's first row)
     const bool patch_pays = (long long)Ho * Wo >= 8192 && kh * kw >= 9 && ((cout_pad == 16 && (cin >> 5) <= 8) || cout_pad >= 32);
     const bool force = g_patch_mode == 2 || g_patch_mode == 6 || g_patch_mode == 7;
     const bool no_r8 = g_patch_mode == 3 || g_patch_mode == 5 || g_patch_mode == 6 || g_patch_mode == 7, no_rows = g_patch_mode == 3 || g_patch_mode == 7;
