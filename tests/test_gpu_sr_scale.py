@@ -82,30 +82,30 @@ def test_plane_chunking_is_bit_identical(monkeypatch):
     assert torch.equal(m(x, decimate=True), ref[..., ::2, ::2])
 
 
-@pytest.mark.parametrize("precision,bar", [("fp32", 60.0), ("fp16", 55.0)])
-def test_vsr_forward_scale2_vs_oracle(cpu_vsr, precision, bar):
+@pytest.mark.parametrize("scale,precision,bar", [(2, "fp32", 60.0), (2, "fp16", 55.0), (3, "fp16", 55.0)])
+def test_vsr_forward_scaled_vs_oracle(cpu_vsr, scale, precision, bar):
     """The whole forward with the x2 SR net (BASELINE configs C1 / C2 / C3-B / C5 are labelled x2): guidance trunks as in
     the x4 tests, SR net swapped.  Same image-quality bar as the x4 end-to-end tests (discrete guidance planes)."""
     from video_super_resolution_amd import VSR
-    m = VSR(upscale_factor=2).eval()
+    m = VSR(upscale_factor=scale).eval()
     sd = {k: v for k, v in cpu_vsr.state_dict().items() if not k.startswith("model.")}
     m.load_state_dict(sd, strict=False)                     # same seeded guidance weights as the x4 model
     fill_module_(m.model, seed=0, prefix="model.")
     P = {k: v.detach().clone() for k, v in m.state_dict().items()}
     data = torch.from_numpy(np.random.RandomState(21).randint(0, 256, (3, 64, 72, 3)).astype(np.float32))
     with torch.no_grad():
-        ref0 = O.vsr_forward(P, data, None, upscale_factor=2)
-        ref1 = O.vsr_forward(P, data, ref0, upscale_factor=2)
+        ref0 = O.vsr_forward(P, data, None, upscale_factor=scale)
+        ref1 = O.vsr_forward(P, data, ref0, upscale_factor=scale)
     m = m.cuda()
     m.precision = m.model.precision = precision
-    hf = torch.zeros(3, 128, 144, 3, device="cuda")
+    hf = torch.zeros(3, 64 * scale, 72 * scale, 3, device="cuda")
     out0, loss = m(data.cuda(), None, hf, None, train=False)
     out1, _ = m(data.cuda(), None, hf, out0, train=False)
-    assert loss is None and out0.shape == (1, 128, 144, 3) and torch.equal(hf[1], out1[0])
+    assert loss is None and out0.shape == (1, 64 * scale, 72 * scale, 3) and torch.equal(hf[1], out1[0])
     for out, ref in ((out0, ref0), (out1, ref1)):
         err = np.abs(out.cpu().numpy() - ref.numpy())
         psnr = 10 * np.log10(255.0 ** 2 / max(float(np.mean(err ** 2)), 1e-20))
-        print(f"[x2 e2e {precision}] PSNR(255) {psnr:.2f} dB, p99 {np.percentile(err, 99):.4f}")
+        print(f"[x{scale} e2e {precision}] PSNR(255) {psnr:.2f} dB, p99 {np.percentile(err, 99):.4f}")
         assert psnr > bar, psnr
 
 
