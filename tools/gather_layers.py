@@ -1,0 +1,28 @@
+"""Gather-kernel times of real low-resolution trunk layer shapes (the LDS-patch kernels switched off)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from video_super_resolution_amd import igemm, _lib as L
+torch.set_grad_enabled(False)
+cases = [("HG c32->64 k7 4x67x120", 4, 32, 67, 120, 64, 7, 1), ("HG c32->64 k3 4x67x120", 4, 32, 67, 120, 64, 3, 1),
+         ("Flow c512->512 k3 2x32x60", 2, 512, 32, 60, 512, 3, 1), ("Flow c256->256 k3 2x64x120", 2, 256, 64, 120, 256, 3, 1),
+         ("Flow c256->512 k3 s2 2x64x120", 2, 256, 64, 120, 512, 3, 2), ("Flow c128->256 k5 s2 2x128x240", 2, 128, 128, 240, 256, 5, 2),
+         ("Flow c1024->1024 k3 2x8x15", 2, 1024, 8, 15, 1024, 3, 1), ("Flow c224->2 k3 2x128x240", 2, 224, 128, 240, 2, 3, 1)]
+lib = L.load()
+if len(sys.argv) > 1: cases = [cases[int(sys.argv[1])]]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+lib.vsr_conv2d_tuning(1)   # gather path only
+for name, N, cin, H, W, cout, k, st in cases:
+    x = igemm.to_nhwc_half(torch.randn(N, cin, H, W, device="cuda"))
+    conv = igemm.HConv(torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5, torch.zeros(cout, device="cuda"), stride=st, pad=(k - 1) // 2)
+    row = []
+    for bits in (0, 2, 4, 6, 8, 14, 30):
+        lib.vsr_conv2d_tuning(2000 + bits)
+        for _ in range(3): conv(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): conv(x)
+        e1.record(); torch.cuda.synchronize()
+        row.append(f"{bits}:{e0.elapsed_time(e1) / reps * 1e3:6.1f}")
+    print(f"{name:36s} " + "  ".join(row) + " us", flush=True)

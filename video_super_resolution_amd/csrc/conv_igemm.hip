@@ -117,10 +117,14 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     constexpr int A_HALF = BN * 64;             // weight tile of one (tap, chunk)
     constexpr int B_HALF = BM * 64;             // pixel tile of one (tap, chunk)
     constexpr int STAGE = 2 * (A_HALF + B_HALF);  // one K step = two (tap, chunk) pairs = 64 K elements
-    constexpr int A_PIECES = A_HALF / 16;       // 16-byte pieces per half (<= 256)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    constexpr int A_PIECES = A_HALF / 16;       // 16-byte pieces per half
+    constexpr int AP = (A_PIECES + 255) / 256;  // ... per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // operand ring [2][STAGE], then the K-walk table
     auto As = [&](int b, int hf) __attribute__((always_inline)) { return smem + b * STAGE + hf * (A_HALF + B_HALF); };
     auto Bs = [&](int b, int hf) __attribute__((always_inline)) { return smem + b * STAGE + hf * (A_HALF + B_HALF) + A_HALF; };
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    u4* const tab = reinterpret_cast<u4*>(smem + 2 * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -141,72 +145,90 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     const int ks0 = zsplit * ks_per;
     const int nk = min(nk_all, ks0 + ks_per);
 
-    // ---- the two pixel pieces this thread stages per pair: piece q = tid + 256 r -> row q>>2, chunk q&3
-    int pn[2], piy0[2], pix0[2];
-    bool pok[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int row = (tid + 256 * r) >> 2;
-        const long long m = m0 + row;
-        pok[r] = m < M;
-        const long long mm = pok[r] ? m : 0;
-        const int n = (int)(mm / ((long long)p.Ho * p.Wo));
-        const int rem = (int)(mm - (long long)n * p.Ho * p.Wo);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        pn[r] = n;
-        piy0[r] = oy * p.stride - pad_y;
-        pix0[r] = ox * p.stride_x - pad_x;
-    }
-    const int bchunk = tid & 3;
-    const int brow[2] = {tid >> 2, (tid + 256) >> 2};
-
-    // Global -> register staging, two K steps deep: the loads of step ks+2 are issued at the top of step ks and stored to
-    // LDS at the end of step ks+1.  Every load is a buffer load whose offset is out of range when the piece does not
-    // exist (padding, tail, idle thread) -- the hardware returns zeros -- so a step issues a FIXED number of loads and
-    // hipcc can wait with vmcnt(6) for the older set only (conditional loads forced vmcnt(0): one step of cover).
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(wpk), 0, (int)((size_t)(STEM ? p.kh : p.kh * p.kw * nchunk) * p.cout_pad * 64), 0x00020000);
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.in_ld * 2), 0x00020000);
-    u4 ra[2][2], rb[2][2][2];
-    auto gload = [&](int ks, auto setc) __attribute__((always_inline)) {
+
+    // ---- the K walk as a table in LDS (see k_conv_igemm_d)
+    {
+        const int pr0 = 2 * ks0, ntab = 2 * (ks_per + 5);
+        const unsigned wstep = (unsigned)p.cout_pad * 64u;
+        for (int i = tid; i < ntab; i += 256) {
+            const int pr = pr0 + i;
+            const bool live = pr < npair && pr < 2 * nk;
+            const int prc = live ? pr : 0;
+            const int tap = prc / nchunk, ch = prc - tap * nchunk;
+            const int ky = STEM ? tap : tap / p.kw, kx = STEM ? 0 : tap - ky * p.kw;
+            const unsigned delta = ((unsigned)(ky * p.W + kx) * (unsigned)p.in_ld + (unsigned)ch * 32u) * 2u;
+            tab[i] = live ? u4{delta, (unsigned)ky, (unsigned)kx, (unsigned)pr * wstep} : u4{0u, 1u << 29, 0u, 0x80000000u};
+        }
+    }
+
+    // ---- the two pixel pieces this thread stages per pair: piece q = tid + 256 r -> row q>>2, chunk piece q&3: four
+    //      neighbouring lanes fetch the 64 contiguous bytes of one pixel's chunk (one L1 tag look-up per 64 bytes; in the MFMA
+    //      fragment layout of k_conv_igemm_d every lane of a load sits in another cache line)
+    const int bchunk = tid & 3;
+    const int brow[2] = {tid >> 2, (tid + 256) >> 2};
+    int piy0[2], pix0[2];
+    unsigned pbase[2];
+    bool xok0[2], xok1[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const long long m = m0 + brow[r];
+        const bool ok = m < M;
+        const long long mm = ok ? m : 0;
+        const int n = (int)(mm / ((long long)p.Ho * p.Wo));
+        const int rem = (int)(mm - (long long)n * p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        piy0[r] = ok ? oy * p.stride - pad_y : -(1 << 28);
+        pix0[r] = ox * p.stride_x - pad_x + (STEM ? 2 * bchunk : 0);
+        pbase[r] = (unsigned)(((((long long)n * p.H + piy0[r]) * p.W + pix0[r]) * p.in_ld + (STEM ? 0 : p.in_coff + bchunk * 8)) * 2);
+        xok0[r] = (unsigned)pix0[r] < (unsigned)p.W;
+        xok1[r] = (unsigned)(pix0[r] + 1) < (unsigned)p.W;
+    }
+    unsigned wlane[AP];
+#pragma unroll
+    for (int ap = 0; ap < AP; ++ap) wlane[ap] = tid + 256 * ap < A_PIECES ? (unsigned)(co0 * 64 + (tid + 256 * ap) * 16) : 0x40000000u;
+
+    // Global -> register staging, two K steps deep, every load unconditional (out-of-range offsets where a piece does not exist)
+    u4 ra[2][2][AP], rb[2][2][2];
+    __syncthreads();   // the table
+    int q = 0;
+    u4 en[2] = {tab[0], tab[1]};
+    auto gload = [&](auto setc) __attribute__((always_inline)) {
         constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const int pr = 2 * ks + hf;
-            const bool live = pr < npair;
-            const int prc = live ? pr : 0;
-            const int tap = prc / nchunk, ch = prc - tap * nchunk;
-            const int ky = STEM ? tap : tap / p.kw, kx = STEM ? 2 * bchunk : tap - ky * p.kw;
-            // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0.. contiguous
-            const unsigned woff = (live && tid < A_PIECES) ? (unsigned)((((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + tid * 8) * 2) : 0xFFFFFFFFu;
-            ra[S][hf] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, woff, 0, 0);
+            const u4 e = en[hf];
+#pragma unroll
+            for (int ap = 0; ap < AP; ++ap) ra[S][hf][ap] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wlane[ap] + e[3], 0, 0);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const int iy = piy0[r] + ky, ix = pix0[r] + kx;
-                const bool rowok = live && pok[r] && iy >= 0 && iy < p.H;
-                if (STEM) {   // this 16-byte piece = taps kx, kx+1 of kernel row ky: two 8-byte pixels
-                    const size_t rowb = ((size_t)pn[r] * p.H + iy) * p.W * 8;
-                    const unsigned o0 = (rowok && ix >= 0 && ix < p.W) ? (unsigned)(rowb + (size_t)ix * 8) : 0xFFFFFFFFu;
-                    const unsigned o1 = (rowok && ix + 1 >= 0 && ix + 1 < p.W) ? (unsigned)(rowb + (size_t)(ix + 1) * 8) : 0xFFFFFFFFu;
-                    const u2 t0 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, o0, 0, 0);
-                    const u2 t1 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, o1, 0, 0);
+                const bool rowok = (unsigned)(piy0[r] + (int)e[1]) < (unsigned)p.H;
+                if (STEM) {
+                    const u2 t0 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, rowok && xok0[r] ? pbase[r] + e[0] : 0xFFFFFFFFu, 0, 0);
+                    const u2 t1 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, rowok && xok1[r] ? pbase[r] + e[0] + 8u : 0xFFFFFFFFu, 0, 0);
                     rb[S][hf][r] = u4{t0[0], t0[1], t1[0], t1[1]};
                 } else {
-                    const unsigned off = (rowok && ix >= 0 && ix < p.W)
-                        ? (unsigned)(((((size_t)pn[r] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + ch * 32 + bchunk * 8) * 2) : 0xFFFFFFFFu;
-                    rb[S][hf][r] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+                    const bool ok = rowok && (unsigned)(pix0[r] + (int)e[2]) < (unsigned)p.W;
+                    rb[S][hf][r] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? pbase[r] + e[0] : 0xFFFFFFFFu, 0, 0);
                 }
             }
         }
+        q += 2;
+        en[0] = tab[q];
+        en[1] = tab[q + 1];
     };
     auto lstore = [&](int buf, auto setc) __attribute__((always_inline)) {
         constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            if (tid < A_PIECES) *reinterpret_cast<u4*>(As(buf, hf) + sw_off(tid >> 2, tid & 3)) = ra[S][hf];
+#pragma unroll
+            for (int ap = 0; ap < AP; ++ap) {
+                const int piece = tid + 256 * ap;
+                if (piece < A_PIECES) *reinterpret_cast<u4*>(As(buf, hf) + sw_off(piece >> 2, piece & 3)) = ra[S][hf][ap];
+            }
 #pragma unroll
             for (int r = 0; r < 2; ++r) *reinterpret_cast<u4*>(Bs(buf, hf) + sw_off(brow[r], bchunk)) = rb[S][hf][r];
         }
@@ -218,35 +240,41 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    if (ks0 < nk) {
-        gload(ks0, C0{});
-        lstore(ks0 & 1, C0{});
-        if (ks0 + 1 < nk) gload(ks0 + 1, C1{});
-    }
+    gload(C0{});
+    lstore(ks0 & 1, C0{});
+    gload(C1{});
     __syncthreads();
     // step ks: its data is in LDS buffer ks&1, step ks+1 is in register set `other`, step ks+2 is requested into set `mine`
     auto body = [&](int ks, auto mine, auto other) __attribute__((always_inline)) {
         const int buf = ks & 1;
-        if (ks + 2 < nk) gload(ks + 2, mine);
+        h8 af[2][MT], bf[2][2];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            h8 bf[2];
+        for (int nt = 0; nt < 2; ++nt) bf[0][nt] = *reinterpret_cast<const h8*>(Bs(buf, 0) + sw_off(32 * wv + 16 * nt + l15, g));
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const h8*>(Bs(buf, hf) + sw_off(32 * wv + 16 * nt + l15, g));
+        for (int mt = 0; mt < MT; ++mt) af[0][mt] = *reinterpret_cast<const h8*>(As(buf, 0) + sw_off(16 * mt + l15, g));
+        __builtin_amdgcn_sched_barrier(0);
+        gload(mine);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const h8 af = *reinterpret_cast<const h8*>(As(buf, hf) + sw_off(16 * mt + l15, g));
+        for (int nt = 0; nt < 2; ++nt) bf[1][nt] = *reinterpret_cast<const h8*>(Bs(buf, 1) + sw_off(32 * wv + 16 * nt + l15, g));
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
-            }
+        for (int mt = 0; mt < MT; ++mt) af[1][mt] = *reinterpret_cast<const h8*>(As(buf, 1) + sw_off(16 * mt + l15, g));
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks < nk) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[hf][mt], bf[hf][nt], acc[mt][nt], 0, 0, 0);
         }
-        if (ks + 1 < nk) lstore(buf ^ 1, other);
+        lstore(buf ^ 1, other);
         __syncthreads();
     };
     for (int ks = ks0; ks < nk; ks += 2) {
         body(ks, C0{}, C1{});
-        if (ks + 1 < nk) body(ks + 1, C1{}, C0{});
+        body(ks + 1, C1{}, C0{});
     }
 
     // ---- epilogue: this lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15
@@ -303,8 +331,11 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
     constexpr int STAGE = 2 * A_HALF;           // one K step = two (tap, chunk) pairs = 64 K elements
     constexpr int A_PIECES = A_HALF / 16;       // 16-byte pieces per half
     constexpr int AP = (A_PIECES + 255) / 256;  // ... per thread (2 for the 128-channel tile)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // weight ring [2][STAGE], then the K-walk table
     auto As = [&](int b, int hf) __attribute__((always_inline)) { return smem + b * STAGE + hf * A_HALF; };
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    u4* const tab = reinterpret_cast<u4*>(smem + 2 * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -325,69 +356,88 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
     const int ks0 = zsplit * ks_per;
     const int nk = min(nk_all, ks0 + ks_per);
 
-    // ---- this lane's two pixels (tile r: row 32 wv + 16 r + l15 of the workgroup's 128) and its channel piece g
-    int pn[2], piy0[2], pix0[2];
-    bool pok[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int row = 32 * wv + 16 * r + l15;
-        const long long m = m0 + row;
-        pok[r] = m < M;
-        const long long mm = pok[r] ? m : 0;
-        const int n = (int)(mm / ((long long)p.Ho * p.Wo));
-        const int rem = (int)(mm - (long long)n * p.Ho * p.Wo);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        pn[r] = n;
-        piy0[r] = oy * p.stride - pad_y;
-        pix0[r] = ox * p.stride_x - pad_x;
-    }
-    const int bchunk = g;
-
-    // Global -> register staging, two K steps deep: the loads of step ks+2 are issued at the top of step ks and stored to
-    // LDS at the end of step ks+1.  Every load is a buffer load whose offset is out of range when the piece does not
-    // exist (padding, tail, idle thread) -- the hardware returns zeros -- so a step issues a FIXED number of loads and
-    // hipcc can wait with vmcnt(6) for the older set only (conditional loads forced vmcnt(0): one step of cover).
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(wpk), 0, (int)((size_t)(STEM ? p.kh : p.kh * p.kw * nchunk) * p.cout_pad * 64), 0x00020000);
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.in_ld * 2), 0x00020000);
-    u4 ra[2][2][AP], rb[3][2][2];
-    auto gload = [&](int ks, auto setc, auto setb) __attribute__((always_inline)) {
+
+    // ---- the K walk as a table in LDS, built once per workgroup: entry i = pair 2 ks0 + i = (tap (ky, kx), chunk ch) as
+    //      {input byte offset of the tap and chunk relative to tap (0,0) chunk 0, ky, kx, byte offset of the pair's weight slab};
+    //      a pair past the kernel or past this split's range has ky = 2^29 (fails every row test) and a weight offset past the
+    //      slabs, so the loop requests it like any other and the hardware returns zeros.  The loop itself then holds no integer
+    //      division, no tap walk and no range logic: per piece one add and two unsigned compares on broadcast table values.
+    //      (Measured, tools/gather_steps.py: with the addresses computed per step from (pair / nchunk, tap / kw, ...) a K step of
+    //      an otherwise EMPTY loop -- loads and MFMAs switched off -- cost 500-620 cycles per workgroup, half of the step.)
+    {
+        const int pr0 = 2 * ks0, ntab = 2 * (ks_per + 5);   // range + rounding to 3-step groups + two steps of prefetch + one of table read-ahead
+        const unsigned wstep = (unsigned)p.cout_pad * 64u;
+        for (int i = tid; i < ntab; i += 256) {
+            const int pr = pr0 + i;
+            const bool live = pr < npair && pr < 2 * nk;
+            const int prc = live ? pr : 0;
+            const int tap = prc / nchunk, ch = prc - tap * nchunk;
+            const int ky = STEM ? tap : tap / p.kw, kx = STEM ? 0 : tap - ky * p.kw;
+            const unsigned delta = ((unsigned)(ky * p.W + kx) * (unsigned)p.in_ld + (unsigned)ch * 32u) * 2u;
+            tab[i] = live ? u4{delta, (unsigned)ky, (unsigned)kx, (unsigned)pr * wstep} : u4{0u, 1u << 29, 0u, 0x80000000u};
+        }
+    }
+
+    // ---- this lane's two pixels (tile r: row 32 wv + 16 r + l15 of the workgroup's 128) and its channel piece g: a 32-bit byte
+    //      offset of (pixel, tap (0,0), chunk 0, piece g) -- wrapped modulo 2^32 where the padding makes it negative; adding the
+    //      table's tap offset wraps it back -- plus the pixel's first input row / column for the bounds tests
+    int piy0[2], pix0[2];
+    unsigned pbase[2];
+    bool xok0[2], xok1[2];   // STEM: the lane's two taps of a kernel row (columns fixed per lane)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = 32 * wv + 16 * r + l15;
+        const long long m = m0 + row;
+        const bool ok = m < M;
+        const long long mm = ok ? m : 0;
+        const int n = (int)(mm / ((long long)p.Ho * p.Wo));
+        const int rem = (int)(mm - (long long)n * p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        piy0[r] = ok ? oy * p.stride - pad_y : -(1 << 28);   // (a pixel past M fails every row test)
+        pix0[r] = ox * p.stride_x - pad_x + (STEM ? 2 * g : 0);
+        pbase[r] = (unsigned)(((((long long)n * p.H + piy0[r]) * p.W + pix0[r]) * p.in_ld + (STEM ? 0 : p.in_coff + g * 8)) * 2);
+        xok0[r] = (unsigned)pix0[r] < (unsigned)p.W;
+        xok1[r] = (unsigned)(pix0[r] + 1) < (unsigned)p.W;
+    }
+
+    // Global -> register staging, two K steps deep: the loads of step ks+2 are issued at the top of step ks and stored to
+    // LDS at the end of step ks+1.  Every load is a buffer load whose offset is out of range when the piece does not
+    // exist (padding, tail, idle thread) -- the hardware returns zeros -- so a step issues a FIXED number of loads and
+    // hipcc can wait with a vmcnt for the older set only.
+    u4 ra[3][2][AP], rb[3][2][2];
+    unsigned wlane[AP];   // this thread's piece of a weight slab [cout_pad][32] fp16 (rows co0.. contiguous); an idle thread points past the slabs
+#pragma unroll
+    for (int ap = 0; ap < AP; ++ap) wlane[ap] = tid + 256 * ap < A_PIECES ? (unsigned)(co0 * 64 + (tid + 256 * ap) * 16) : 0x40000000u;
+    __syncthreads();   // the table
+    int q = 0;         // table index of the next step's first pair
+    u4 en[2] = {tab[0], tab[1]};   // entries of the next request, read one step ahead (a broadcast ds_read_b128 each)
+    auto gload = [&](auto setc, auto setb) __attribute__((always_inline)) {
         constexpr int S = decltype(setc)::value, SB = decltype(setb)::value;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const int pr = 2 * ks + hf;
-            const bool live = pr < npair;
-            const int prc = live ? pr : 0;
-            const int tap = prc / nchunk, ch = prc - tap * nchunk;
-            const int ky = STEM ? tap : tap / p.kw, kx = STEM ? 2 * bchunk : tap - ky * p.kw;
-            // weight slab of this (tap, chunk): [cout_pad][32] fp16, rows co0.. contiguous
+            const u4 e = en[hf];
 #pragma unroll
-            for (int ap = 0; ap < AP; ++ap) {
-                const int piece = tid + 256 * ap;
-                const unsigned woff = (live && piece < A_PIECES) ? (unsigned)((((size_t)(tap * nchunk + ch) * p.cout_pad + co0) * 32 + piece * 8) * 2) : 0xFFFFFFFFu;
-                ra[S][hf][ap] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, woff, 0, 0);
-            }
+            for (int ap = 0; ap < AP; ++ap) ra[S][hf][ap] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wlane[ap] + e[3], 0, 0);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const int iy = piy0[r] + ky, ix = pix0[r] + kx;
-                const bool rowok = live && pok[r] && iy >= 0 && iy < p.H;
+                const bool rowok = (unsigned)(piy0[r] + (int)e[1]) < (unsigned)p.H;
                 if (STEM) {   // this 16-byte piece = taps kx, kx+1 of kernel row ky: two 8-byte pixels
-                    const size_t rowb = ((size_t)pn[r] * p.H + iy) * p.W * 8;
-                    const unsigned o0 = (rowok && ix >= 0 && ix < p.W) ? (unsigned)(rowb + (size_t)ix * 8) : 0xFFFFFFFFu;
-                    const unsigned o1 = (rowok && ix + 1 >= 0 && ix + 1 < p.W) ? (unsigned)(rowb + (size_t)(ix + 1) * 8) : 0xFFFFFFFFu;
-                    const u2 t0 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, o0, 0, 0);
-                    const u2 t1 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, o1, 0, 0);
+                    const u2 t0 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, rowok && xok0[r] ? pbase[r] + e[0] : 0xFFFFFFFFu, 0, 0);
+                    const u2 t1 = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, rowok && xok1[r] ? pbase[r] + e[0] + 8u : 0xFFFFFFFFu, 0, 0);
                     rb[SB][hf][r] = u4{t0[0], t0[1], t1[0], t1[1]};
                 } else {
-                    const unsigned off = (rowok && ix >= 0 && ix < p.W)
-                        ? (unsigned)(((((size_t)pn[r] * p.H + iy) * p.W + ix) * p.in_ld + p.in_coff + ch * 32 + bchunk * 8) * 2) : 0xFFFFFFFFu;
-                    rb[SB][hf][r] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+                    const bool ok = rowok && (unsigned)(pix0[r] + (int)e[2]) < (unsigned)p.W;
+                    rb[SB][hf][r] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? pbase[r] + e[0] : 0xFFFFFFFFu, 0, 0);
                 }
             }
         }
+        q += 2;
+        en[0] = tab[q];
+        en[1] = tab[q + 1];
     };
     auto lstore = [&](int buf, auto setc) __attribute__((always_inline)) {
         constexpr int S = decltype(setc)::value;
@@ -407,41 +457,54 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    if (ks0 < nk) {
-        gload(ks0, C0{}, C0{});
-        lstore(ks0 & 1, C0{});
-        if (ks0 + 1 < nk) gload(ks0 + 1, C1{}, C1{});
-    }
+    // Control flow around the loads is kept UNIFORM: every step requests its six pieces whether or not they exist (steps past
+    // the range get out-of-range offsets: zeros, no traffic), the loop runs whole groups of three steps and only the MFMAs of
+    // a step past the range are skipped.  With a load under `if (ks + 2 < nk)` the compiler's wait-count pass has to assume
+    // the younger loads were skipped and emitted s_waitcnt vmcnt(0) before the MFMAs of every third step -- the pipeline
+    // drained, one memory latency exposed per three steps (seen in the ISA; this held the low-resolution layers at ~1 us per
+    // K step).
+    gload(C0{}, C0{});
+    lstore(ks0 & 1, C0{});
+    gload(C1{}, C1{});
     __syncthreads();
     // step ks (i = ks - ks0): weights in LDS buffer ks&1, pixels in register set i%3; step ks+1 is in flight (weights in
-    // set (i+1)&1, pixels in set (i+1)%3); step ks+2 is requested at the top of the step into the sets step ks-1 used
-    auto body = [&](int ks, auto amine, auto aother, auto bcur, auto bnew) __attribute__((always_inline)) {
-        constexpr int BC = decltype(bcur)::value;
+    // register set (i+1)%3, pixels in set (i+1)%3); step ks+2 is requested at the top of the step into set (i+2)%3
+    // Order inside a step (pinned with scheduling barriers: at one wave per SIMD -- the low-resolution layers -- nothing else
+    // hides a latency): the weight fragments of the first half are read from LDS first, the next-but-one step's addresses and
+    // loads are issued under that latency, the second half's fragments are requested, then the 4 MT MFMAs run back to back.
+    // Read where they are used (two ds_read_b128, wait, two MFMAs, ...) the fragments exposed an LDS latency per pair of MFMAs.
+    auto body = [&](int ks, auto cur, auto nxt, auto nw) __attribute__((always_inline)) {
+        constexpr int BC = decltype(cur)::value;
         const int buf = ks & 1;
-        if (ks + 2 < nk) gload(ks + 2, amine, bnew);
+        h8 af[2][MT];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            h8 bf[2];
+        for (int mt = 0; mt < MT; ++mt) af[0][mt] = *reinterpret_cast<const h8*>(As(buf, 0) + sw_off(16 * mt + l15, g));
+        __builtin_amdgcn_sched_barrier(0);
+        gload(nw, nw);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bf[nt] = __builtin_bit_cast(h8, rb[BC][hf][nt]);
+        for (int mt = 0; mt < MT; ++mt) af[1][mt] = *reinterpret_cast<const h8*>(As(buf, 1) + sw_off(16 * mt + l15, g));
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks < nk) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const h8 af = *reinterpret_cast<const h8*>(As(buf, hf) + sw_off(16 * mt + l15, g));
+            for (int hf = 0; hf < 2; ++hf) {
+                h8 bf[2];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < 2; ++nt) bf[nt] = __builtin_bit_cast(h8, rb[BC][hf][nt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[hf][mt], bf[nt], acc[mt][nt], 0, 0, 0);
             }
         }
-        if (ks + 1 < nk) lstore(buf ^ 1, aother);
+        lstore(buf ^ 1, nxt);
         __syncthreads();
     };
-    for (int ks = ks0; ks < nk; ks += 6) {   // lcm of the two-deep weight sets and the three-deep pixel sets
-        body(ks, C0{}, C1{}, C0{}, C2{});
-        if (ks + 1 < nk) body(ks + 1, C1{}, C0{}, C1{}, C0{});
-        if (ks + 2 < nk) body(ks + 2, C0{}, C1{}, C2{}, C1{});
-        if (ks + 3 < nk) body(ks + 3, C1{}, C0{}, C0{}, C2{});
-        if (ks + 4 < nk) body(ks + 4, C0{}, C1{}, C1{}, C0{});
-        if (ks + 5 < nk) body(ks + 5, C1{}, C0{}, C2{}, C1{});
+    for (int ks = ks0; ks < nk; ks += 3) {
+        body(ks, C0{}, C1{}, C2{});
+        body(ks + 1, C1{}, C2{}, C0{});
+        body(ks + 2, C2{}, C0{}, C1{});
     }
 
     // ---- epilogue: this lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15
@@ -1221,6 +1284,29 @@ __global__ void __launch_bounds__(256) k_corr_mfma(const _Float16* __restrict__ 
     }
 }
 
+// k_conv_igemm_d's dynamic LDS: the double-buffered weight ring + the K-walk table of one workgroup's range of steps
+template <int BN, bool STEM>
+static int launch_gather(const ConvP& p, dim3 grid, hipStream_t stream) {
+    const int nchunk = STEM ? 1 : p.cin >> 5, npair = STEM ? p.kh : p.kh * p.kw * nchunk;
+    const int nk_all = (npair + 1) >> 1, ks_per = (nk_all + p.splits - 1) / p.splits;
+    const size_t lds = (size_t)BN * 256 + (size_t)2 * (ks_per + 5) * 16;
+    if (lds > 64 * 1024) return vsr::fail(VSR_E_ARG, "conv2d: %d K steps per workgroup exceed the kernel's walk table (split K further)", ks_per);
+    if ((unsigned long long)npair * p.cout_pad * 64 >= (1ull << 30)) return vsr::fail(VSR_E_ARG, "conv2d: packed weights beyond 1 GiB");
+    hipLaunchKernelGGL((k_conv_igemm_d<BN, STEM>), grid, dim3(256), lds, stream, p);
+    return VSR_OK;
+}
+
+template <int BN, bool STEM>
+static int launch_gather_lds(const ConvP& p, dim3 grid, hipStream_t stream) {
+    const int nchunk = STEM ? 1 : p.cin >> 5, npair = STEM ? p.kh : p.kh * p.kw * nchunk;
+    const int nk_all = (npair + 1) >> 1, ks_per = (nk_all + p.splits - 1) / p.splits;
+    const size_t lds = (size_t)4 * (BN * 64 + BM * 64) + (size_t)2 * (ks_per + 5) * 16;
+    if (lds > 64 * 1024) return vsr::fail(VSR_E_ARG, "conv2d: %d K steps per workgroup exceed the kernel's walk table (split K further)", ks_per);
+    if ((unsigned long long)npair * p.cout_pad * 64 >= (1ull << 30)) return vsr::fail(VSR_E_ARG, "conv2d: packed weights beyond 1 GiB");
+    hipLaunchKernelGGL((k_conv_igemm<BN, STEM>), grid, dim3(256), lds, stream, p);
+    return VSR_OK;
+}
+
 static int g_splitk_fill = 256;   // split K when a launch has fewer workgroups than this (measured: tools/probe_splitk.py)
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
 
@@ -1356,13 +1442,13 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
     p.splits = splits;
     const dim3 grid(gx, gy, 4 * splits);
     if (g_patch_mode == 8) {   // the first gather build (pixel operand through LDS): cross-check / A-B
-        if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, vsr::S(stream), p);
-        else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, vsr::S(stream), p);
-        else hipLaunchKernelGGL(k_conv_igemm<16>, grid, dim3(256), 0, vsr::S(stream), p);
+        const int rc = bn == 64 ? launch_gather_lds<64, false>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather_lds<32, false>(p, grid, vsr::S(stream))
+                                                                                                     : launch_gather_lds<16, false>(p, grid, vsr::S(stream));
+        if (rc) return rc;
     } else {
-        if (bn == 64) hipLaunchKernelGGL(k_conv_igemm_d<64>, grid, dim3(256), 0, vsr::S(stream), p);
-        else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm_d<32>, grid, dim3(256), 0, vsr::S(stream), p);
-        else hipLaunchKernelGGL(k_conv_igemm_d<16>, grid, dim3(256), 0, vsr::S(stream), p);
+        const int rc = bn == 64 ? launch_gather<64, false>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather<32, false>(p, grid, vsr::S(stream))
+                                                                                                 : launch_gather<16, false>(p, grid, vsr::S(stream));
+        if (rc) return rc;
     }
     if (splits > 1) {
         int rc = vsr::launched("deconv4s2_nhwc_f16");
@@ -1403,13 +1489,13 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const dim3 grid(vsr::cdiv(M, BM), cout_pad / bn, 1);
     if (g_patch_mode == 8) {
-        if (bn == 64) hipLaunchKernelGGL((k_conv_igemm<64, true>), grid, dim3(256), 0, vsr::S(stream), p);
-        else if (bn == 32) hipLaunchKernelGGL((k_conv_igemm<32, true>), grid, dim3(256), 0, vsr::S(stream), p);
-        else hipLaunchKernelGGL((k_conv_igemm<16, true>), grid, dim3(256), 0, vsr::S(stream), p);
+        const int rc = bn == 64 ? launch_gather_lds<64, true>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather_lds<32, true>(p, grid, vsr::S(stream))
+                                                                                                    : launch_gather_lds<16, true>(p, grid, vsr::S(stream));
+        if (rc) return rc;
     } else {
-        if (bn == 64) hipLaunchKernelGGL((k_conv_igemm_d<64, true>), grid, dim3(256), 0, vsr::S(stream), p);
-        else if (bn == 32) hipLaunchKernelGGL((k_conv_igemm_d<32, true>), grid, dim3(256), 0, vsr::S(stream), p);
-        else hipLaunchKernelGGL((k_conv_igemm_d<16, true>), grid, dim3(256), 0, vsr::S(stream), p);
+        const int rc = bn == 64 ? launch_gather<64, true>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather<32, true>(p, grid, vsr::S(stream))
+                                                                                                : launch_gather<16, true>(p, grid, vsr::S(stream));
+        if (rc) return rc;
     }
     return vsr::launched("conv2d_stem_f16");
 }
@@ -1538,14 +1624,13 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     p.splits = splits;
     const dim3 grid(gx, gy, splits);
     if (g_patch_mode == 8) {   // the first gather build (pixel operand through LDS): cross-check / A-B
-        if (bn == 64) hipLaunchKernelGGL(k_conv_igemm<64>, grid, dim3(256), 0, vsr::S(stream), p);
-        else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm<32>, grid, dim3(256), 0, vsr::S(stream), p);
-        else hipLaunchKernelGGL(k_conv_igemm<16>, grid, dim3(256), 0, vsr::S(stream), p);
+        const int rc = bn == 64 ? launch_gather_lds<64, false>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather_lds<32, false>(p, grid, vsr::S(stream))
+                                                                                                     : launch_gather_lds<16, false>(p, grid, vsr::S(stream));
+        if (rc) return rc;
     } else {
-        if (bn == 128) hipLaunchKernelGGL(k_conv_igemm_d<128>, grid, dim3(256), 0, vsr::S(stream), p);
-        else if (bn == 64) hipLaunchKernelGGL(k_conv_igemm_d<64>, grid, dim3(256), 0, vsr::S(stream), p);
-        else if (bn == 32) hipLaunchKernelGGL(k_conv_igemm_d<32>, grid, dim3(256), 0, vsr::S(stream), p);
-        else hipLaunchKernelGGL(k_conv_igemm_d<16>, grid, dim3(256), 0, vsr::S(stream), p);
+        const int rc = bn == 128 ? launch_gather<128, false>(p, grid, vsr::S(stream)) : bn == 64 ? launch_gather<64, false>(p, grid, vsr::S(stream))
+                     : bn == 32 ? launch_gather<32, false>(p, grid, vsr::S(stream)) : launch_gather<16, false>(p, grid, vsr::S(stream));
+        if (rc) return rc;
     }
     if (splits > 1) {
         int rc = vsr::launched("conv2d_nhwc_f16");
