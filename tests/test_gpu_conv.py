@@ -217,3 +217,17 @@ def test_pair_conv_stride2(case):
     got = igemm.to_nchw_float(out, cout)
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_splitk_runs_are_bit_identical():
+    """Split-K layers (few output pixels, long K): k_splitk_finish sums the partial tiles in the fixed order z = 0, 1, ..."""
+    rs = np.random.RandomState(5)
+    for N, cin, H, W, cout, k, s in ((1, 473, 8, 16, 256, 3, 1), (2, 512, 16, 30, 512, 3, 2), (1, 1026, 4, 6, 2, 3, 1)):
+        x = igemm.to_nhwc_half(torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda())
+        w = torch.from_numpy((rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).cuda()
+        conv = igemm.HConv(w, torch.zeros(cout, device="cuda"), stride=s, pad=1, act=igemm.ACT_LEAKY)
+        first = conv(x).clone()
+        for _ in range(8):
+            assert torch.equal(conv(x), first)
+        ref = F.leaky_relu(F.conv2d(igemm.to_nchw_float(x, cin), w.half().float(), None, stride=s, padding=1), 0.1)
+        assert (igemm.to_nchw_float(first, cout) - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()

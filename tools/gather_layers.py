@@ -15,14 +15,10 @@ lib.vsr_conv2d_tuning(1)   # gather path only
 for name, N, cin, H, W, cout, k, st in cases:
     x = igemm.to_nhwc_half(torch.randn(N, cin, H, W, device="cuda"))
     conv = igemm.HConv(torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5, torch.zeros(cout, device="cuda"), stride=st, pad=(k - 1) // 2)
-    row = []
-    for bits in (0, 2, 4, 6, 8, 14, 30):
-        lib.vsr_conv2d_tuning(2000 + bits)
-        for _ in range(3): conv(x)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps): conv(x)
-        e1.record(); torch.cuda.synchronize()
-        row.append(f"{bits}:{e0.elapsed_time(e1) / reps * 1e3:6.1f}")
-    print(f"{name:36s} " + "  ".join(row) + " us", flush=True)
+    for _ in range(3): conv(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): conv(x)
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:36s} {e0.elapsed_time(e1) / reps * 1e3:6.1f} us", flush=True)

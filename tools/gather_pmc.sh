@@ -1,16 +1,15 @@
 #!/bin/bash
-# PMC passes over ONE gather-kernel layer of tools/gather_layers.py (case index $2): wave-cycle split, instruction mix, TA / TCP / TCC
-# activity and latency.  usage (on the GPU box, from the repo root): bash tools/gather_pmc.sh <outdir under gpurun_out> <case>
+# PMC passes over ONE gather-kernel layer of tools/gather_layers.py (case index $2): wave-cycle split, instruction mix, L1 / L2
+# requests and latency (at most three TCP / TCC counters fit one pass on gfx950).  usage (on the GPU box, from the repo root): bash tools/gather_pmc.sh <outdir under gpurun_out> <case>
 OUT=gpurun_out/$1; CASE=$2; mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$(pwd)
 run() { name=$1; shift; (cd /tmp && timeout -k 10 200 rocprofv3 --output-format csv --pmc "$@" -d $ROOT/$OUT/$name -o run -- python3 $ROOT/tools/gather_layers.py $CASE 5 > $ROOT/$OUT/$name.log 2>&1) || echo "pass $name failed"; echo "pass $name done"; }
 run a GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run b SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU
-run c TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum
-run d TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum
-run e TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum TCC_BUSY_avr TCC_EA0_RDREQ_sum TCC_IB_STALL_sum
-run f SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES
+run c TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
+run d TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum
+run f SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA FETCH_SIZE
 python3 - $OUT <<'PY'
 import csv, glob, os, sys, collections
 out = sys.argv[1]

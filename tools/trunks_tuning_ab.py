@@ -14,7 +14,7 @@ fr = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (4, h, w, 3)).ast
 fx, hx, ox = m._flow_exec.get(), m._depth_exec.get(), m._vos_exec.get()
 stages = {"flow (2 pairs)": lambda: m.FlowModule.forward_pairs([(fr[0], fr[1]), (fr[1], fr[2])], fx), "depth x4": lambda: hx(fr),
           "depth x1": lambda: hx(fr[:1]), "vos": lambda: m.VOSModule(fr[0], fr[1], ox)}
-modes = [0, 2, 5, 10, 11]
+modes = [int(a) for a in os.environ.get("VSR_MODES", "0,2,5,10,11").split(",")]
 res = {(s, md): [] for s in stages for md in modes}
 lib = L.load()
 for rnd in range(3):
