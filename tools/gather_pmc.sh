@@ -17,8 +17,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_conv_igemm_d" not in k and "k_splitk" not in k: continue
-        name = "gather" if "k_conv_igemm_d" in k else "finish"
+        if "k_conv_" not in k and "k_splitk" not in k: continue
+        name = "finish" if "k_splitk" in k else ("patch" if "k_conv_patch" in k else "gather")
         agg[name][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[name][r["Counter_Name"]] += 1
 for name, d in agg.items():
     print(name)

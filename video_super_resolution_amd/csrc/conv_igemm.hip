@@ -56,8 +56,8 @@ __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((
 // wave transposes its own NT x 16 pixels in its own LDS slice (the caller has synchronised after the last patch read).
 // acc(ti, mt) -> f4 of pixel-tile ti; pixoff(ti, li) -> element offset of pixel li of tile ti in the output tensor (its
 // channel 0), or -1 when the pixel does not exist.
-template <int MT, int NT, class GetAcc, class PixOf>
-__device__ __forceinline__ void patch_epilogue(const ConvP& p, unsigned char* wave_lds, int co0, int lane, GetAcc acc, PixOf pixoff) {
+template <int MT, int NT, int ACT, class GetAcc, class PixOf>
+__device__ __forceinline__ void patch_epilogue_act(const ConvP& p, unsigned char* wave_lds, int co0, int lane, GetAcc acc, PixOf pixoff) {
     constexpr int RB = 32 * MT, LPP = 2 * MT, PPI = 64 / LPP;
     const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -73,8 +73,8 @@ __device__ __forceinline__ void patch_epilogue(const ConvP& p, unsigned char* wa
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float tt = a[e] + bz[e];
-                if (p.act == 1) tt = fmaxf(tt, 0.0f);
-                else if (p.act == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
+                if (ACT == 1) tt = fmaxf(tt, 0.0f);
+                else if (ACT == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
                 v[e] = tt;
             }
             *reinterpret_cast<h4*>(wave_lds + (ti * 16 + l15) * RB + (((2 * mt + (g >> 1)) ^ (l15 & (LPP - 1))) << 4) + ((g & 1) << 3)) =
@@ -101,6 +101,16 @@ __device__ __forceinline__ void patch_epilogue(const ConvP& p, unsigned char* wa
                 if (c + e < p.cout) dst[e] = v[e];
         }
     }
+}
+
+// (the activation is a template constant: tested per value at run time it compiled to two scalar branches per output value --
+//  128 branches per wave in the 3x3 build, whose epilogue and patch addressing together issued 9 vector instructions per MFMA;
+//  PMC on the 32 -> 64 layer at 2 x 512 x 960: 1340 VALU / 586 SALU / 144 MFMA per wave, VALU pipe 51 % busy, MFMA pipe 22 %)
+template <int MT, int NT, class GetAcc, class PixOf>
+__device__ __forceinline__ void patch_epilogue(const ConvP& p, unsigned char* wave_lds, int co0, int lane, GetAcc acc, PixOf pixoff) {
+    if (p.act == 0) patch_epilogue_act<MT, NT, 0>(p, wave_lds, co0, lane, acc, pixoff);
+    else if (p.act == 1) patch_epilogue_act<MT, NT, 1>(p, wave_lds, co0, lane, acc, pixoff);
+    else patch_epilogue_act<MT, NT, 2>(p, wave_lds, co0, lane, acc, pixoff);
 }
 
 __device__ __forceinline__ long long patch_pixoff(const ConvP& p, int n, int oy, int ox) {
@@ -701,23 +711,75 @@ __device__ __forceinline__ void stage_patch(const ConvP& p, unsigned char* patch
         0x00020000);
     const int total = PH * PW * 4;
     const unsigned coff = (unsigned)(p.in_coff + ch * 32) * 2;
+    // piece q = tid + 256 k of the patch = pixel q >> 2 (row py, column px), 16-byte piece q & 3.  One division per call; from slot
+    // to slot the pixel index grows by 64 = dpy rows + dpx columns (a division per piece was half of this function's instructions)
+    const int c4 = tid & 3;
+    int pix = tid >> 2, py = pix / PW, px = pix - py * PW;
+    const int dpy = 64 / PW, dpx = 64 - dpy * PW;
+    const unsigned ld2 = (unsigned)p.in_ld * 2, row2 = (unsigned)p.W * ld2;
     for (int q0 = 0; q0 < total; q0 += 256 * U) {
         u4v v[U];
         int dst[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int q = q0 + u * 256 + tid;
-            const int pix = q >> 2, c4 = q & 3;
-            const int py = pix / PW, px = pix - py * PW;
             const int iy = iy0 + py, ix = ix0 + px;
-            const bool ok = q < total && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const unsigned off = ok ? ((unsigned)((iy - by) * p.W + ix) * (unsigned)p.in_ld * 2 + coff + c4 * 16) : 0xFFFFFFFFu;
+            const bool in = pix * 4 < total;   // (all four pieces of a pixel exist or none: total is a multiple of 4)
+            const bool ok = in && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? ((unsigned)(iy - by) * row2 + (unsigned)ix * ld2 + coff + c4 * 16) : 0xFFFFFFFFu;
             v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-            dst[u] = q < total ? pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4) : -1;
+            dst[u] = in ? pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4) : -1;
+            pix += 64; py += dpy; px += dpx;
+            if (px >= PW) { px -= PW; ++py; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (dst[u] >= 0) *reinterpret_cast<u4v*>(patch + dst[u]) = v[u];
+    }
+}
+
+// The same staging with the pieces' descriptors kept in registers across the 32-channel chunks of a layer: a thread's NP
+// pieces are the same pixels for every chunk -- only the channel offset moves, 64 bytes per chunk -- so the (row, column) walk,
+// the bounds tests and the LDS addresses are computed once per workgroup (`patch_pieces`) and a chunk's staging is one add per
+// piece (`stage_patch_cached`).  A 256 -> 256 3x3 layer spent 330 of its 465 vector instructions per chunk on this walk.
+template <int NP>
+__device__ __forceinline__ void patch_pieces(const ConvP& p, int iy0, int ix0, int PH, int PW, int tid, unsigned (&poff)[NP], int (&pdst)[NP]) {
+    const int by = iy0 > 0 ? iy0 : 0;
+    const int total = PH * PW * 4;
+    const int c4 = tid & 3;
+    int pix = tid >> 2, py = pix / PW, px = pix - py * PW;
+    const int dpy = 64 / PW, dpx = 64 - dpy * PW;
+    const unsigned ld2 = (unsigned)p.in_ld * 2, row2 = (unsigned)p.W * ld2;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool in = pix * 4 < total;
+        const bool ok = in && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        poff[k] = ok ? ((unsigned)(iy - by) * row2 + (unsigned)ix * ld2 + (unsigned)p.in_coff * 2 + c4 * 16) : 0xFFFFFFFFu;
+        pdst[k] = in ? pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4) : -1;
+        pix += 64; py += dpy; px += dpx;
+        if (px >= PW) { px -= PW; ++py; }
+    }
+}
+template <int NP>
+__device__ __forceinline__ void stage_patch_cached(const ConvP& p, unsigned char* patch, int n, int ch, int iy0, const unsigned (&poff)[NP],
+                                                   const int (&pdst)[NP]) {
+    constexpr int U = 6;
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const int by = iy0 > 0 ? iy0 : 0;
+    const size_t rem_bytes = (size_t)(p.H - by) * p.W * p.in_ld * 2;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(p.in) + ((size_t)n * p.H + by) * p.W * p.in_ld, 0, (int)(rem_bytes < 0x7FFFFFF0ull ? rem_bytes : 0x7FFFFFF0ull),
+        0x00020000);
+    const unsigned coff = (unsigned)ch * 64u;
+#pragma unroll
+    for (int k0 = 0; k0 < NP; k0 += U) {
+        u4v v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k0 + u < NP) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, poff[k0 + u] == 0xFFFFFFFFu ? 0xFFFFFFFFu : poff[k0 + u] + coff, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k0 + u < NP && pdst[k0 + u] >= 0) *reinterpret_cast<u4v*>(patch + pdst[k0 + u]) = v[u];
     }
 }
 
@@ -860,7 +922,7 @@ __global__ void __launch_bounds__(256) k_conv_patch_r8(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     const int PH = P8_H + KH - 1, PW = P8_W + p.kw - 1;
     unsigned char* const patch = psm;                      // [PH][PW] pixels of 64 B (chunk XOR pixel-column bits 1-2)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar arithmetic downstream)
     const int l15 = lane & 15, g = lane >> 4;
     const int tiles_x = (p.Wo + P8_W - 1) / P8_W;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -884,9 +946,17 @@ __global__ void __launch_bounds__(256) k_conv_patch_r8(const ConvP p) {
     for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) A[ky][mt] = wfrag(ky, 0, 0, mt);
+    // pieces of the patch this thread stages: descriptors kept across chunks where the layer has several and the kernel is square
+    constexpr int NPC = ((P8_H + KH - 1) * (P8_W + KH - 1) * 4 + 255) / 256;
+    constexpr bool CACHE = KH <= 7;
+    unsigned poff[CACHE ? NPC : 1];
+    int pdst[CACHE ? NPC : 1];
+    const bool cached = CACHE && p.kw == KH && nchunk > 1;
+    if (CACHE && cached) patch_pieces(p, iy0, ix0, PH, PW, tid, poff, pdst);
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();
-        stage_patch(p, patch, n, ch, iy0, ix0, PH, PW, tid);
+        if (CACHE && cached) stage_patch_cached(p, patch, n, ch, iy0, poff, pdst);
+        else stage_patch(p, patch, n, ch, iy0, ix0, PH, PW, tid);
         __syncthreads();
         for (int kx = 0; kx < p.kw; ++kx) {
             // the column after this one (next chunk's first at the end; the very last refresh re-reads its own)
@@ -913,8 +983,12 @@ __global__ void __launch_bounds__(256) k_conv_patch_r8(const ConvP p) {
         }
     }
     __syncthreads();
+    // output offsets: the wave's first pixel once (64-bit, scalar), then row / column strides
+    const long long wbase = (((long long)n * p.outH + (oy0 + ry0) * p.oy_mul + p.oy_off) * p.outW + (ox0 + cx0) * p.ox_mul + p.ox_off) * p.out_ld;
+    const int rstride = p.oy_mul * p.outW * p.out_ld, cstride = p.ox_mul * p.out_ld;
+    const int rows_ok = p.Ho - (oy0 + ry0), cols_ok = p.Wo - (ox0 + cx0);
     patch_epilogue<MT, P8_R>(p, psm + wv * (P8_R * 16 * 32 * MT), co0, lane, [&](int r, int mt) { return acc[r][mt]; },
-                             [&](int r, int li) { return patch_pixoff(p, n, oy0 + ry0 + r, ox0 + cx0 + li); });
+                             [&](int r, int li) { return r < rows_ok && li < cols_ok ? wbase + r * rstride + li * cstride : -1ll; });
 }
 
 template <int KH, int MT>
