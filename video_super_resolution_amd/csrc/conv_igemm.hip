@@ -118,6 +118,65 @@ __device__ __forceinline__ long long patch_pixoff(const ConvP& p, int n, int oy,
     return (long long)((((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld);
 }
 
+// Epilogue of the gather kernels.  This lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15 (straight
+// from the MFMA layout: the LDS-transposed epilogue of the patch kernels was measured here too and loses 10-25 % on these
+// shorter, lower-resolution launches).  Split-K: the fp32 partial tile for k_splitk_finish.  The activation is a template
+// constant (tested per value at run time it compiled to scalar branches per output value) and the bias is read as one 16-byte
+// piece per out-channel tile.
+template <int BN, int ACT>
+__device__ __forceinline__ void gather_store(const ConvP& p, const f4 (&acc)[BN / 16][2], long long M, long long m0, int co0, int tid, int zsplit,
+                                             int ph, int oy_off, int ox_off) {
+    constexpr int MT = BN / 16;
+    const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    if (p.splits > 1) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const long long m = m0 + 32 * wv + 16 * nt + l15;
+            if (m >= M) continue;
+            float* wsp = p.ws + (((size_t)zsplit * (p.nphase > 1 ? 4 : 1) + ph) * M + m) * p.cout_pad + co0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4*>(wsp + 16 * mt + 4 * g) = acc[mt][nt];
+        }
+        return;
+    }
+    f4 bz[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)   // (bias: cout_pad floats, 16-byte aligned pieces)
+        bz[mt] = p.bias ? *reinterpret_cast<const f4*>(p.bias + co0 + 16 * mt + 4 * g) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+    const bool vec_ok = (p.out_coff & 3) == 0 && (p.out_ld & 3) == 0;   // (co0 + 16 mt + 4 g is a multiple of 4)
+    const unsigned HoWo = (unsigned)(p.Ho * p.Wo);   // (M < 2^31: checked by the launchers; 32-bit divisions)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const long long m = m0 + 32 * wv + 16 * nt + l15;
+        if (m >= M) continue;
+        const int n = (int)((unsigned)m / HoWo);
+        const int rem = (int)((unsigned)m - (unsigned)n * HoWo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + oy_off) * p.outW + ox * p.ox_mul + ox_off) * p.out_ld +
+                        p.out_coff;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c = co0 + 16 * mt + 4 * g;
+            if (c >= p.cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[mt][nt][r] + bz[mt][r];
+                if (ACT == 1) t = fmaxf(t, 0.0f);
+                else if (ACT == 2) t = t >= 0.0f ? t : t * p.slope;
+                v[r] = t;
+            }
+            if (vec_ok && c + 4 <= p.cout) {
+                *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < p.cout) dst[c + r] = (_Float16)v[r];
+            }
+        }
+    }
+}
+
 // STEM: the input has 4 channels per pixel ([N,H,W,4] fp16, 3 live) and one K chunk is a whole kernel ROW: k = 4 kx + c
 // for kx < 8 (packed weights [ky][cout_pad][32], zero where kx >= kw or c >= cin).  A 7x7 stem on an RGB image is 7 K
 // chunks instead of 49 chunks that are 29/32 zero padding.
@@ -187,9 +246,9 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     for (int r = 0; r < 2; ++r) {
         const long long m = m0 + brow[r];
         const bool ok = m < M;
-        const long long mm = ok ? m : 0;
-        const int n = (int)(mm / ((long long)p.Ho * p.Wo));
-        const int rem = (int)(mm - (long long)n * p.Ho * p.Wo);
+        const unsigned mm = ok ? (unsigned)m : 0u, HoWo = (unsigned)(p.Ho * p.Wo);   // (M < 2^31: checked by the launchers; 32-bit divisions)
+        const int n = (int)(mm / HoWo);
+        const int rem = (int)(mm - (unsigned)n * HoWo);
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         piy0[r] = ok ? oy * p.stride - pad_y : -(1 << 28);
         pix0[r] = ox * p.stride_x - pad_x + (STEM ? 2 * bchunk : 0);
@@ -287,45 +346,9 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
         body(ks + 1, C1{}, C0{});
     }
 
-    // ---- epilogue: this lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15
-    //      (straight from the MFMA layout: the LDS-transposed epilogue of the patch kernels was measured here too and
-    //      loses 10-25 % on these shorter, lower-resolution launches)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const long long m = m0 + 32 * wv + 16 * nt + l15;
-        if (m >= M) continue;
-        if (p.splits > 1) {
-            float* wsp = p.ws + (((size_t)zsplit * (p.nphase > 1 ? 4 : 1) + ph) * M + m) * p.cout_pad + co0;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4*>(wsp + 16 * mt + 4 * g) = acc[mt][nt];
-            continue;
-        }
-        const int n = (int)(m / ((long long)p.Ho * p.Wo));
-        const int rem = (int)(m - (long long)n * p.Ho * p.Wo);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + oy_off) * p.outW + ox * p.ox_mul + ox_off) * p.out_ld +
-                        p.out_coff;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int c = co0 + 16 * mt + 4 * g;
-            if (c >= p.cout) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = acc[mt][nt][r] + (p.bias ? p.bias[c + r] : 0.0f);
-                if (p.act == 1) t = fmaxf(t, 0.0f);
-                else if (p.act == 2) t = t >= 0.0f ? t : t * p.slope;
-                v[r] = t;
-            }
-            if (c + 4 <= p.cout && ((p.out_coff + c) & 3) == 0 && (p.out_ld & 3) == 0) {
-                *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c + r < p.cout) dst[c + r] = (_Float16)v[r];
-            }
-        }
-    }
+    if (p.splits > 1 || p.act == 0) gather_store<BN, 0>(p, acc, M, m0, co0, tid, zsplit, ph, oy_off, ox_off);
+    else if (p.act == 1) gather_store<BN, 1>(p, acc, M, m0, co0, tid, zsplit, ph, oy_off, ox_off);
+    else gather_store<BN, 2>(p, acc, M, m0, co0, tid, zsplit, ph, oy_off, ox_off);
 }
 
 
@@ -403,9 +426,9 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
         const int row = 32 * wv + 16 * r + l15;
         const long long m = m0 + row;
         const bool ok = m < M;
-        const long long mm = ok ? m : 0;
-        const int n = (int)(mm / ((long long)p.Ho * p.Wo));
-        const int rem = (int)(mm - (long long)n * p.Ho * p.Wo);
+        const unsigned mm = ok ? (unsigned)m : 0u, HoWo = (unsigned)(p.Ho * p.Wo);   // (M < 2^31: checked by the launchers; 32-bit divisions)
+        const int n = (int)(mm / HoWo);
+        const int rem = (int)(mm - (unsigned)n * HoWo);
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         piy0[r] = ok ? oy * p.stride - pad_y : -(1 << 28);   // (a pixel past M fails every row test)
         pix0[r] = ox * p.stride_x - pad_x + (STEM ? 2 * g : 0);
@@ -517,45 +540,9 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
         body(ks + 2, C2{}, C0{}, C1{});
     }
 
-    // ---- epilogue: this lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15
-    //      (straight from the MFMA layout: the LDS-transposed epilogue of the patch kernels was measured here too and
-    //      loses 10-25 % on these shorter, lower-resolution launches)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const long long m = m0 + 32 * wv + 16 * nt + l15;
-        if (m >= M) continue;
-        if (p.splits > 1) {
-            float* wsp = p.ws + (((size_t)zsplit * (p.nphase > 1 ? 4 : 1) + ph) * M + m) * p.cout_pad + co0;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f4*>(wsp + 16 * mt + 4 * g) = acc[mt][nt];
-            continue;
-        }
-        const int n = (int)(m / ((long long)p.Ho * p.Wo));
-        const int rem = (int)(m - (long long)n * p.Ho * p.Wo);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        _Float16* dst = p.out + (((size_t)n * p.outH + oy * p.oy_mul + oy_off) * p.outW + ox * p.ox_mul + ox_off) * p.out_ld +
-                        p.out_coff;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int c = co0 + 16 * mt + 4 * g;
-            if (c >= p.cout) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = acc[mt][nt][r] + (p.bias ? p.bias[c + r] : 0.0f);
-                if (p.act == 1) t = fmaxf(t, 0.0f);
-                else if (p.act == 2) t = t >= 0.0f ? t : t * p.slope;
-                v[r] = t;
-            }
-            if (c + 4 <= p.cout && ((p.out_coff + c) & 3) == 0 && (p.out_ld & 3) == 0) {
-                *reinterpret_cast<h4*>(dst + c) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c + r < p.cout) dst[c + r] = (_Float16)v[r];
-            }
-        }
-    }
+    if (p.splits > 1 || p.act == 0) gather_store<BN, 0>(p, acc, M, m0, co0, tid, zsplit, ph, oy_off, ox_off);
+    else if (p.act == 1) gather_store<BN, 1>(p, acc, M, m0, co0, tid, zsplit, ph, oy_off, ox_off);
+    else gather_store<BN, 2>(p, acc, M, m0, co0, tid, zsplit, ph, oy_off, ox_off);
 }
 
 
@@ -1500,6 +1487,7 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
         p.oy_off_ph[ph] = py; p.ox_off_ph[ph] = px;
     }
     const long long M = (long long)N * H * W;
+    VSR_REQUIRE(M < (1ll << 31), "deconv4s2: %lld output pixels per phase exceed the kernel's 32-bit pixel index", M);
     const unsigned gx = vsr::cdiv(M, BM);
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const unsigned gy = cout_pad / bn;
@@ -1549,6 +1537,7 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
     p.outH = Ho; p.outW = Wo; p.oy_mul = 1; p.oy_off = 0; p.ox_mul = 1; p.ox_off = 0;
     p.act = act; p.slope = slope; p.ws = nullptr; p.splits = 1; p.nphase = 0;
     const long long M = (long long)N * Ho * Wo;
+    VSR_REQUIRE(M < (1ll << 31), "conv2d_stem: %lld output pixels exceed the kernels' 32-bit pixel index", M);
     // the hourglass stem's shape: persistent row-walking kernel with register-resident weights and full-line stores
     if (g_patch_mode != 1 && kh == 7 && kw == 7 && stride == 1 && pad_y == 3 && pad_x == 3 && cout == 128 && cout_pad == 128 && Ho == H &&
         Wo == W && (out_ld & 7) == 0 && (out_coff & 7) == 0 && (unsigned long long)N * H * W * 8 < (1ull << 31) && M >= 65536) {
@@ -1613,6 +1602,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     p.outH = outH; p.outW = outW; p.oy_mul = oy_mul; p.oy_off = oy_off; p.ox_mul = ox_mul; p.ox_off = ox_off;
     p.act = act; p.slope = slope; p.nphase = 0;
     const long long M = (long long)N * Ho * Wo;
+    VSR_REQUIRE(M < (1ll << 31), "conv2d: %lld output pixels exceed the kernels' 32-bit pixel index", M);
     // stride-1 layers with a real spatial kernel and enough pixels: the 2-D LDS patch kernel (stages the input once per
     // 32-channel chunk instead of gathering it kh*kw times from L2).  Measured on MI355X (tools/conv_microbench.py).
     const int patch_lds = (PT_H + kh - 1) * (PT_W + kw - 1) * 64;
