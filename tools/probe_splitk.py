@@ -10,7 +10,7 @@ m = fill_module_(VSR().eval(), 0).cuda()
 fr = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (4, h, w, 3)).astype(np.float32)).cuda()
 fx, hx, ox = m._flow_exec.get(), m._depth_exec.get(), m._vos_exec.get()
 fns = {"flow": lambda: m.FlowModule.forward_pairs([(fr[0], fr[1]), (fr[1], fr[2])], fx), "depth4": lambda: hx(fr), "vos": lambda: m.VOSModule(fr[0], fr[1], ox)}
-for thr in (1, 32, 64, 128, 256, 1, 64, 256):
+for thr in (64, 96, 128, 160, 192, 256, 96, 128, 192, 256):
     L.load().vsr_conv2d_tuning(1000 + thr)
     row = []
     for name, fn in fns.items():

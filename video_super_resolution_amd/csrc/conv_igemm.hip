@@ -1368,7 +1368,8 @@ static int launch_gather_lds(const ConvP& p, dim3 grid, hipStream_t stream) {
     return VSR_OK;
 }
 
-static int g_splitk_fill = 256;   // split K when a launch has fewer workgroups than this (measured: tools/probe_splitk.py)
+static int g_splitk_fill = 128;   // split K when a launch has fewer workgroups than this, into ~2x as many (tools/probe_splitk.py; 256 until the
+                                   // round-2 rebuild made a K step cheap: FlowNet2 3.7 -> 3.45 ms, hourglass 5.03 -> 4.88, OSVOS 1.25 -> 1.29)
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
 
 // byte range a gather kernel's buffer resource and its 32-bit offsets cover (0xFFFFFFFF marks "outside the image")
@@ -1378,7 +1379,7 @@ extern "C" {
 
 int vsr_conv2d_tuning(int patch_mode) {
     const int old = g_patch_mode;
-    if (patch_mode >= 1000) {   // 1000 + n: split-K fill threshold n (experiments; default 256)
+    if (patch_mode >= 1000) {   // 1000 + n: split-K fill threshold n (experiments; default 128)
         g_splitk_fill = patch_mode - 1000;
         return old;
     }
