@@ -140,7 +140,9 @@ def test_conv_writes_into_channel_slices():
         assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 7, 9, 32), (2, 1026, 4, 5, 256), (1, 386, 16, 30, 64)])
+@pytest.mark.parametrize("shape", [(1, 64, 7, 9, 32), (2, 1026, 4, 5, 256), (1, 386, 16, 30, 64),
+                                   # few out-channels on >= 8192 pixels: the four phases from one staged patch (k_deconv4s2_patch), ragged tiles
+                                   (2, 192, 83, 101, 16), (1, 32, 97, 130, 2), (2, 128, 70, 118, 32), (1, 64, 128, 64, 13)])
 def test_transposed_conv_k4s2(shape):
     N, cin, H, W, cout = shape
     rs = np.random.RandomState(cin)
@@ -152,6 +154,13 @@ def test_transposed_conv_k4s2(shape):
     got = igemm.to_nchw_float(dc(igemm.to_nhwc_half(x)), cout)
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    from video_super_resolution_amd import _lib as L
+    old = L.load().vsr_conv2d_tuning(1)   # the same layer through the gather kernel (four phases in one launch)
+    try:
+        got1 = igemm.to_nchw_float(dc(igemm.to_nhwc_half(x)), cout)
+    finally:
+        L.load().vsr_conv2d_tuning(old)
+    assert (got1 - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 120, 256), (1, 13, 37, 256), (1, 8, 15, 64)])

@@ -896,6 +896,79 @@ __global__ void __launch_bounds__(256) k_conv_patch_rows(const ConvP p) {
                          [&](int r, int li) { return patch_pixoff(p, n, oy0 + ry0 + r, ox0 + cx0 + li); });
 }
 
+// k4 s2 p1 transposed convolution with few out-channels on many pixels (FlowNetSD's 192 -> 16 at 2 x 256 x 480, the 2 -> 2 flow
+// upsamplings): ALL FOUR phases from ONE staged input patch.  Through the gather kernel every input pixel is fetched 16 times
+// (4 phases x 2x2 taps) in the MFMA fragment layout, 64 L1 tag look-ups per load, for 4 MFMAs per K step at 16 out-channels:
+// 199 us for a layer whose HBM time is 30 us.  Here a workgroup stages the (8+2) x (32+2)-pixel patch of an 8 x 32 input tile
+// once per 32-channel chunk; a wave owns 4 rows x 16 columns, keeps the chunk's 16 weight fragments (4 phases x 2x2 taps) in
+// registers and walks the 3 x 6 patch positions it needs: the fragment at offset (dy, dx) feeds every (phase, tap) with
+// ky - pad_y(py) = dy and kx - pad_x(px) = dx (1, 2 or 4 of them).  Output pixel (2y + py, 2x + px).
+__global__ void __launch_bounds__(256) k_deconv4s2_patch(const ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    constexpr int PH = PT_H + 2, PW = PT_W + 2;
+    unsigned char* const patch = psm;                      // [PH][PW] pixels of 64 B (chunk XOR pixel-column bits 1-2)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tiles_x = (p.W + PT_W - 1) / PT_W;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int n = blockIdx.y;
+    const int co0 = blockIdx.z * 16;
+    const int oy0 = ty * PT_H, ox0 = tx * PT_W;
+    const int nchunk = p.cin >> 5;
+    const int ry0 = 4 * (wv >> 1), cx0 = 16 * (wv & 1);    // this wave's 4 x 16 input pixels of the 8 x 32 tile
+
+    f4 acc[4][4];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ph][r] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();
+        stage_patch(p, patch, n, ch, oy0 - 1, ox0 - 1, PH, PW, tid);
+        h8 A[4][4];   // [phase py * 2 + px][tap ky * 2 + kx]
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap)
+                A[ph][tap] = *reinterpret_cast<const h8*>(p.wpk_ph[ph] + ((size_t)(tap * nchunk + ch) * p.cout_pad + co0 + l15) * 32 + 8 * g);
+        __syncthreads();
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+            const int pxl = cx0 + l15 + dxi;
+            const unsigned char* src = patch + (ry0 * PW + pxl) * 64 + ((g ^ ((pxl >> 1) & 3)) << 4);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                const h8 bf = *reinterpret_cast<const h8*>(src + pr * PW * 64);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dy = pr - 1 - r;
+                    if (dy < -1 || dy > 1) continue;
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        const int ky = dy + (py == 0 ? 1 : 0);
+                        if (ky < 0 || ky > 1) continue;
+#pragma unroll
+                        for (int px = 0; px < 2; ++px) {
+                            const int kx = dxi - 1 + (px == 0 ? 1 : 0);
+                            if (kx < 0 || kx > 1) continue;
+                            acc[py * 2 + px][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[py * 2 + px][ky * 2 + kx], bf, acc[py * 2 + px][r], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with the patch: its memory carries the output tiles now
+    const int rows_ok = p.H - (oy0 + ry0), cols_ok = p.W - (ox0 + cx0);
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const long long wbase = (((long long)n * p.outH + 2 * (oy0 + ry0) + (ph >> 1)) * p.outW + 2 * (ox0 + cx0) + (ph & 1)) * p.out_ld;
+        const int rstride = 2 * p.outW * p.out_ld, cstride = 2 * p.out_ld;
+        patch_epilogue<1, 4>(p, psm + wv * (4 * 16 * 32), co0, lane, [&](int r, int) { return acc[ph][r]; },
+                             [&](int r, int li) { return r < rows_ok && li < cols_ok ? wbase + r * rstride + li * cstride : -1ll; });
+    }
+}
+
 // The patch kernel with a 16 x 32 output tile and 8 rows x 16 columns x MT out-channel tiles per wave.  Measured on
 // MI355X (tools/patch_exp.py): k_conv_patch spends 15-33 % of its time on the per-tap weight fragments (every wave
 // fetches every fragment, 1 KiB per 4 MFMAs, which is the L1's whole bandwidth) and one ds_read per 1-4 MFMAs.  Here
@@ -1489,6 +1562,14 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
     }
     const long long M = (long long)N * H * W;
     VSR_REQUIRE(M < (1ll << 31), "deconv4s2: %lld output pixels per phase exceed the kernel's 32-bit pixel index", M);
+    // few out-channels on many pixels: all four phases from one staged input patch (k_deconv4s2_patch)
+    if (g_patch_mode != 1 && g_patch_mode != 8 && cout_pad <= 32 && (long long)H * W >= 8192 && H >= 4 && W >= 16 && N <= 65535 &&
+        (unsigned long long)(PT_H + 18) * W * in_ld * 2 < (1ull << 31)) {
+        p.ws = nullptr; p.splits = 1;
+        const unsigned tiles = vsr::cdiv(H, PT_H) * vsr::cdiv(W, PT_W);
+        hipLaunchKernelGGL(k_deconv4s2_patch, dim3(tiles, N, cout_pad / 16), dim3(256), (PT_H + 2) * (PT_W + 2) * 64, vsr::S(stream), p);
+        return vsr::launched("deconv4s2_nhwc_f16/patch");
+    }
     const unsigned gx = vsr::cdiv(M, BM);
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const unsigned gy = cout_pad / bn;
