@@ -352,6 +352,11 @@ int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int 
                          vsr_stream_t stream);
 int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,
                             void* out, int N, int H, int W, int C, vsr_stream_t stream);
+/* The same with `a` (up2 = 1) or `b` (b_up2 = 1: b is [N,H/2,W/2,b_ld]) standing for UpsamplingNearest2d(2) of the tensor passed
+ * (the doubled map is never written): the tail of an hourglass level, `up` followed by coolAddTensors (pytorch_DIW_scratch.py:
+ * UpsamplingNearest2d(scale_factor=2), then F.interpolate(a, b.shape) + b), in one pass with the two-step index arithmetic. */
+int vsr_up2_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, int up2, const void* b_or_null, int b_ld, int b_coff,
+                                int b_up2, void* out, int N, int H, int W, int C, vsr_stream_t stream);
 
 /* FlowNetC cost volume + LeakyReLU(0.1) on MFMA (reference networks/FlowNetC.py: Correlation(pad_size=20, kernel_size=1,
  * max_displacement=20, stride1=1, stride2=2), correlation_cuda_kernel.cu:74-147): feat_a, feat_b [B,H,W,C] fp16 ->

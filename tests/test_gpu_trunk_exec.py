@@ -25,6 +25,24 @@ def test_hourglass_exec(gpu_vsr, hw):
     assert _rel(got, ref) < 1e-2
 
 
+@pytest.mark.parametrize("hw", [(70, 90), (64, 96), (135, 240)])
+def test_hourglass_deferred_upsampling_is_bit_identical(gpu_vsr, hw):
+    """`up` + AddResized as one pass (the x2 map never written, whichever arm ends in `up`) against the two passes: same index
+    arithmetic, so the same bits -- including the levels whose sizes are odd (a 135-row skip resized onto a 2 x 67-row arm)."""
+    netg = gpu_vsr.DepthModule.model.netG
+    fr = torch.from_numpy(np.random.RandomState(4).randint(0, 256, (2,) + hw + (3,)).astype(np.float32)).cuda()
+    ex = HourglassExec(netg)
+    assert ex.defer_up
+    with torch.no_grad():
+        fused = ex(fr).clone()
+        ex.defer_up = False
+        try:
+            two_pass = ex(fr).clone()
+        finally:
+            ex.defer_up = True
+    assert torch.equal(fused, two_pass)
+
+
 def test_flownet2_exec(gpu_vsr):
     net = gpu_vsr.FlowModule.net
     x = torch.from_numpy(np.random.RandomState(2).randint(0, 256, (2, 3, 2, 64, 128)).astype(np.float32)).cuda()

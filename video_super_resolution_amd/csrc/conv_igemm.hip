@@ -1276,7 +1276,7 @@ __global__ void __launch_bounds__(256) k_nchw_to_nhwc_h(const float* __restrict_
 // out[n,y,x,:] = a[n, y*Ha/H, x*Wa/W, slice a] (nearest, as F.interpolate(size)) + b[n,y,x, slice b]; b == null: resize only.
 __global__ void __launch_bounds__(256) k_resize_add(const _Float16* __restrict__ a, int a_ld, int a_coff, int Ha, int Wa,
                                                     const _Float16* __restrict__ b, int b_ld, int b_coff,
-                                                    _Float16* __restrict__ out, int N, int H, int W, int C) {
+                                                    _Float16* __restrict__ out, int N, int H, int W, int C, int up2, int b_up2) {
     // blockIdx.y = image row (n * H + y), blockIdx.x walks (x, 8-channel piece) of that row: 32-bit index math only
     // (a flat 64-bit index with three divisions per thread made this copy VALU-bound at a third of the device's copy rate)
     const unsigned c8n = (unsigned)C >> 3;
@@ -1285,10 +1285,14 @@ __global__ void __launch_bounds__(256) k_resize_add(const _Float16* __restrict__
     const unsigned x = q / c8n, c8 = q - x * c8n;
     const unsigned row = blockIdx.y, n = row / (unsigned)H, y = row - n * (unsigned)H;
     // ATen nearest: src = min(floor(dst * (in / out)), in - 1) with a float scale
-    const int ya = min((int)floorf((float)y * ((float)Ha / (float)H)), Ha - 1);
-    const int xa = min((int)floorf((float)x * ((float)Wa / (float)W)), Wa - 1);
+    // up2: `a` stands for UpsamplingNearest2d(2)(a), never materialised -- the resize indexes the doubled map (same float scale
+    // as the two-step evaluation) and halves the index
+    const int Hs = Ha << up2, Ws = Wa << up2;
+    const int ya = min((int)floorf((float)y * ((float)Hs / (float)H)), Hs - 1) >> up2;
+    const int xa = min((int)floorf((float)x * ((float)Ws / (float)W)), Ws - 1) >> up2;
     h8v v = *reinterpret_cast<const h8v*>(a + (((size_t)n * Ha + ya) * Wa + xa) * a_ld + a_coff + 8 * c8);
-    if (b) v += *reinterpret_cast<const h8v*>(b + ((size_t)row * W + x) * b_ld + b_coff + 8 * c8);
+    // b_up2: `b` stands for UpsamplingNearest2d(2)(b) of exactly the output's size (H = 2 Hb, W = 2 Wb): pixel (y >> 1, x >> 1)
+    if (b) v += *reinterpret_cast<const h8v*>(b + (((size_t)n * (H >> b_up2) + (y >> b_up2)) * (W >> b_up2) + (x >> b_up2)) * b_ld + b_coff + 8 * c8);
     *reinterpret_cast<h8v*>(out + ((size_t)row * W + x) * C + 8 * c8) = v;
 }
 
@@ -1482,13 +1486,20 @@ int vsr_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, in
 
 int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,
                             void* out, int N, int H, int W, int C, vsr_stream_t stream) {
+    return vsr_up2_resize_add_nhwc_f16(a, a_ld, a_coff, Ha, Wa, 0, b_or_null, b_ld, b_coff, 0, out, N, H, W, C, stream);
+}
+
+int vsr_up2_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, int up2, const void* b_or_null, int b_ld, int b_coff,
+                                int b_up2, void* out, int N, int H, int W, int C, vsr_stream_t stream) {
     VSR_REQUIRE(a && out, "resize_add: null pointer");
+    VSR_REQUIRE((up2 == 0 || up2 == 1) && (b_up2 == 0 || (b_up2 == 1 && b_or_null && (H & 1) == 0 && (W & 1) == 0)),
+                "resize_add: up2 flags (an upsampled addend needs an even output size)");
     VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ha > 0 && Wa > 0 && C > 0 && (C & 7) == 0 && (a_ld & 7) == 0 && (a_coff & 7) == 0 &&
                     a_coff + C <= a_ld, "resize_add: bad arguments");
     VSR_REQUIRE(!b_or_null || ((b_ld & 7) == 0 && (b_coff & 7) == 0 && b_coff + C <= b_ld), "resize_add: bad addend slice");
     VSR_REQUIRE((long long)N * H <= 65535 && (long long)W * (C >> 3) < (1ll << 31), "resize_add: more than 65535 image rows");
     hipLaunchKernelGGL(k_resize_add, dim3(vsr::cdiv((long long)W * (C >> 3), 256), (unsigned)(N * H)), dim3(256), 0, vsr::S(stream),
-                       (const _Float16*)a, a_ld, a_coff, Ha, Wa, (const _Float16*)b_or_null, b_ld, b_coff, (_Float16*)out, N, H, W, C);
+                       (const _Float16*)a, a_ld, a_coff, Ha, Wa, (const _Float16*)b_or_null, b_ld, b_coff, (_Float16*)out, N, H, W, C, up2, b_up2);
     return vsr::launched("resize_add");
 }
 

@@ -240,12 +240,14 @@ def pool2x2(x, coff, c, mode):
     return out
 
 
-def resize_add(a, a_coff, c, out_hw, b=None, b_coff=0):
-    """nearest-resize slice [a_coff, +c) of `a` to out_hw and (optionally) add slice [b_coff, +c) of `b` -> dense [N,H,W,c]."""
+def resize_add(a, a_coff, c, out_hw, b=None, b_coff=0, up2=False, b_up2=False):
+    """nearest-resize slice [a_coff, +c) of `a` to out_hw and (optionally) add slice [b_coff, +c) of `b` -> dense [N,H,W,c].
+    up2 / b_up2: `a` / `b` stands for UpsamplingNearest2d(2) of the tensor passed (not materialised; the index arithmetic of the
+    two steps; an upsampled `b` is [N, H/2, W/2, .])."""
     N, Ha, Wa, a_ld = a.shape
     H, W = out_hw
     out = torch.empty((N, H, W, c), dtype=torch.float16, device=a.device)
-    L.check(L.load().vsr_resize_add_nhwc_f16(L.dptr(a, torch.float16), a_ld, a_coff, Ha, Wa, L.optr(b, torch.float16),
-                                             b.shape[3] if b is not None else 0, b_coff, L.dptr(out, torch.float16), N, H, W, c,
-                                             L.stream()), "resize_add")
+    L.check(L.load().vsr_up2_resize_add_nhwc_f16(L.dptr(a, torch.float16), a_ld, a_coff, Ha, Wa, 1 if up2 else 0, L.optr(b, torch.float16),
+                                                 b.shape[3] if b is not None else 0, b_coff, 1 if b_up2 else 0, L.dptr(out, torch.float16),
+                                                 N, H, W, c, L.stream()), "resize_add")
     return out

@@ -156,6 +156,7 @@ class HourglassExec:
     # Off by default: alone the trunk gains 8 % (5.5 -> 5.1 ms for four frames) but inside VSR.forward, where FlowNet2
     # already runs beside it, the frame loses 1.8 ms (same-box A/B, tools/depth_ab.py and bench.py); results are identical.
     concurrent = os.environ.get("VSR_HOURGLASS_STREAMS", "0") == "1"
+    defer_up = True   # (False: "up" as a pass of its own, the first build -- the cross-check of tests/test_gpu_trunk_exec.py)
 
     def _run(self, node, x, coff, c, level=0):
         """x: NHWC buffer whose live channels are [coff, coff+c) -> (buffer, coff, c)."""
@@ -173,12 +174,20 @@ class HourglassExec:
             buf, m, ctot = node[1](x, coff)
             return buf, m, ctot
         if tag == "S":
-            for ch in node[1]:
+            items = node[1]
+            for i, ch in enumerate(items):
                 if ch == "+":
-                    (a, ca, na), (b, cb, nb) = x  # list from the preceding fan-out
-                    x, coff, c = resize_add(a, ca, nb, (b.shape[1], b.shape[2]), b, cb), 0, nb
+                    # list from the preceding fan-out; an arm that ends in "up" hands over its low-resolution map (4th field):
+                    # UpsamplingNearest2d(2) and the resize-to-b + add run as ONE pass, the x2 map is never written
+                    a, ca, na = x[0][:3]
+                    b, cb, nb = x[1][:3]
+                    a_up, b_up = len(x[0]) > 3, len(x[1]) > 3
+                    out_hw = (b.shape[1] << b_up, b.shape[2] << b_up)   # = the second arm's size (AddResized: interpolate(a, b.shape) + b)
+                    x, coff, c = resize_add(a, ca, nb, out_hw, b, cb, up2=a_up, b_up2=b_up), 0, nb
                 elif isinstance(ch, tuple) and ch[0] == "M":
                     x = self._fan_out(ch[1], x, coff, c, level)
+                elif ch == "up" and i == len(items) - 1 and self.defer_up:
+                    return x, coff, c, "up2"
                 else:
                     x, coff, c = self._run(ch, x, coff, c, level)
             return x, coff, c
