@@ -186,12 +186,31 @@ def g10(vsr):
     target = torch.from_numpy(hr[1:2].copy())
     hf = torch.from_numpy(hr.copy())
     vsr.loss4object.mask = None
+    # per-term taps: the four terms of video_super_resolution.py:73-79 and what loss4object returned
+    # (loss_function.py:87-101), so the fixture pins each term and the masked tensors, not only the weighted sum
+    taps = {"sr": [], "flow": [], "obj": []}
+    hooks = [vsr.SR_loss.register_forward_hook(lambda m, i, o: taps["sr"].append(o.detach().clone())),
+             vsr.Flow_loss.register_forward_hook(lambda m, i, o: taps["flow"].append(o.detach().clone())),
+             vsr.loss4object.register_forward_hook(lambda m, i, o: taps["obj"].append(o))]
     out0, loss0 = vsr(data.clone(), target, hf, None)
     mask = vsr.loss4object.mask.clone()
     hf2 = torch.from_numpy(hr.copy())
     out1, loss1 = vsr(data.clone(), target, hf2, out0)
+    for h in hooks:
+        h.remove()
+    assert len(taps["sr"]) == 4 and len(taps["flow"]) == 4 and len(taps["obj"]) == 4
+    terms = np.array([[float(taps["sr"][2 * k]), float(taps["sr"][2 * k + 1]), float(taps["flow"][2 * k]),
+                       float(taps["flow"][2 * k + 1])] for k in range(2)], dtype=np.float64)   # genSR, objSR, genFlow, objFlow
+    (mo0, mt0), mf0 = taps["obj"][0], taps["obj"][1]
+    (mo1, mt1), mf1 = taps["obj"][2], taps["obj"][3]
+    for t in (mo0, mt0, mf0, mo1, mt1, mf1):
+        assert float((t - t.round()).abs().max()) == 0 and 0 <= float(t.min()) and float(t.max()) <= 255
+    u8 = lambda t: t.numpy().astype(np.uint8)   # noqa: E731  (uint8-valued float tensors: stored losslessly)
     _save("g10_loss", hr=hr.astype(np.uint8), out0=out0.numpy(), out1=out1.numpy(), loss0=loss0.numpy(), loss1=loss1.numpy(),
-          mask=mask.numpy())
+          mask=mask.numpy(), terms=terms, masked_sr_out0=u8(mo0), masked_sr_tgt0=u8(mt0), masked_flow0=u8(mf0),
+          masked_sr_out1=u8(mo1), masked_flow1=u8(mf1))
+    print("terms (genSR, objSR, genFlow, objFlow):", terms.tolist())
+    print("masked fill values of the flow variant:", np.unique(u8(mf0)[np.broadcast_to(mask.numpy().reshape(mf0.shape[1:]), mf0.shape)]))
     print("loss0", float(loss0), "loss1", float(loss1), "mask mean", float(mask.float().mean()))
 
 

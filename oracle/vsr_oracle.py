@@ -572,10 +572,12 @@ def flow_loss(P: Params, pre: str, outputs: torch.Tensor) -> torch.Tensor:
                                            sr_loss(P, pre + "SR_loss.", outputs[1:2], outputs[2:3]))))
 
 
-def loss_calculate(P: Params, target: torch.Tensor, outputs: torch.Tensor, state: dict) -> torch.Tensor:
+def loss_calculate(P: Params, target: torch.Tensor, outputs: torch.Tensor, state: dict, taps: dict | None = None) -> torch.Tensor:
     """VSR.loss_calculate -- video_super_resolution.py:71-80.  `state` plays GetObjectsForOBJLoss.mask: the OSVOS mask is
     computed on the first call and reused ever after (loss_function.py:69-74, defect D7).  The masked-array calls are the
-    reference's own numpy expressions (:87-92, :98-99), including the [3,H,W] mask applied to [H,W,3] data."""
+    reference's own numpy expressions (:87-92, :98-99), including the [3,H,W] mask applied to [H,W,3] data; BOTH variants pass
+    `fill_value=0` (getSRMaskedOutputs :89,:92 and getFlowMaskedOutputs :99).  `taps`, when given, receives the four terms
+    and the masked tensors (what fixture g10 pins one by one)."""
     if state.get("mask") is None:
         seg = vos_projection(P, outputs[0], outputs[1], "loss4object.VOS.net.")
         state["mask"] = torch.stack((seg == 1,) * 3)
@@ -588,7 +590,10 @@ def loss_calculate(P: Params, target: torch.Tensor, outputs: torch.Tensor, state
                                      dtype=torch.float32)
         obj_sr = sr_loss(P, "SR_loss.", masked_output, masked_target)
         gen_flow = flow_loss(P, "Flow_loss.", outputs)
-        masked = torch.stack([torch.tensor(np.ma.MaskedArray(o.numpy().astype(np.uint8), mask).filled()) for o in outputs]
+        masked = torch.stack([torch.tensor(np.ma.MaskedArray(o.numpy().astype(np.uint8), mask, fill_value=0).filled()) for o in outputs]
                              ).type(torch.float32)
         obj_flow = flow_loss(P, "Flow_loss.", masked)
+    if taps is not None:
+        taps.update(terms=[float(gen_sr), float(obj_sr), float(gen_flow), float(obj_flow)], masked_sr_out=masked_output,
+                    masked_sr_tgt=masked_target, masked_flow=masked)
     return gen_sr + obj_sr + 0.006 * gen_flow + 0.006 * obj_flow

@@ -49,7 +49,8 @@ def test_reference_saved_checkpoint_loads_strict_and_round_trips(tmp_path):
     m = VSR().eval()
     fill_module_(m, seed=0)
     before = m.model.conv_in[0].weight.detach().clone()
-    ckpt = driver.load_checkpoint(m, os.path.join(GOLDEN, "g9_ref_checkpoint.pth.tar"), map_location="cpu")   # strict (main.py:118)
+    ref_file = os.path.join(GOLDEN, "g9_ref_checkpoint.pth.tar")
+    ckpt = driver.load_checkpoint(m, ref_file, map_location="cpu")   # strict (main.py:118); tensors only: the safe unpickler
     assert ckpt["epoch"] == meta["epoch"] and ckpt["arch"] == meta["arch"] and set(ckpt) == {"arch", "epoch", "state_dict", "optimizer"}
     sd = m.model.state_dict()
     assert set(sd) == set(meta["tensors"]) and len(sd) == 91
@@ -67,7 +68,13 @@ def test_reference_saved_checkpoint_loads_strict_and_round_trips(tmp_path):
     assert list(again["state_dict"]) == list(ckpt["state_dict"]) and again["epoch"] == 4
     assert all(torch.equal(again["state_dict"][k], ckpt["state_dict"][k]) for k in ckpt["state_dict"])
     m2 = VSR().eval()
-    driver.load_checkpoint(m2, name, map_location="cpu")
+    try:      # this file holds a pickled Adam OBJECT like main.py:236 writes: refused unless the caller trusts the file
+        driver.load_checkpoint(m2, name, map_location="cpu")
+        refused = False
+    except RuntimeError as e:
+        refused = "trusted=True" in str(e)
+    assert refused
+    driver.load_checkpoint(m2, name, map_location="cpu", trusted=True)
     assert torch.equal(m2.model.fc[0].weight, m.model.fc[0].weight)
 
 

@@ -85,6 +85,32 @@ def test_cpu_input_raises_and_train_true_needs_its_tensors(gpu_vsr):
         gpu_vsr(x.cuda(), None, None, None)  # train defaults to True like the reference signature: target / high_frames needed
 
 
+def _check_loss_terms(model, g, rep, bar):
+    """Each of genSR, objSR, genFlow, objFlow (video_super_resolution.py:73-79) against the reference's own value, and the
+    masked tensors loss4object handed out (loss_function.py:87-101): masked entries are 0 in BOTH variants.  The weighted sum
+    alone hides the flow terms (0.006 * 26.7 in 16364): a wrong fill of the flow variant (63) once passed on it."""
+    t = model.last_loss_terms
+    for name, got, ref in zip(("genSR", "objSR", "genFlow", "objFlow"), t["terms"], g["terms"][rep]):
+        rel = abs(got - ref) / abs(ref)
+        print(f"  [{name}] {got:.4f} vs reference {ref:.4f} (rel {rel:.2e})")
+        assert rel < bar, (rep, name, got, ref)
+    m = model.loss4object.mask
+    mf = t["masked_flow"]
+    assert float(mf[m.reshape(mf.shape[1:]).expand(mf.shape)].abs().max()) == 0.0          # fill_value=0 (:99)
+    assert float(t["masked_sr_out"][m.reshape(t["masked_sr_out"].shape[1:]).unsqueeze(0)].abs().max()) == 0.0
+    # frames 0 and 2 of high_frames are the fixture's own uint8 frames: where this run's mask agrees with the reference's, the
+    # masked tensors must be the reference's exactly (frame 1 is this run's SR output, compared through the terms above)
+    same = torch.from_numpy(g["mask"]).to(m.device) == m
+    ref_mf = torch.from_numpy(g[f"masked_flow{rep}"].astype(np.float32)).to(mf.device)
+    for k in (0, 2):
+        ok = same.reshape(mf.shape[1:])
+        assert torch.equal(mf[k][ok], ref_mf[k][ok])
+    if rep == 0:
+        ref_t = torch.from_numpy(g["masked_sr_tgt0"].astype(np.float32)).to(mf.device)
+        ok = same.reshape(ref_t.shape[1:]).unsqueeze(0)
+        assert torch.equal(t["masked_sr_tgt"][ok], ref_t[ok])
+
+
 def test_reference_driver_call_with_loss(golden, gpu_vsr):
     """main.py:196-203 replayed verbatim against the drop-in -- positional call, `train` left at its default (True),
     `real_loss.data` read -- on the inputs of the reference-generated fixture g10 (train=True, two recurrent frames).
@@ -94,6 +120,7 @@ def test_reference_driver_call_with_loss(golden, gpu_vsr):
     g = golden("g10_loss")
     model = copy.deepcopy(gpu_vsr)
     model.loss4object.reset()
+    model.keep_loss_terms = True
     hr = torch.from_numpy(g["hr"])                                   # one dataset item, uint8 [3,H,W,3] -> T = 1 below
     datas = hr.unsqueeze(0)
     from video_super_resolution_amd import driver
@@ -111,6 +138,7 @@ def test_reference_driver_call_with_loss(golden, gpu_vsr):
         rel = abs(float(real_loss) - float(want)) / abs(float(want))
         print(f"[train=True call {rep}] loss {float(real_loss):.3f} vs reference {float(want):.3f} (rel {rel:.2e})")
         assert rel < 2e-3
+        _check_loss_terms(model, g, rep, 2e-3)
     assert (model.loss4object.mask.cpu().numpy() != g["mask"]).mean() < 5e-3
     assert float(sum(total_loss) / len(total_loss)) > 0                # main.py:207 forms this mean
 
@@ -173,7 +201,21 @@ def test_streaming_mode_matches_per_window_evaluation(gpu_vsr_f16):
     assert key_f2 not in hits_before                        # the stale prediction of the old frame contents cannot match
     est2, _ = m(clip[1:4], None, None, est, train=False)
     assert torch.isfinite(est2).all()
+    # two DIFFERENT windows built afresh (torch.stack: version 0 every time) back to back.  The caching allocator
+    # hands the freed window's address to the next one; a cache that keyed on (address, shape, version) alone then served the
+    # first window's depth / flow for the second.  Entries now hold their frames, so the address cannot come back.
+    m.reset_temporal_cache()
+    rs = np.random.RandomState(11)
+    wins = [torch.from_numpy(rs.randint(0, 256, (3, 66, 70, 3)).astype(np.float32)) for _ in range(2)]
+    got2 = []
+    for wnd in wins:
+        fresh = torch.stack([f.cuda() for f in wnd])         # fresh storage, _version == 0
+        got2.append(m(fresh, None, None, None, train=False)[0].clone())
+        del fresh
     m.temporal_cache = False
+    want2 = [m(torch.stack([f.cuda() for f in wnd]), None, None, None, train=False)[0] for wnd in wins]
+    assert torch.equal(got2[0], want2[0])
+    assert torch.equal(got2[1], want2[1])                    # a stale hit would show the first window's guidance here
 
 
 def test_reference_driver_call_with_loss_fp16(golden, gpu_vsr_f16):
@@ -185,6 +227,7 @@ def test_reference_driver_call_with_loss_fp16(golden, gpu_vsr_f16):
     g = golden("g10_loss")
     model = copy.deepcopy(gpu_vsr_f16)
     model.loss4object.reset()
+    model.keep_loss_terms = True
     data, target, high_frames = driver.ingest_item(torch.from_numpy(g["hr"]).unsqueeze(0).cuda(), 4)
     estimated_image = None
     for rep, want in enumerate((g["loss0"], g["loss1"])):
@@ -196,5 +239,6 @@ def test_reference_driver_call_with_loss_fp16(golden, gpu_vsr_f16):
         rel = abs(float(real_loss) - float(want)) / abs(float(want))
         print(f"[train=True fp16 call {rep}] loss {float(real_loss):.3f} vs reference {float(want):.3f} (rel {rel:.2e})")
         assert rel < 2e-3                                          # measured 1.0e-4 / 6.3e-5
+        _check_loss_terms(model, g, rep, 4e-3)
     assert model.SR_loss._exec is not None and model.loss4object._exec is not None   # the MFMA executors ran
     assert (model.loss4object.mask.cpu().numpy() != g["mask"]).mean() < 1e-2

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(kBlock) k_conv1x1(const float* __restrict__ in
 }
 
 // ---- ConvTranspose2d(32,32,K,S,p2)+PReLU, (K,S) = (8,4) the reference's literals | (6,2) | (7,3) (SRFBN's table, see
-//      oracle sr_geometry).  HR pixel (Y,X): iy=(Y+2)/S, py=(Y+2)%S (same in x); T = ceil(K/S) taps per axis:
+//      sr.py sr_geometry).  HR pixel (Y,X): iy=(Y+2)/S, py=(Y+2)%S (same in x); T = ceil(K/S) taps per axis:
 //      out = b + sum_{dy,dx < T, py+S*dy < K, ..} sum_ci in[ci, iy-dy, ix-dx] * W[ci, co, py+S*dy, px+S*dx].
 //      wp = weight repacked to [ky][kx][ci][co] so the 32 co of one tap are contiguous and uniform.
 //      Block = one HR row Y (py uniform), lanes = LR column index q, loop over the S px phases.

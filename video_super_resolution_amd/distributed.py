@@ -63,10 +63,14 @@ class ClipGather:
     `[n_clips, K, ...]` in clip order on `dst`, None elsewhere.  Single process (no process group): pass-through."""
 
     def __init__(self, n_clips: int, dst: int = 0, group=None):
+        """`dst` is a GLOBAL rank (what dist.gather takes); with a sub-group it is translated to the group rank for the
+        "am I the root" test."""
         self.n_clips, self.dst, self.group = n_clips, dst, group
         self.dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.dist else 1
         self.rank = dist.get_rank(group) if self.dist else 0
+        # group rank of the root; single process: whatever `dst` was asked for, this process is the root
+        self.dst_in_group = (dist.get_group_rank(group, dst) if group is not None else dst) if self.dist else 0
         self.rounds = []   # (work handle or None, receive buffers or [local])
         self._shape = None
 
@@ -80,7 +84,7 @@ class ClipGather:
         if not self.dist:
             self.rounds.append((None, [frames]))
             return
-        bufs = [torch.empty_like(frames) for _ in range(self.world)] if self.rank == self.dst else None
+        bufs = [torch.empty_like(frames) for _ in range(self.world)] if self.rank == self.dst_in_group else None
         work = dist.gather(frames, bufs, dst=self.dst, group=self.group, async_op=True)
         self.rounds.append((work, bufs, frames))   # keep `frames` alive until the transfer has completed
 
@@ -89,10 +93,10 @@ class ClipGather:
         for entry in self.rounds:
             if entry[0] is not None:
                 entry[0].wait()
-            if self.rank == self.dst:
+            if self.rank == self.dst_in_group:
                 out.extend(entry[1])
         self.rounds = []
-        if self.rank != self.dst:
+        if self.rank != self.dst_in_group:
             return None
         # round j delivered clips j*W + r for r = 0..W-1, i.e. already in clip order; drop the padding of the last round
         return torch.stack(out[:self.n_clips])
@@ -103,6 +107,10 @@ def run_sharded_clips(forward_clip, n_clips: int, rank: int, world: int, dst: in
     (frames inside a clip are serial), each finished clip gathered to `dst` while the next one runs.
     `forward_clip(clip_id) -> [K, ...]` produces the finished frames of one clip on this rank's device.
     Returns ([n_clips, K, ...] on dst | None, number of clips this rank ran)."""
+    if n_clips < world:   # checked on EVERY rank BEFORE any collective: a clipless rank would leave the others' async
+        #                   gathers waiting for it until the RCCL timeout (ADVICE r2)
+        raise RuntimeError(f"a rank without any clip cannot take part in the gather: n_clips ({n_clips}) must be >= the "
+                           f"world size ({world})")
     mine = clips_of_rank(n_clips, rank, world)
     rounds = -(-n_clips // world)
     g = ClipGather(n_clips, dst=dst, group=group)
@@ -120,6 +128,5 @@ def run_sharded_clips(forward_clip, n_clips: int, rank: int, world: int, dst: in
             g.submit(None, like=like)
         else:
             pending_none += 1
-    if pending_none:
-        raise RuntimeError("a rank without any clip cannot take part in the gather: use n_clips >= world size")
+    assert pending_none == 0
     return g.finish(), len(mine)

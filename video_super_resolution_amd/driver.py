@@ -15,7 +15,8 @@ feeds it, on the GPU path and without OpenCV:
                             SRmodel.model.state_dict(),'optimizer'} -- files interchange with the reference's
 
 `python -m video_super_resolution_amd.driver` is BASELINE.json's config C1 (3-frame 128x128 LR synthetic clip through the
-main-like plumbing) on the GPU path; `--check` times the CPU oracle beside it and reports the PSNR between the two.
+main-like plumbing) on the GPU path (`tools/c1_check.py` runs the CPU checker beside it and reports the PSNR between the two:
+the package itself never touches the checker).
 Decoding compressed video (cv2.VideoCapture, video_utils.py:17-23) is out of scope: a clip enters as a uint8 RGB array
 (`.npy`, raw rgb24, or synthetic).
 """
@@ -66,6 +67,8 @@ class VideoDataset(torch.utils.data.Dataset):
     def __init__(self, videos, raw_shape: Optional[Tuple[int, int]] = None, splitvideonum: int = 20):
         if isinstance(videos, str):
             videos = sorted(glob(os.path.join(videos, "*")))
+        elif isinstance(videos, np.ndarray):   # ONE clip [T,H,W,3], not a list of clips (list() would split it into frames)
+            videos = [videos]
         self.video_paths = list(videos)
         self.raw_shape = raw_shape
         self.data: list = []
@@ -151,9 +154,18 @@ def checkpoint_state(model, epoch: int, optimizer=None, arch: str = "VSR") -> di
     return {"arch": arch, "epoch": epoch, "state_dict": model.model.state_dict(), "optimizer": optimizer}
 
 
-def load_checkpoint(model, path: str, map_location=None) -> dict:
-    """main.py:108-122: `SRmodel.model.load_state_dict(checkpoint['state_dict'])` (strict)."""
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+def load_checkpoint(model, path: str, map_location=None, trusted: bool = False) -> dict:
+    """main.py:108-122: `SRmodel.model.load_state_dict(checkpoint['state_dict'])` (strict).
+    The file is first read with `weights_only=True` (tensors and plain containers only).  The reference's checkpoints hold
+    the pickled Adam OBJECT under 'optimizer' (main.py:236), which that mode refuses: such a file is unpickled in full only
+    when the caller says it is `trusted` (unpickling runs arbitrary code from the file)."""
+    try:
+        ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as e:   # pickle.UnpicklingError and friends: an object beyond tensors / containers
+        if not trusted:
+            raise RuntimeError(f"{path} holds pickled objects beyond tensors (the reference saves its optimizer object, "
+                               f"main.py:236); pass trusted=True to unpickle it in full -- only for files you trust") from e
+        ckpt = torch.load(path, map_location=map_location, weights_only=False)
     model.model.load_state_dict(ckpt["state_dict"])
     return ckpt
 
@@ -169,26 +181,19 @@ def synthetic_video(n_frames: int, H: int, W: int, seed: int = 1234) -> np.ndarr
     return np.stack([np.floor(base[k:k + H, 2 * k:2 * k + W]) for k in range(n_frames)]).astype(np.uint8)
 
 
-def main(argv=None):
-    import argparse
-    import json
+def run_c1(lr: int = 128, frames: int = 3, scale: int = 4, precision: str = "fp32"):
+    """Config C1: a synthetic clip through ingest_item / run_item on the GPU path.
+    -> (result line, model, datas uint8 [T,3,H,W,3] on the device, outputs [T,H,W,3])."""
     import time
-    ap = argparse.ArgumentParser(description="config C1: a synthetic clip through the main.py-like plumbing on the GPU path")
-    ap.add_argument("--lr", type=int, default=128, help="LR frame size (BASELINE.json C1: 128)")
-    ap.add_argument("--frames", type=int, default=3, help="frames of the clip (3 = one window)")
-    ap.add_argument("--scale", type=int, default=4, choices=[2, 3, 4], help="4 = the reference's geometry; 2 = C1's label")
-    ap.add_argument("--precision", default="fp32", choices=["fp16", "fp32"])
-    ap.add_argument("--check", action="store_true", help="run the CPU oracle on the same windows and report the PSNR")
-    args = ap.parse_args(argv)
     from . import VSR
     from .weights import fill_module_
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    S = args.scale
+    S = scale
     model = fill_module_(VSR(upscale_factor=S).eval(), seed=0).to(dev)
-    model.precision = model.model.precision = args.precision
-    video = synthetic_video(args.frames, S * args.lr, S * args.lr)
-    windows = [video[i:i + 3] for i in range(args.frames - 2)]            # one dataset item (video_utils.py:25)
+    model.precision = model.model.precision = precision
+    video = synthetic_video(frames, S * lr, S * lr)
+    windows = [video[i:i + 3] for i in range(frames - 2)]                 # one dataset item (video_utils.py:25)
     datas = torch.from_numpy(np.stack(windows)).to(dev)                   # main.py:186 `torch.tensor(dataset[batch_idx])`
     data, target, high_frames = ingest_item(datas, S)
     run_item(model, data, target, high_frames)                            # warm-up (packing, allocator)
@@ -198,20 +203,21 @@ def main(argv=None):
     u8 = frames_to_u8(outs)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    line = dict(config=f"C1: {args.frames}-frame {args.lr}x{args.lr} LR synthetic clip, x{S}, main-like driver, GPU path",
-                precision=args.precision, windows=len(windows), frames_per_s=round(len(windows) / dt, 3), out_shape=list(u8.shape))
-    if args.check:
-        from oracle import vsr_oracle as O
-        P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        est, mse = None, 0.0
-        t0 = time.perf_counter()
-        lr_cpu = O.make_lr(datas.cpu(), S)
-        for t in range(len(windows)):
-            with torch.no_grad():
-                est = O.vsr_forward(P, lr_cpu[t], est, upscale_factor=S)
-            mse += float(((outs[t].cpu() - est[0]) ** 2).mean())
-        line["cpu_oracle_frames_per_s"] = round(len(windows) / (time.perf_counter() - t0), 5)
-        line["psnr_vs_oracle_db"] = round(10 * np.log10(255.0 ** 2 / max(mse / len(windows), 1e-20)), 2)
+    line = dict(config=f"C1: {frames}-frame {lr}x{lr} LR synthetic clip, x{S}, main-like driver, GPU path",
+                precision=precision, windows=len(windows), frames_per_s=round(len(windows) / dt, 3), out_shape=list(u8.shape))
+    return line, model, datas, outs
+
+
+def main(argv=None):
+    import argparse
+    import json
+    ap = argparse.ArgumentParser(description="config C1: a synthetic clip through the main.py-like plumbing on the GPU path")
+    ap.add_argument("--lr", type=int, default=128, help="LR frame size (BASELINE.json C1: 128)")
+    ap.add_argument("--frames", type=int, default=3, help="frames of the clip (3 = one window)")
+    ap.add_argument("--scale", type=int, default=4, choices=[2, 3, 4], help="4 = the reference's geometry; 2 = C1's label")
+    ap.add_argument("--precision", default="fp32", choices=["fp16", "fp32"])
+    args = ap.parse_args(argv)
+    line, _, _, _ = run_c1(args.lr, args.frames, args.scale, args.precision)
     print(json.dumps(line))
 
 

@@ -6,8 +6,8 @@ Mirrors loss_function.py:9-101 and `VSR.loss_calculate` (network/video_super_res
     Flow_loss             0.005 * mean(SR_loss(f0, f1), SR_loss(f1, f2)) with its OWN SR_loss       (:51-62)
     GetObjectsForOBJLoss  OSVOS mask of (frame 0, frame 1), computed ONCE and cached forever (D7, :69-74), applied by
                           numpy masked arrays whose [3,H,W] mask is re-read as [H,W,3] (equal sizes: numpy reshapes it),
-                          on frames cast to uint8 (C cast: truncation, wrap modulo 256), masked entries filled with 0 (SR
-                          variant, :87-92) or with uint8(999999) = 63, numpy's default integer fill value (flow variant, :98-99)
+                          on frames cast to uint8 (C cast: truncation, wrap modulo 256), masked entries filled with 0 in both
+                          variants (`fill_value=0`: getSRMaskedOutputs :89,:92 and getFlowMaskedOutputs :99)
     loss = genSR + objSR + 0.006 * genFlow + 0.006 * objFlow                                       (:73-80), a 0-d CPU tensor
 
 Sub-module and parameter names are the reference's (`SR_loss.loss_network.<i>`, `Flow_loss.SR_loss.loss_network.<i>`,
@@ -147,19 +147,25 @@ class GetObjectsForOBJLoss(nn.Module):
             m_tgt = self.mask.reshape(target.shape)
             masked_target = torch.where(m_tgt, torch.zeros((), device=m_tgt.device), _as_uint8(target))
             return masked_output, masked_target
-        fill = float(999999 & 255)   # .filled() without fill_value: numpy's default for integers, wrapped into uint8 (= 63)
-        outs = [torch.where(self.mask.reshape(o.shape), torch.full((), fill, device=o.device), _as_uint8(o)) for o in outputs]
+        # getFlowMaskedOutputs (loss_function.py:95-101): `fill_value=0` like the SR variant
+        outs = [torch.where(self.mask.reshape(o.shape), torch.zeros((), device=o.device), _as_uint8(o)) for o in outputs]
         return torch.stack(outs).to(torch.float32)
 
 
-def loss_calculate(model, target, outputs) -> torch.Tensor:
-    """VSR.loss_calculate (network/video_super_resolution.py:71-80).  target [1,H,W,3], outputs = high_frames [3,H,W,3]."""
+def loss_calculate(model, target, outputs, taps: dict | None = None) -> torch.Tensor:
+    """VSR.loss_calculate (network/video_super_resolution.py:71-80).  target [1,H,W,3], outputs = high_frames [3,H,W,3].
+    `taps`, when given, receives the four terms (genSR, objSR, genFlow, objFlow) and the tensors loss4object returned, so that
+    tests can pin each against the reference's (fixture g10) rather than only their weighted sum."""
     with torch.no_grad():
         model.SR_loss.precision = model.Flow_loss.SR_loss.precision = model.loss4object.precision = getattr(model, "precision", "fp32")
         gen_sr = model.SR_loss(outputs[0:1], target)
         masked = model.loss4object(outputs[:2], target, SR=True)
         obj_sr = model.SR_loss(masked[0], masked[1])
         gen_flow = model.Flow_loss(outputs)
-        obj_flow = model.Flow_loss(model.loss4object(outputs))
+        masked_flow = model.loss4object(outputs)
+        obj_flow = model.Flow_loss(masked_flow)
+        if taps is not None:
+            taps.update(terms=[float(gen_sr), float(obj_sr), float(gen_flow), float(obj_flow)], masked_sr_out=masked[0],
+                        masked_sr_tgt=masked[1], masked_flow=masked_flow)
         loss = gen_sr.data + obj_sr.data + 0.006 * gen_flow.data + 0.006 * obj_flow.data
         return loss.cpu()

@@ -37,7 +37,7 @@ def sr_geometry(upscale_factor: int):
     (SRProjectionModule.py:10-12,101-103 -- the x4 row of SRFBN's table); x2 = (6, 2, 2) and x3 = (7, 3, 2) are that
     table's other rows: the scale extension SURVEY.md 7-1 / 8(d) asks for (BASELINE configs C1, C2, C3-B, C5 are labelled
     x2).  The reference itself crashes for upscale_factor != 4, so x2 / x3 have no reference output: they are checked
-    against the oracle evaluated with the same three literals (parity-unpinned by construction)."""
+    against the CPU checker evaluated with the same three literals (parity-unpinned by construction)."""
     try:
         return {2: (6, 2, 2), 3: (7, 3, 2), 4: (8, 4, 2)}[int(upscale_factor)]
     except KeyError:
@@ -297,6 +297,12 @@ class SRProjectionModule(nn.Module):
         operators so that `loss.backward()` reaches the SR net's parameters (SURVEY.md 8(b) "autograd": backward kernels are
         not built).  The benchmark and every parity test of the kernels run the first path."""
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            if not getattr(self, "_warned_autograd", False):   # modules are born in training mode: say so once (ADVICE r2)
+                import warnings
+                warnings.warn("SRProjectionModule: training mode with autograd enabled -> this call runs the differentiable "
+                              "stock-operator path in float32 (the train step of main.py:205-210), not the HIP kernels; "
+                              "call .eval() or wrap the call in torch.no_grad() for inference", stacklevel=2)
+                self._warned_autograd = True
             out = self._forward_autograd(x)
             S = self.upscale_factor
             return out[..., ::S, ::S] if decimate else out

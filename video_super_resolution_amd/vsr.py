@@ -19,9 +19,9 @@ What differs, on purpose:
   * the loss branch (`train=True`, :67,:71-80) is evaluated by loss.py (the reference's SR_loss / Flow_loss /
     GetObjectsForOBJLoss with its own names) under no_grad on the device and returns the reference's 0-d CPU tensor, so the
     reference driver's call `model(x, y, high_frame, estimated_image)` + `real_loss.data` (main.py:199-203) works as is.
-    What does NOT exist is autograd through the hand-written kernels: main.py:205-210 replaces `loss.data` by the running mean
-    and calls `loss.backward()` on a graph that starts at `output.cpu()`, which here carries no grad_fn -- training the SR
-    net needs backward kernels (not built).  Inference (`train=False`) returns `loss=None`.
+    Inference (`train=False`) returns `loss=None`;
+  * the train step's single differentiable call (:64 at main.py:205-210) is served by `SRProjectionModule._forward_autograd`
+    (sr.py) when the module is in training mode with autograd enabled; eval mode or `no_grad` always runs the HIP kernels.
 """
 from __future__ import annotations
 
@@ -72,10 +72,15 @@ class VSR(nn.Module):
         # across calls, keyed by the identity AND version counter of the frame tensors (views of one clip tensor, as
         # main.py:196-199 / driver.run_item hand them over): about two of G1's four hourglass runs and one of its two FlowNet2
         # runs saved per window.  Same networks on the same frames, but on smaller batches -- the MFMA convolution picks its
-        # tile / split-K shape by the pixel count -- so the frames agree with the per-window evaluation to rounding, not bit for bit.  The caller must not free and refill frame storage between calls without
-        # going through tensor operations (the version counter is how a change is seen); `reset_temporal_cache()` drops it.
+        # tile / split-K shape by the pixel count -- so the frames agree with the per-window evaluation to rounding, not bit for bit.
+        # A cache entry HOLDS the frame tensors it was computed from, so their storage cannot be freed and handed out again
+        # under the same address (windows built afresh by torch.stack / .to(dev) never hit: different storage, and the old
+        # one is still alive); what the key cannot see is a write into the SAME storage that bypasses the version counter
+        # (a raw-pointer kernel launch): call `reset_temporal_cache()` after one.
         self.temporal_cache = False
         self._tcache = {"depth": {}, "flow": {}}
+        self.keep_loss_terms = False   # True: `last_loss_terms` = the four terms + masked tensors of the last train=True call
+        self.last_loss_terms = None
         self._flow_exec = TrunkExecCache(self.FlowModule.net, FlowNet2Exec)
         self._depth_exec = TrunkExecCache(self.DepthModule.model.netG, HourglassExec)
         self._vos_exec = TrunkExecCache(self.VOSModule.net, OSVOSExec)
@@ -90,7 +95,11 @@ class VSR(nn.Module):
 
     def loss_calculate(self, target, outputs):
         """video_super_resolution.py:71-80 (a 0-d CPU tensor, computed under no_grad like the reference)."""
-        return loss_calculate(self, target, outputs)
+        taps = {} if self.keep_loss_terms else None
+        loss = loss_calculate(self, target, outputs, taps)
+        if taps is not None:
+            self.last_loss_terms = taps
+        return loss
 
     def __deepcopy__(self, memo):
         """copy.deepcopy of a module that has run: HIP streams and the executors built on them are per-instance run-time
@@ -150,7 +159,7 @@ class VSR(nn.Module):
             for f in trip:
                 hit = tc["depth"].get(self._tkey(f))
                 if hit is not None and f.data_ptr() not in depth_cache:
-                    depth_cache[f.data_ptr()] = (f, hit)
+                    depth_cache[f.data_ptr()] = (f, hit[1])
         new = []
         for f in list(trip) + list(extra_depth):
             if f.data_ptr() not in depth_cache and all(f.data_ptr() != g.data_ptr() for g in new):
@@ -175,11 +184,13 @@ class VSR(nn.Module):
         if tc is not None:
             keys = [(self._tkey(a), self._tkey(b)) for a, b in pairs]
             have = [tc["flow"].get(k) for k in keys]
+            have = [hv[2] if hv is not None else None for hv in have]
             todo = [p for p, hv in zip(pairs, have) if hv is None]
             fresh = iter(self.FlowModule.forward_pairs(todo, net)) if todo else iter(())
             pics_l = [hv if hv is not None else next(fresh) for hv in have]
             pics = torch.stack(pics_l)
-            tc["flow"] = {k: p for k, p in zip(keys, pics_l)}                      # keep this window's two pictures only
+            # keep this window's two pictures only -- WITH their frames, so the keyed addresses stay taken
+            tc["flow"] = {k: (a, b, p) for k, (a, b), p in zip(keys, pairs, pics_l)}
         else:
             pics = self.FlowModule.forward_pairs(pairs, net)
         if fast:
@@ -187,7 +198,7 @@ class VSR(nn.Module):
             main.wait_stream(s_vos)
         z = [depth_cache[f.data_ptr()][1] for f in trip]
         if tc is not None:
-            tc["depth"] = {self._tkey(f): zz for f, zz in zip(trip, z)}             # ... and its three depth predictions
+            tc["depth"] = {self._tkey(f): (f, zz) for f, zz in zip(trip, z)}        # ... and its three depth predictions
         return pics, z, mask
 
     @staticmethod

@@ -8,7 +8,7 @@ from `numpy.random.RandomState` (a frozen bit-stream), so the very same
 numbers are produced
 
   * in the development container for the reference's own modules (golden
-    fixtures, `oracle/make_golden.py`), and
+    fixtures: the golden-vector generator), and
   * on the GPU box for this package's modules (which keep the reference's
     `state_dict` key names),
 
