@@ -140,6 +140,32 @@ def cpu_baseline(scale: int, sizes=(64, 96, 128), budget_s: float = 75.0):
                 cores=cores, cores_available=avail, cpu=cpu_model())
 
 
+def other_configs(progress, names=("C3B", "C5", "C2"), steps=5, warmup=2, timeout_s=170):
+    """The other single-GPU configurations of BASELINE.json, each as a SHORT run of this same script in a child process
+    (own model, own allocator; a failure there cannot cost the headline line), so that the driver's one default invocation
+    also times reading B of the headline ("1080p LR -> 4K", C3-B), C5 and C2.  -> {name: {value, ms_per_step, roofline, ...}}"""
+    import subprocess
+    torch.cuda.empty_cache()
+    out = {}
+    for name in names:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", name, "--steps", str(steps), "--warmup", str(warmup),
+               "--no-extras", "--no-cpu-baseline", "--no-configs"]
+        progress(f"config {name}: {steps} steps in a child process")
+        t0 = time.time()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or len(lines) != 1:
+                out[name] = dict(error=f"rc {p.returncode}: {p.stderr[-300:]}")
+                continue
+            d = json.loads(lines[0])
+            out[name] = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
+            out[name]["wall_s"] = round(time.time() - t0, 1)
+        except subprocess.TimeoutExpired:
+            out[name] = dict(error=f"no line within {timeout_s} s")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +181,11 @@ def main():
                     help="config C4: this many independent clips round-robin over the ranks (clip i -> rank i mod N), `steps` "
                          "frames each, one asynchronous gather per finished clip; 0 = one clip per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and issue every collective (barrier, gathers, all_reduce) even with ONE "
+                         "rank: lets a one-GPU box execute the N > 1 code path (tests/test_gpu_rccl_single_rank.py)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="default C3-A line only: do not append the short C3-B / C5 / C2 runs under `configs`")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two separately-labelled extra loops (opt-in streaming mode; PCIe-inclusive uint8 in / uint8 out)")
     args = ap.parse_args()
@@ -173,9 +204,14 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
 
     from video_super_resolution_amd import VSR, _lib
     from video_super_resolution_amd.distributed import clips_of_rank, gather_frames, run_sharded_clips
@@ -229,7 +265,7 @@ def main():
                 out[i].copy_(e[0])
             return out
 
-        if world > 1:
+        if use_dist:
             dist.barrier()
         # HIP events around the dominant kernel's launches only: ~12 event pairs per frame, not one per launch
         _lib.TIMER.reset()
@@ -238,23 +274,23 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if args.clips > 0:
-            gathered, ran = run_sharded_clips(forward_clip, n_clips, rank, world, dst=0)   # [n_clips, K, H, W, 3] on rank 0
+            gathered, ran = run_sharded_clips(forward_clip, n_clips, rank, world, dst=0, force_collective=args.force_dist)   # [n_clips, K, H, W, 3] on rank 0
             total_frames = n_clips * args.steps
         else:
             finished = forward_clip(my_clips[0])
-            g = gather_frames(finished, dst=0)
+            g = gather_frames(finished, dst=0, force_collective=args.force_dist)
             gathered = torch.stack(g) if g is not None else None
             ran = 1
             total_frames = world * args.steps
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         _lib.TIMER.enabled = False
         _lib.TIMER.only = None
         progress(f"timed region: {elapsed:.3f} s for {args.steps} steps x {ran} clip(s) on this rank")
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -387,8 +423,13 @@ def main():
                                         sample=f"1 frame of VSR.forward (the oracle, x{scale}) at LR {pts}; least-squares line "
                                                f"{cb['intercept_s']:.2f} s + {cb['slope_s_per_px'] * 1e3:.4f} ms/px evaluated at "
                                                f"LR {h}x{w} = {sec_full:.0f} s per frame (extrapolated)")
+        if (world == 1 and args.config == "C3A" and not args.no_configs and not args.force_dist and args.clips == 0 and
+                args.lr_h is None and args.lr_w is None and args.scale is None and args.precision is None):
+            line["configs"] = other_configs(progress)
+        if use_dist:
+            line["process_group"] = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), forced_single_rank=bool(args.force_dist))
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

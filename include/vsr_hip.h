@@ -37,6 +37,10 @@ typedef void* vsr_stream_t; /* hipStream_t */
 
 int vsr_abi_version(void);
 const char* vsr_last_error(void);
+/* Name of the kernel the convolution launchers (vsr_conv2d_*, vsr_deconv4s2_*) routed this thread's last call to, e.g.
+ * "patch_r8<3,2>", "gather<128>+splitk4", "tile<128>": kernel SELECTION depends on the layer's size, so the full-size parity
+ * tests log it per layer (the reference delegates this choice to cuDNN's heuristics). */
+const char* vsr_last_route(void);
 
 /* ------------------------------------------------------------------------------------------
  * FlowNet2's three native operators.  Each replaces one pybind entry point of the reference.

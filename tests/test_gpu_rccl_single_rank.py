@@ -1,0 +1,78 @@
+"""The RCCL code path executed on hardware with what a one-GPU box offers: a process group of ONE rank, backend "nccl"
+(= RCCL on ROCm), every collective of the N > 1 path issued for real (`force_collective`) on device tensors.
+
+It measures nothing -- one rank exchanges no bytes over xGMI -- but communicator initialisation, the device-side gather
+buffers, asynchronous work handles, stream ordering between the compute stream and RCCL's, `all_reduce(MAX)` of the timing
+scalar and the process-group teardown stop being code that first runs on the driver's 8-GPU node.
+Each case runs in a FRESH process (the group is initialised before anything else touches the GPU there)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29547")
+import torch, torch.distributed as dist
+from video_super_resolution_amd.distributed import ClipGather, gather_frames, run_sharded_clips
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+g = torch.Generator(device="cpu").manual_seed(3)
+frames = torch.rand((3, 32, 48, 3), generator=g).to(dev).half()
+# (1) the end-of-job gather of bench.py: all_gather of the counts + gather of the padded stacks, on device tensors
+got = gather_frames(frames, dst=0, force_collective=True)
+assert isinstance(got, list) and len(got) == 1 and torch.equal(got[0], frames)
+# (2) config C4's per-clip asynchronous gathers, issued while "the next clip" is computed on the compute stream
+def forward_clip(cid):
+    x = frames * (cid + 1)
+    for _ in range(4):
+        x = x + 0          # some work on the compute stream between submits
+    return x
+out, ran = run_sharded_clips(forward_clip, 3, 0, 1, dst=0, force_collective=True)
+assert ran == 3 and out.shape == (3,) + tuple(frames.shape)
+for c in range(3):
+    assert torch.equal(out[c], frames * (c + 1)), c
+cg = ClipGather(2, dst=0, force_collective=True)
+assert cg.dist and cg.world == 1
+cg.submit(frames); cg.submit(None, like=frames)        # a rank without a clip in the last round submits zeros
+fin = cg.finish()
+assert fin.shape[0] == 2 and torch.equal(fin[0], frames) and float(fin[1].abs().max()) == 0.0
+# (3) bench.py's max-over-ranks of the elapsed time
+el = torch.tensor([1.25], dtype=torch.float64, device=dev)
+dist.all_reduce(el, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert float(el.item()) == 1.25
+dist.destroy_process_group()
+print("RCCL_SINGLE_RANK_OK")
+'''
+
+
+def test_gather_helpers_on_a_one_rank_rccl_group():
+    p = subprocess.run([sys.executable, "-c", _CHILD, ROOT], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_SINGLE_RANK_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+@pytest.mark.parametrize("extra", [[], ["--clips", "2"]])
+def test_bench_under_the_distributed_launcher_with_one_rank(extra):
+    """bench.py exactly as the driver launches N > 1 (`python -m torch.distributed.run --nproc-per-node N ...`), N = 1, with
+    --force-dist: init_process_group("nccl"), barrier, the gathers, all_reduce(MAX), destroy -- all executed."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--lr-h", "64",
+           "--lr-w", "96", "--no-cpu-baseline", "--no-extras", "--force-dist"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["process_group"] == {"backend": "nccl", "world_size": 1, "forced_single_rank": True}
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"

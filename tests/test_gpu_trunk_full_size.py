@@ -1,0 +1,119 @@
+"""The guidance trunks and the whole forward at BASELINE.json's headline size (LR 540x960, FlowNet2 crop 512x960), on the GPU.
+
+The launchers choose kernels by layer size: at the sizes of test_gpu_trunk_exec.py (<= 135x240) the LDS-patch kernels
+(>= 8192 pixels), the 128-channel tiles, the hourglass stem kernel, the streaming 1x1 and the four-phase patch kernel of the
+thin transposed convolutions never run.  Here every trunk runs at the size the benchmark runs it, against its float32
+master module on stock convolutions (same weights, same inputs), at the bars of the small-size tests; the kernel every layer
+was routed to is logged (`vsr_last_route`) and the size-dependent ones are asserted to be among them.  One `VSR.forward` at
+540x960 in the fp16 configuration is compared with the fp32 configuration (exact float32 SR kernels, stock float32 trunks):
+PSNR and the 99th percentile of the absolute difference ("What's weak" 3)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from video_super_resolution_amd import _lib as L  # noqa: E402
+from video_super_resolution_amd.trunk_exec import FlowNet2Exec, HourglassExec, OSVOSExec  # noqa: E402
+
+H, W = 540, 960
+
+
+def _smooth_frames(n, h, w, seed):
+    """Blurred-noise scene translated by (2k, k) px per frame (bench.py's synthetic clip): flows are sane, edges exist."""
+    from scipy.ndimage import gaussian_filter
+    rs = np.random.RandomState(seed)
+    pad = 4 * n
+    base = gaussian_filter(rs.uniform(0, 255, size=(h + pad, w + 2 * pad, 3)).astype(np.float32), sigma=(3, 3, 0))
+    base = (base - base.min()) / (base.max() - base.min()) * 255.0
+    return np.stack([np.floor(base[k:k + h, 2 * k:2 * k + w]) for k in range(n)]).astype(np.float32)
+
+
+def _rel(a, ref):
+    return (a - ref).abs().max().item() / ref.abs().max().item()
+
+
+def _logged(fn):
+    L.ROUTES.calls = []
+    L.ROUTES.enabled = True
+    try:
+        out = fn()
+    finally:
+        L.ROUTES.enabled = False
+    hist = L.ROUTES.histogram()
+    for label, route in L.ROUTES.calls:
+        print(f"    {label:48s} -> {route}")
+    print("  routes:", ", ".join(f"{k} x{v}" for k, v in sorted(hist.items())))
+    return out, hist
+
+
+def test_hourglass_exec_at_4x540x960(gpu_vsr):
+    netg = gpu_vsr.DepthModule.model.netG
+    fr = torch.from_numpy(_smooth_frames(4, H, W, 1)).cuda()
+    with torch.no_grad():
+        ex = HourglassExec(netg)
+        got, hist = _logged(lambda: ex(fr))
+        ref = netg(fr.permute(0, 3, 1, 2))
+    err = _rel(got, ref)
+    print(f"[hourglass 4x{H}x{W} fp16 executor vs fp32 master] max {err:.3e} of range")
+    assert got.shape == ref.shape == (4, 1, H, W)
+    assert err < 1e-2                          # measured 2.0e-3
+    for k in ("stem7_rows", "conv1x1_stream<4>", "patch_r8<11,1>", "patch_r8<7,1>", "patch_r8<3,1>"):
+        assert k in hist, (k, hist)            # the size-dependent kernels the small tests never reach
+
+
+def test_flownet2_exec_at_2_pairs_512x960(gpu_vsr):
+    net = gpu_vsr.FlowModule.net
+    fr = _smooth_frames(3, 512, W, 2)
+    x = torch.from_numpy(np.stack([np.stack([fr[0], fr[1]]), np.stack([fr[1], fr[2]])])).permute(0, 4, 1, 2, 3).contiguous().cuda()  # [2,3,2,512,960]
+    with torch.no_grad():
+        ex = FlowNet2Exec(net)
+        got, hist = _logged(lambda: ex(x))
+        ref = net(x)
+    mx, mean = _rel(got, ref), (got - ref).abs().mean().item() / ref.abs().max().item()
+    print(f"[FlowNet2 2x512x{W} fp16 executor vs fp32 master] max {mx:.3e} mean {mean:.3e} of range")
+    assert got.shape == ref.shape == (2, 2, 512, W)
+    assert mx < 2e-2 and mean < 2e-3           # measured 1.2e-3 / 1.4e-4 (smooth scene; the random-pixel golden case: 2.1e-2)
+    assert "deconv4s2_patch" in hist and any(k.startswith("patch_r8<3") for k in hist), hist
+    assert any("splitk" in k for k in hist), hist
+
+
+def test_osvos_exec_at_2x540x960(gpu_vsr):
+    net = gpu_vsr.VOSModule.net
+    x = (torch.from_numpy(_smooth_frames(2, H, W, 3)).cuda() - gpu_vsr.VOSModule.meanval.to("cuda")).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        ex = OSVOSExec(net)
+        got, hist = _logged(lambda: ex(x))
+        ref = net(x)
+    err = _rel(got, ref)
+    print(f"[OSVOS 2x{H}x{W} fp16 executor vs fp32 master] max {err:.3e} of range")
+    assert got.shape == ref.shape
+    assert err < 1e-2                          # measured 1.4e-3
+    assert any(k.startswith("patch_r8<3,2>") or k.startswith("tile<") for k in hist), hist
+
+
+def test_whole_forward_at_540x960_fp16_vs_fp32_configuration(gpu_vsr, gpu_vsr_f16):
+    """Two recurrent frames of VSR.forward at the headline size: the throughput configuration against the exact one
+    (the reference cannot produce this size in test time; the exact configuration is pinned to the reference by
+    the golden-vector tests).  The discrete guidance planes (uint8 flow pictures, thresholded mask) flip a few pixels between
+    the two, as in the small end-to-end tests: image-quality bars."""
+    clip = torch.from_numpy(_smooth_frames(4, H, W, 4)).cuda()
+    outs = {}
+    for name, m in (("fp32", gpu_vsr), ("fp16", gpu_vsr_f16)):
+        est, res = None, []
+        for t in range(2):
+            est, loss = m(clip[t:t + 3], None, None, est, train=False)
+            assert loss is None and est.shape == (1, 4 * H, 4 * W, 3) and torch.isfinite(est).all()
+            res.append(est.clone())
+        outs[name] = res
+        torch.cuda.empty_cache()
+    for t in range(2):
+        a, b = outs["fp16"][t], outs["fp32"][t]
+        d = (a - b).abs()
+        mse = float((d * d).mean())
+        psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-20))
+        # percentiles on a strided sample (torch.quantile caps its input size)
+        p99 = float(torch.quantile(d.flatten()[::97].float(), 0.99))
+        span = float(b.max() - b.min())
+        print(f"[forward {H}x{W} frame {t}] fp16 vs fp32 configuration: PSNR(255) {psnr:.2f} dB, p99 |diff| {p99:.3f}, frame span {span:.1f}")
+        assert psnr > 70.0 and p99 < 0.5, (t, psnr, p99)      # measured 79.9 / 79.6 dB, p99 0.09 grey levels

@@ -48,6 +48,7 @@ def load() -> ctypes.CDLL:
                 "(there is no CPU fallback for the device path)")
         lib = ctypes.CDLL(LIB_PATH)
         lib.vsr_last_error.restype = ctypes.c_char_p
+        lib.vsr_last_route.restype = ctypes.c_char_p
         for fn in ("vsr_sr_utd_blob_bytes", "vsr_sr_utd_s2_blob_bytes", "vsr_sr_tail_s2_blob_bytes"):
             if hasattr(lib, fn):
                 getattr(lib, fn).restype = ctypes.c_size_t
@@ -160,3 +161,25 @@ class EventTimer:
 
 
 TIMER = EventTimer()
+
+
+class RouteLog:
+    """Which kernel every convolution launch was routed to (`vsr_last_route`), recorded while `enabled`: the launchers
+    pick by layer size, so the full-size parity tests log what actually ran (label -> route -> count)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.calls = []
+
+    def note(self, label: str):
+        if self.enabled:
+            self.calls.append((label, load().vsr_last_route().decode()))
+
+    def histogram(self):
+        h = {}
+        for _, r in self.calls:
+            h[r] = h.get(r, 0) + 1
+        return h
+
+
+ROUTES = RouteLog()

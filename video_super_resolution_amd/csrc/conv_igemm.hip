@@ -1578,6 +1578,7 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
         (unsigned long long)(PT_H + 18) * W * in_ld * 2 < (1ull << 31)) {
         p.ws = nullptr; p.splits = 1;
         const unsigned tiles = vsr::cdiv(H, PT_H) * vsr::cdiv(W, PT_W);
+        vsr::route("deconv4s2_patch");
         hipLaunchKernelGGL(k_deconv4s2_patch, dim3(tiles, N, cout_pad / 16), dim3(256), (PT_H + 2) * (PT_W + 2) * 64, vsr::S(stream), p);
         return vsr::launched("deconv4s2_nhwc_f16/patch");
     }
@@ -1596,6 +1597,7 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
     p.ws = splits > 1 ? (float*)splitk_ws : nullptr;
     p.splits = splits;
     const dim3 grid(gx, gy, 4 * splits);
+    vsr::route(splits > 1 ? "deconv4s2 gather<%d>+splitk%d" : "deconv4s2 gather<%d>", bn, splits);
     if (g_patch_mode == 8) {   // the first gather build (pixel operand through LDS): cross-check / A-B
         const int rc = bn == 64 ? launch_gather_lds<64, false>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather_lds<32, false>(p, grid, vsr::S(stream))
                                                                                                      : launch_gather_lds<16, false>(p, grid, vsr::S(stream));
@@ -1638,12 +1640,14 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
         const long long ntiles = (long long)N * tiles_x * tiles_y;
         if (ntiles < (1ll << 30)) {
             const unsigned grid1 = (unsigned)(ntiles < 256 * 2 ? ntiles : 256 * 2);   // two 4-wave workgroups resident per CU (registers)
+            vsr::route("stem7_rows");
             hipLaunchKernelGGL(k_stem7_rows, dim3(grid1), dim3(256), 0, vsr::S(stream), p, tiles_x, tiles_y, (int)ntiles);
             return vsr::launched("conv2d_stem_f16/rows");
         }
     }
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const dim3 grid(vsr::cdiv(M, BM), cout_pad / bn, 1);
+    vsr::route("gather<%d,stem>", bn);
     if (g_patch_mode == 8) {
         const int rc = bn == 64 ? launch_gather_lds<64, true>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather_lds<32, true>(p, grid, vsr::S(stream))
                                                                                                     : launch_gather_lds<16, true>(p, grid, vsr::S(stream));
@@ -1715,12 +1719,14 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         const int r8_mt = (cout_pad & 31) == 0 ? 2 : (cout_pad == 16 ? 1 : 0);
         if (!no_r8 && r8_mt && r8_lds <= 80 * 1024 && Ho >= 12 && (kh == 3 || kh == 5 || kh == 7 || kh == 11)) {
             hipStream_t st = vsr::S(stream);
+            vsr::route("patch_r8<%d,%d>", kh, r8_mt);
 #define VSR_R8(KH_) \
             if (kh == KH_) { if (r8_mt == 2) launch_patch_r8<KH_, 2>(p, N, st); else launch_patch_r8<KH_, 1>(p, N, st); }
             VSR_R8(3) VSR_R8(5) VSR_R8(7) VSR_R8(11)
 #undef VSR_R8
             return vsr::launched("conv2d_nhwc_f16/patch_r8");
         }
+        vsr::route((cout_pad & 63) == 0 ? "patch<4>" : (cout_pad & 31) == 0 ? "patch<2>" : (cout_pad == 16 && !no_rows && (kh == 3 || kh == 5 || kh == 7 || kh == 11)) ? "patch_rows<%d>" : "patch<1>", kh);
         const auto lds_for = [&](int mt) { const int o = 4 * 4 * 16 * 32 * mt; return patch_lds > o ? patch_lds : o; };   // patch, then the output tile
         if ((cout_pad & 63) == 0)
             hipLaunchKernelGGL(k_conv_patch<4>, dim3(tiles, N, cout_pad / 64), dim3(256), lds_for(4), vsr::S(stream), p);
@@ -1756,6 +1762,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         const int per_cu = (int)((160 * 1024) / k_lds) < 2 ? 1 : 2;   // 512-thread workgroups resident per CU
         const long long nblk = (M + 255) / 256;
         const unsigned grid = (unsigned)(nblk < 256LL * per_cu ? nblk : 256LL * per_cu);
+        vsr::route("conv1x1_stream<%d>", cin >> 5);
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), k_lds, vsr::S(stream), p);
         return vsr::launched("conv2d_nhwc_f16/1x1");
     }
@@ -1780,6 +1787,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     p.ws = splits > 1 ? (float*)splitk_ws : nullptr;
     p.splits = splits;
     const dim3 grid(gx, gy, splits);
+    vsr::route(splits > 1 ? "gather<%d>+splitk%d" : "gather<%d>", bn, splits);
     if (g_patch_mode == 8) {   // the first gather build (pixel operand through LDS): cross-check / A-B
         const int rc = bn == 64 ? launch_gather_lds<64, false>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather_lds<32, false>(p, grid, vsr::S(stream))
                                                                                                      : launch_gather_lds<16, false>(p, grid, vsr::S(stream));

@@ -575,6 +575,7 @@ extern "C" {
 
 int vsr_abi_version(void) { return VSR_ABI_VERSION; }
 const char* vsr_last_error(void) { return vsr::err_buf(); }
+const char* vsr_last_route(void) { return vsr::route_buf(); }
 
 int vsr_resample2d_f32(const float* img, const float* flow, float* out, int B, int C, int H, int W, int kernel_size,
                        int bilinear, vsr_stream_t stream) {

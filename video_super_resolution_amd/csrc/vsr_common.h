@@ -21,6 +21,18 @@ inline int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// Which kernel a launcher routed its last call to (thread-local; tests log it per layer: vsr_last_route()).
+inline char* route_buf() {
+    static thread_local char buf[96] = "";
+    return buf;
+}
+inline void route(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(route_buf(), 96, fmt, ap);
+    va_end(ap);
+}
+
 // Called right after a kernel launch: reports launch-configuration errors without synchronising.
 inline int launched(const char* what) {
     hipError_t e = hipGetLastError();

@@ -19,12 +19,14 @@ def clips_of_rank(n_clips: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_clips, world))
 
 
-def gather_frames(local: torch.Tensor, dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+def gather_frames(local: torch.Tensor, dst: int = 0, group=None, force_collective: bool = False) -> Optional[List[torch.Tensor]]:
     """Gather every rank's finished frames `[k_r, ...]` on `dst`; ranks may hold different k_r.
 
     Returns the list of per-rank tensors (trimmed to their true length) on `dst`, None elsewhere.
+    `force_collective`: issue the collectives even in a process group of ONE rank (a one-GPU box can then execute the RCCL
+    path -- communicator init, device-side gather buffers, stream ordering -- that otherwise first runs on an 8-GPU node).
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collective):
         return [local]
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -62,11 +64,11 @@ class ClipGather:
     in the last round (n_clips not a multiple of W) submits None.  `finish()` waits for all rounds and returns
     `[n_clips, K, ...]` in clip order on `dst`, None elsewhere.  Single process (no process group): pass-through."""
 
-    def __init__(self, n_clips: int, dst: int = 0, group=None):
-        """`dst` is a GLOBAL rank (what dist.gather takes); with a sub-group it is translated to the group rank for the
+    def __init__(self, n_clips: int, dst: int = 0, group=None, force_collective: bool = False):
+        """`force_collective`: see gather_frames.  `dst` is a GLOBAL rank (what dist.gather takes); with a sub-group it is translated to the group rank for the
         "am I the root" test."""
         self.n_clips, self.dst, self.group = n_clips, dst, group
-        self.dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.dist = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
         self.world = dist.get_world_size(group) if self.dist else 1
         self.rank = dist.get_rank(group) if self.dist else 0
         # group rank of the root; single process: whatever `dst` was asked for, this process is the root
@@ -102,7 +104,7 @@ class ClipGather:
         return torch.stack(out[:self.n_clips])
 
 
-def run_sharded_clips(forward_clip, n_clips: int, rank: int, world: int, dst: int = 0, group=None):
+def run_sharded_clips(forward_clip, n_clips: int, rank: int, world: int, dst: int = 0, group=None, force_collective: bool = False):
     """Control flow of config C4 (`bench.py --clips N`): clip i runs on rank i mod W, clips of a rank one after the other
     (frames inside a clip are serial), each finished clip gathered to `dst` while the next one runs.
     `forward_clip(clip_id) -> [K, ...]` produces the finished frames of one clip on this rank's device.
@@ -113,7 +115,7 @@ def run_sharded_clips(forward_clip, n_clips: int, rank: int, world: int, dst: in
                            f"world size ({world})")
     mine = clips_of_rank(n_clips, rank, world)
     rounds = -(-n_clips // world)
-    g = ClipGather(n_clips, dst=dst, group=group)
+    g = ClipGather(n_clips, dst=dst, group=group, force_collective=force_collective)
     like = None
     pending_none = 0
     for j in range(rounds):

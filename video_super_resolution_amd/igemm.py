@@ -123,6 +123,8 @@ class HConv:
             stride_x, self.pad_y, self.pad_x, out.shape[1], out.shape[2], self.oy[0], self.oy[1], self.ox[0], self.ox[1], self.act,
             L.cf(self.slope), L.dptr(_splitk_ws(x.device)), ctypes.c_size_t(_WS_BYTES), L.stream()), "conv2d_nhwc_f16")
         L.TIMER.stop(tok)
+        if L.ROUTES.enabled:
+            L.ROUTES.note(f"conv N{N} {H}x{W} c{self.cin_pad}->{self.cout} k{self.kh}x{self.kw} s{self.stride}")
         return out
 
 
@@ -192,6 +194,8 @@ class HConvStem:
                                              self.cout_pad, self.kh, self.kw, self.stride, self.pad, self.pad, self.act,
                                              L.cf(self.slope), L.stream()), "conv2d_stem_f16")
         L.TIMER.stop(tok)
+        if L.ROUTES.enabled:
+            L.ROUTES.note(f"conv N{N} {H}x{W} c4->{self.cout} k{self.kh}x{self.kw} s{self.stride} stem")
         return out
 
 
@@ -226,6 +230,8 @@ class HDeconv4s2:
             c0.cin_pad, self.cout, c0.cout_pad, c0.act, L.cf(c0.slope), L.dptr(_splitk_ws(x.device)), ctypes.c_size_t(_WS_BYTES),
             L.stream()), "deconv4s2_nhwc_f16")
         L.TIMER.stop(tok)
+        if L.ROUTES.enabled:
+            L.ROUTES.note(f"deconv4s2 N{N} {H}x{W} c{c0.cin_pad}->{self.cout}")
         return out
 
 
