@@ -45,8 +45,10 @@ def test_conv_matches_torch(case):
         ref = F.relu(ref)
     elif act == igemm.ACT_LEAKY:
         ref = F.leaky_relu(ref, 0.1)
+    from video_super_resolution_amd import _lib as L
     conv = igemm.HConv(w, b, stride=s, pad=p, act=act)
     out = conv(igemm.to_nhwc_half(x))
+    route = L.load().vsr_last_route().decode()
     got = igemm.to_nchw_float(out, cout)
     assert got.shape == ref.shape
     err = (got - ref).abs().max().item()
@@ -54,14 +56,13 @@ def test_conv_matches_torch(case):
     if out.shape[3] > cout:  # padding channels stay zero so the tensor can feed the next layer
         assert float(out[..., cout:].abs().max()) == 0.0
     # the first gather build (pixel operand through LDS, 64-channel tiles) runs the same MFMAs in the same order: equal bit for bit
-    from video_super_resolution_amd import _lib as L
     old = L.load().vsr_conv2d_tuning(8)
     try:
         out8 = conv(igemm.to_nhwc_half(x))
         torch.cuda.synchronize()
     finally:
         L.load().vsr_conv2d_tuning(old)
-    if cout <= 64 or (N * out.shape[1] * out.shape[2] + 127) // 128 * ((cout + 127) // 128) < 128:
+    if route.startswith("gather") and (cout <= 64 or (N * out.shape[1] * out.shape[2] + 127) // 128 * ((cout + 127) // 128) < 128):
         assert torch.equal(out8, out)   # (128-channel tiles may split K differently: a different fp32 summation order)
     else:
         assert (igemm.to_nchw_float(out8, cout) - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
@@ -73,6 +74,65 @@ def test_conv_matches_torch(case):
         finally:
             L.load().vsr_conv2d_tuning(old)
         assert (igemm.to_nchw_float(outm, cout) - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), mode
+
+
+TILE_CASES = [  # (N, Cin, H, W, Cout, k, stride, pad, act): the two-operand LDS-DMA tile kernel (csrc/conv_tile.hip)
+    (1, 256, 33, 47, 512, 3, 2, 1, igemm.ACT_LEAKY),   # stride 2, 128-channel tiles, ragged pixel tile, split-K
+    (2, 512, 34, 60, 512, 3, 1, 1, igemm.ACT_RELU),    # OSVOS's VGG 512 -> 512 at 34 x 60
+    (1, 473, 8, 16, 256, 3, 1, 1, igemm.ACT_LEAKY),    # odd channel count (15 chunks: the odd tail pair is zero-filled), one pixel tile
+    (2, 128, 131, 67, 128, 5, 2, 2, igemm.ACT_RELU),   # 5x5 stride 2
+    (1, 64, 92, 94, 256, 3, 2, 1, igemm.ACT_LEAKY),    # 64 -> 256
+    (4, 64, 128, 130, 128, 3, 2, 1, igemm.ACT_LEAKY),  # many workgroups (the XCD remap's padded grid)
+    (1, 96, 40, 52, 64, 3, 1, 1, igemm.ACT_NONE),      # 64-channel tile, three chunks
+    (1, 32, 67, 45, 70, 7, 1, 3, igemm.ACT_RELU),      # cout 70 -> padded 128: dead out-channel rows
+    (3, 160, 9, 7, 192, 1, 1, 0, igemm.ACT_RELU),      # 1x1, 192 out-channels (64-channel tiles), images smaller than a tile
+    (1, 1056, 16, 30, 512, 3, 1, 1, igemm.ACT_LEAKY),  # long K (297 pairs), split-K
+]
+
+
+@pytest.mark.parametrize("case", TILE_CASES)
+@pytest.mark.parametrize("mode", [2003])
+def test_tile_kernel_matches_torch(case, mode):
+    """csrc/conv_tile.hip against the stock operator on the same fp16-rounded operands, and -- with split-K off on both sides --
+    against the gather kernel k_conv_igemm_d bit for bit: same products, same K order per accumulator (fp32 accumulate in
+    MFMA 16x16x32 steps of one (tap, 32-channel chunk) pair each)."""
+    from video_super_resolution_amd import _lib as L
+    N, cin, H, W, cout, k, s, p, act = case
+    rs = np.random.RandomState(cin * 3 + cout + k)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.conv2d(x.float(), w, b, stride=s, padding=p)
+    ref = F.relu(ref) if act == igemm.ACT_RELU else (F.leaky_relu(ref, 0.1) if act == igemm.ACT_LEAKY else ref)
+    conv = igemm.HConv(w, b, stride=s, pad=p, act=act)
+    lib = L.load()
+    xs = igemm.to_nhwc_half(x)
+    lib.vsr_conv2d_tuning(mode)
+    try:
+        out = conv(xs).clone()
+        route = lib.vsr_last_route().decode()
+        assert route.startswith("tile<"), route
+        got = igemm.to_nchw_float(out, cout)
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item(), (route, err, ref.abs().max().item())
+        if out.shape[3] > cout:
+            assert float(out[..., cout:].abs().max()) == 0.0
+        assert torch.equal(conv(xs), out)                       # deterministic (split-K sums in a fixed order)
+        # no split-K on either side: the tile kernel against the gather kernel, bit for bit
+        lib.vsr_conv2d_tuning(5001)
+        lib.vsr_conv2d_tuning(1000)
+        t_ns = conv(xs).clone()
+        assert lib.vsr_last_route().decode().startswith("tile<") and "splitk" not in lib.vsr_last_route().decode()
+        lib.vsr_conv2d_tuning(2000)
+        lib.vsr_conv2d_tuning(1)                                # (mode 1: never the patch kernels)
+        g_ns = conv(xs).clone()
+        assert lib.vsr_last_route().decode().startswith("gather<"), lib.vsr_last_route().decode()
+        assert torch.equal(t_ns, g_ns)
+    finally:
+        lib.vsr_conv2d_tuning(0)
+        lib.vsr_conv2d_tuning(2001)
+        lib.vsr_conv2d_tuning(5000)
+        lib.vsr_conv2d_tuning(1128)
 
 
 @pytest.mark.parametrize("case", [  # (N, Cin, H, W, Cout, k, act): the LDS-patch builds, forced (the heuristic wants >= 8192 pixels)
@@ -142,7 +202,9 @@ def test_conv_writes_into_channel_slices():
 
 @pytest.mark.parametrize("shape", [(1, 64, 7, 9, 32), (2, 1026, 4, 5, 256), (1, 386, 16, 30, 64),
                                    # few out-channels on >= 8192 pixels: the four phases from one staged patch (k_deconv4s2_patch), ragged tiles
-                                   (2, 192, 83, 101, 16), (1, 32, 97, 130, 2), (2, 128, 70, 118, 32), (1, 64, 128, 64, 13)])
+                                   (2, 192, 83, 101, 16), (1, 32, 97, 130, 2), (2, 128, 70, 118, 32), (1, 64, 128, 64, 13),
+                                   # wide layers with >= 100 workgroups: the tile kernel, four phases in one launch (FlowNet decoders)
+                                   (2, 416, 64, 120, 64), (2, 800, 32, 60, 128), (1, 96, 61, 47, 192)])
 def test_transposed_conv_k4s2(shape):
     N, cin, H, W, cout = shape
     rs = np.random.RandomState(cin)
@@ -150,14 +212,26 @@ def test_transposed_conv_k4s2(shape):
     w = torch.from_numpy((rs.randn(cin, cout, 4, 4) / np.sqrt(cin * 4)).astype(np.float32)).cuda().half().float()
     b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
     ref = F.leaky_relu(F.conv_transpose2d(x.float(), w, b, stride=2, padding=1), 0.1)
+    from video_super_resolution_amd import _lib as L
     dc = igemm.HDeconv4s2(w, b, act=igemm.ACT_LEAKY)
     got = igemm.to_nchw_float(dc(igemm.to_nhwc_half(x)), cout)
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
     from video_super_resolution_amd import _lib as L
+    route = L.load().vsr_last_route().decode()
+    lib = L.load()
+    if cout > 32:    # the tile kernel on the same layer (forced: the heuristic takes only the long-K / many-workgroup ones), four phases in one launch
+        lib.vsr_conv2d_tuning(2003)
+        try:
+            gott = igemm.to_nchw_float(dc(igemm.to_nhwc_half(x)), cout)
+            assert "tile<" in lib.vsr_last_route().decode()
+        finally:
+            lib.vsr_conv2d_tuning(2001)
+        assert (gott - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
     old = L.load().vsr_conv2d_tuning(1)   # the same layer through the gather kernel (four phases in one launch)
     try:
         got1 = igemm.to_nchw_float(dc(igemm.to_nhwc_half(x)), cout)
+        assert "gather<" in L.load().vsr_last_route().decode()
     finally:
         L.load().vsr_conv2d_tuning(old)
     assert (got1 - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()

@@ -15,7 +15,8 @@ fr = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (4, h, w, 3)).ast
 fx, hx, ox = m._flow_exec.get(), m._depth_exec.get(), m._vos_exec.get()
 fn = {"flow": lambda: m.FlowModule.forward_pairs([(fr[0], fr[1]), (fr[1], fr[2])], fx),
       "depth": lambda: hx(fr), "vos": lambda: m.VOSModule(fr[0], fr[1], ox)}[which]
-if os.environ.get('VSR_TUNING'): L.load().vsr_conv2d_tuning(int(os.environ['VSR_TUNING']))
+for _t in os.environ.get('VSR_TUNING', '').split(','):
+    if _t: L.load().vsr_conv2d_tuning(int(_t))
 for _ in range(2): fn()
 torch.cuda.synchronize()
 L.TIMER.enabled = True; L.TIMER.reset()

@@ -6,6 +6,9 @@ import numpy as np, torch
 from video_super_resolution_amd import VSR
 from video_super_resolution_amd.weights import fill_module_
 torch.set_grad_enabled(False)
+from video_super_resolution_amd import _lib as L
+for _t in os.environ.get('VSR_TUNING', '').split(','):
+    if _t: L.load().vsr_conv2d_tuning(int(_t))
 which = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 h, w = 540, 960
 m = fill_module_(VSR().eval(), 0).cuda()
@@ -20,3 +23,7 @@ e0.record()
 for _ in range(reps): fn()
 e1.record(); torch.cuda.synchronize()
 print(f"{which}: {e0.elapsed_time(e1)/reps:.2f} ms per call")
+if os.environ.get("VSR_ROUTES_OUT"):   # the (layer label, kernel route) list of one more call, in launch order
+    L.ROUTES.calls = []; L.ROUTES.enabled = True; fn(); torch.cuda.synchronize(); L.ROUTES.enabled = False
+    with open(os.environ["VSR_ROUTES_OUT"], "w") as f:
+        for lab, route in L.ROUTES.calls: f.write(f"{lab}\t{route}\n")

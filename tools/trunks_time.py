@@ -5,6 +5,9 @@ import numpy as np, torch
 from video_super_resolution_amd import VSR
 from video_super_resolution_amd.weights import fill_module_
 torch.set_grad_enabled(False)
+from video_super_resolution_amd import _lib as L
+for _t in os.environ.get('VSR_TUNING', '').split(','):
+    if _t: L.load().vsr_conv2d_tuning(int(_t))
 h, w = 540, 960
 m = fill_module_(VSR().eval(), 0).cuda()
 fr = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (4, h, w, 3)).astype(np.float32)).cuda()

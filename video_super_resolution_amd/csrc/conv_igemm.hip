@@ -12,42 +12,20 @@
 // Epilogue: + bias (fp32), none / ReLU / LeakyReLU, fp16 store into a channel slice [out_coff, out_coff+Cout) of a
 // tensor with out_ld channels (concatenations are written in place), with an output pixel stride/offset so the four
 // phases of a k4 s2 transposed convolution are four ordinary 2x2-tap launches.
-#include "vsr_common.h"
+#include "conv_common.h"
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-constexpr int BM = 128;  // output pixels per workgroup
-
-struct ConvP {
-    const _Float16* in;
-    const _Float16* wpk;   // [tap][cin/32][cout_pad][32]
-    const float* bias;     // [cout_pad] or null
-    _Float16* out;
-    int in_ld, in_coff, out_ld, out_coff;
-    int N, H, W, cin, Ho, Wo, cout, cout_pad;
-    int kh, kw, stride, pad_y, pad_x;   // stride: rows (and columns unless stride_x differs)
-    int stride_x;
-    int outH, outW, oy_mul, oy_off, ox_mul, ox_off;
-    int act;
-    float slope;
-    float* ws;      // split-K partial sums [splits][phases][M][cout_pad] fp32, or null
-    int splits;
-    // the four phases of a k4 s2 transposed convolution in ONE launch (blockIdx.z = split * 4 + phase): per-phase packed
-    // weights, padding and output offset; nphase <= 1: the scalar fields above
-    int nphase;
-    const _Float16* wpk_ph[4];
-    int pad_y_ph[4], pad_x_ph[4], oy_off_ph[4], ox_off_ph[4];
-};
+using vsrc::h8;
+using vsrc::h4;
+using vsrc::f4;
+using vsrc::BM;
+using vsrc::ConvP;
+using vsrc::sw_off;
 
 struct C0 { static constexpr int value = 0; };
 struct C1 { static constexpr int value = 1; };
 struct C2 { static constexpr int value = 2; };
-
-__device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
 // Epilogue of the convolution kernels: bias + activation + fp16, then out through LDS so that a pixel's 16 MT channels leave
 // as whole 16-byte pieces from adjacent lanes (a full 128-byte line per pixel at MT = 4).  Straight from the MFMA
@@ -1447,15 +1425,78 @@ static int launch_gather_lds(const ConvP& p, dim3 grid, hipStream_t stream) {
 
 static int g_splitk_fill = 128;   // split K when a launch has fewer workgroups than this, into ~2x as many (tools/probe_splitk.py; 256 until the
                                    // round-2 rebuild made a K step cheap: FlowNet2 3.7 -> 3.45 ms, hourglass 5.03 -> 4.88, OSVOS 1.25 -> 1.29)
+static int g_tile_mode = 1;   // conv_tile.hip (two-operand LDS-DMA tile): 0 never, 1 (default) where tile_choice says it wins over the gather kernel, 3 every layer it can run, the patch kernels' too (tests) (vsr_conv2d_tuning(2000 + n))
+static int g_tile_bn = 0, g_tile_splits = 0;   // experiments: force the tile width (64 / 128) / the split count (vsr_conv2d_tuning(4000 + bn), (5000 + n)); 0 = heuristic
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
 
 // byte range a gather kernel's buffer resource and its 32-bit offsets cover (0xFFFFFFFF marks "outside the image")
 static constexpr unsigned long long kGatherLimit = 0xFFFFFFFFull;
 
+// The tile kernel (conv_tile.hip) for a layer the launchers prepared in `p` (everything but splits / ws): picks the tile width,
+// splits K when the launch cannot fill two workgroups per CU, launches it and the split-K finish.  nph = 4: the four phases of a
+// k4 s2 transposed convolution in one launch.
+// Where the tile kernel (conv_tile.hip) replaces the gather kernel -- from per-layer device times INSIDE the three trunks at the
+// benchmark size, both kernels on the same layers in one process (tools/trunk_layers.sh; profiles/r03_tile_vs_gather_layers.txt):
+//   * 128-channel tiles with >= 384 workgroups (two per CU cover each other's DMA waits), no split-K: FlowNet's 5x5 / 3x3
+//     stride-2 layers at 1/4 and 1/8 resolution, OSVOS's 512-channel VGG stage at 68 x 120: -10 ... -21 %;
+//   * 64-out-channel stride-2 layers on >= 1000 pixel tiles (FlowNetS conv1 / conv2 at 512 x 960): -8 ... -10 %;
+//   * long-K layers on few pixels (50-200 workgroups of 128 channels, >= 64 K steps: FlowNet's 1056 -> 256 transposed
+//     convolution at 16 x 30, 800 -> 256 at 32 x 60) split to ~320 workgroups: -15 ... -25 %;
+//   * everything else stays: 64-channel tiles LOSE to the gather kernel (32 x 60 512 -> 512: 42 -> 54 us; the tile kernel moves
+//     32 KB through LDS per 2.1 MFLOP step and measures ~55 GB/s per CU of L2 -> LDS fill, 3/4 of what LDS-DMA gathers reach
+//     on this chip: it is fill-bound, and narrower tiles only lower its FLOP per byte), the LDS-patch kernels keep the
+//     stride-1 k x k layers (they stage the input once per 32-channel chunk for all k x k taps).
+// -> 0: not the tile kernel; 64 / 128: tile width, *splits set.
+static int tile_choice(const ConvP& p, long long M, int nk_all, int nph, int* splits) {
+    *splits = 1;
+    const long long gx = vsr::cdiv(M, BM);
+    const bool can128 = (p.cout_pad & 127) == 0;
+    const long long nwg128 = can128 ? gx * (p.cout_pad / 128) * nph : 0;
+    if (nwg128 >= 384) return 128;
+    if (p.cout_pad == 64 && p.stride == 2 && gx * nph >= 1000) return 64;
+    if (nwg128 >= 50 && nwg128 < 200 && nk_all >= 64) {
+        *splits = (int)((320 + nwg128 - 1) / nwg128);
+        return 128;
+    }
+    return 0;
+}
+
+static int run_tile(ConvP& p, long long M, int nk_all, int nph, void* splitk_ws, size_t splitk_ws_bytes, hipStream_t st, const char* what) {
+    const bool can128 = (p.cout_pad & 127) == 0;
+    int splits = 1;
+    int bn = tile_choice(p, M, nk_all, nph, &splits);
+    if (bn == 0) {   // (mode 3 / experiments: a layer the heuristic leaves to the other kernels)
+        const long long nwg = vsr::cdiv(M, BM) * (long long)(p.cout_pad / (can128 ? 128 : 64)) * nph;
+        bn = can128 ? 128 : 64;
+        if (nwg < 200) splits = (int)((320 + nwg - 1) / nwg);
+    }
+    if (g_tile_bn == 64 || (g_tile_bn == 128 && can128)) bn = g_tile_bn;   // (experiments)
+    if (g_tile_splits > 0) splits = g_tile_splits;
+    if (splits > nk_all / 4) splits = nk_all / 4;
+    if (splits > 32) splits = 32;
+    if (!splitk_ws) splits = 1;
+    while (splits > 1 && (size_t)splits * nph * M * p.cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
+    if (splits < 1) splits = 1;
+    p.ws = splits > 1 ? (float*)splitk_ws : nullptr;
+    p.splits = splits;
+    vsr::route(splits > 1 ? "%stile<%d>+splitk%d" : "%stile<%d>", nph > 1 ? "deconv4s2 " : "", bn, splits);
+    int rc = vsrc::launch_conv_tile(p, bn, st);
+    if (rc) return rc;
+    if (splits > 1) {
+        rc = vsr::launched(what);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_splitk_finish, dim3(vsr::cdiv(M * (p.cout_pad >> 2), 256), nph), dim3(256), 0, st, p);
+    }
+    return vsr::launched(what);
+}
+
 extern "C" {
 
 int vsr_conv2d_tuning(int patch_mode) {
     const int old = g_patch_mode;
+    if (patch_mode >= 5000) { g_tile_splits = patch_mode - 5000; return old; }
+    if (patch_mode >= 4000) { g_tile_bn = patch_mode - 4000; return old; }
+    if (patch_mode >= 2000) { g_tile_mode = patch_mode - 2000; return old; }
     if (patch_mode >= 1000) {   // 1000 + n: split-K fill threshold n (experiments; default 128)
         g_splitk_fill = patch_mode - 1000;
         return old;
@@ -1582,6 +1623,10 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
         hipLaunchKernelGGL(k_deconv4s2_patch, dim3(tiles, N, cout_pad / 16), dim3(256), (PT_H + 2) * (PT_W + 2) * 64, vsr::S(stream), p);
         return vsr::launched("deconv4s2_nhwc_f16/patch");
     }
+    int ts_ = 1;
+    if (g_tile_mode >= 1 && g_patch_mode != 8 && g_patch_mode != 1 && (cout_pad & 63) == 0 &&
+        (g_tile_mode >= 3 || tile_choice(p, M, (4 * (cin >> 5) + 1) >> 1, 4, &ts_) != 0))
+        return run_tile(p, M, (4 * (cin >> 5) + 1) >> 1, 4, splitk_ws, splitk_ws_bytes, vsr::S(stream), "deconv4s2_nhwc_f16/tile");
     const unsigned gx = vsr::cdiv(M, BM);
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const unsigned gy = cout_pad / bn;
@@ -1708,6 +1753,13 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     const bool patch_pays = (long long)Ho * Wo >= 8192 && kh * kw >= 9 && ((cout_pad == 16 && (cin >> 5) <= 8) || cout_pad >= 32);
     const bool force = g_patch_mode == 2 || g_patch_mode == 6 || g_patch_mode == 7;
     const bool no_r8 = g_patch_mode == 3 || g_patch_mode == 5 || g_patch_mode == 6 || g_patch_mode == 7, no_rows = g_patch_mode == 3 || g_patch_mode == 7;
+    // the tile kernel (conv_tile.hip) where it wins (tile_choice); mode 3: every layer it can run, also the patch kernels' (tests)
+    int ts_ = 1;
+    const int nk_all_ = (kh * kw * (cin >> 5) + 1) >> 1;
+    const bool tile_can = g_tile_mode >= 1 && g_patch_mode != 8 && g_patch_mode != 1 && (cout_pad & 63) == 0;
+    const bool tile_ok = tile_can && (g_tile_mode >= 3 || (tile_choice(p, M, nk_all_, 1, &ts_) != 0 && !(kh == 1 && kw == 1 && M >= 65536)));
+    if (tile_can && g_tile_mode >= 3 && !force)
+        return run_tile(p, M, nk_all_, 1, splitk_ws, splitk_ws_bytes, vsr::S(stream), "conv2d_nhwc_f16/tile");
     if (patch_legal && g_patch_mode != 1 && (patch_pays || force)) {
         p.ws = nullptr;
         p.splits = 1;
@@ -1766,6 +1818,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), k_lds, vsr::S(stream), p);
         return vsr::launched("conv2d_nhwc_f16/1x1");
     }
+    if (tile_ok) return run_tile(p, M, nk_all_, 1, splitk_ws, splitk_ws_bytes, vsr::S(stream), "conv2d_nhwc_f16/tile");
     const unsigned gx = vsr::cdiv(M, BM);
     // widest tile the padded count fills; 128 out-channels per workgroup (half the pixel-operand traffic per FLOP: these
     // layers run at the L2's bandwidth, 43 FLOP per byte with the 128 x 64 tile) when that still leaves 128 workgroups
