@@ -393,6 +393,42 @@ int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, in
 int vsr_conv2d_tuning(int patch_mode);
 
 /* ------------------------------------------------------------------------------------------
+ * Train step: forward AND backward kernels of the SR net's operators for the reference's one
+ * differentiable call (network/video_super_resolution.py:64 at main.py:205-213).  The reference leaves these to ATen /
+ * cuDNN autograd (SRProjectionModule.py:96-150, blocks.py:7-74); here torch.autograd only walks the graph (sr_train.py)
+ * and every value and gradient comes from these kernels.  float32 NCHW; weights as [ky][kx][cin][cout] ("kkio").
+ * Partial sums are combined in a fixed order: gradients are deterministic.
+ * ------------------------------------------------------------------------------------------ */
+
+/* nn.Conv2d forward (blocks.py:16-22); also the input gradient of a transposed convolution (weight roles swapped). */
+int vsr_train_conv2d_f32(const float* in, const float* w_kkio, const float* bias_or_null, float* out, int N, int Cin, int H, int W, int Cout,
+                         int Ho, int Wo, int K, int stride, int pad, vsr_stream_t stream);
+/* nn.ConvTranspose2d forward (blocks.py:34); also the input gradient of a convolution. */
+int vsr_train_deconv2d_f32(const float* in, const float* w_kkio, const float* bias_or_null, float* out, int N, int Cin, int H, int W, int Cout,
+                           int Ho, int Wo, int K, int stride, int pad, vsr_stream_t stream);
+/* Weight gradient: dw[a][b][ky][kx] = sum_{n,oy,ox} small[n,a,oy,ox] * big[n,b,stride*oy-pad+ky,stride*ox-pad+kx].
+ * Conv2d: (small, big) = (grad_out, input) -> [cout][cin][k][k]; ConvTranspose2d: (input, grad_out) -> [cin][cout][k][k].
+ * ws: vsr_train_corr_dw_ws_floats(...) floats of scratch. */
+size_t vsr_train_corr_dw_ws_floats(int N, int A, int oh, int Bc, int K);
+int vsr_train_corr_dw_f32(const float* small, const float* big, float* dw, float* ws, int N, int A, int oh, int ow, int Bc, int BH, int BW, int K,
+                          int stride, int pad, vsr_stream_t stream);
+/* Bias gradient db[c] = sum_{n,p} g[n,c,p]; ws: N * 16 * C floats. */
+int vsr_train_chan_sum_f32(const float* g, float* db, float* ws, int N, int C, size_t P, vsr_stream_t stream);
+/* nn.PReLU(num_parameters=1) (blocks.py:64-71) forward / backward (gv, and dslope[0] = sum g * min(v, 0)). */
+int vsr_train_prelu_f32(const float* v, float slope, float* y, size_t n, vsr_stream_t stream);
+size_t vsr_train_prelu_bwd_ws_floats(size_t n);
+int vsr_train_prelu_bwd_f32(const float* v, const float* g, float slope, float* gv, float* dslope, float* ws, size_t n, vsr_stream_t stream);
+/* y = (a + b) * scale[c] + shift[c]: MeanShift (blocks.py:46-55) and the skip add + add_mean (SRProjectionModule.py:142-143). */
+int vsr_train_affine_ch_f32(const float* a, const float* b_or_null, const float* scale, const float* shift_or_null, float* y, int N, int C, size_t P,
+                            vsr_stream_t stream);
+/* F.interpolate(scale_factor=S, mode='bilinear', align_corners=False) (SRProjectionModule.py:136) on NC planes. */
+int vsr_train_bilinear_up_f32(const float* x, float* y, int NC, int h, int w, int scale, vsr_stream_t stream);
+/* Fusion MLP backward (SRProjectionModule.py:126-131,146): go [Q], gh / rh [hidden][Q], dv [nplanes][Q], Q = 3 * pixels;
+ * the forward is vsr_sr_fc_fuse_f32. */
+int vsr_train_fc_bwd_f32(const float* prefc, const float* g, const float* w1, const float* b1, const float* w2, const float* b2, int nplanes,
+                         int hidden, float* go, float* gh, float* rh, float* dv, size_t Q, vsr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Clip I/O: the data formats either side of the path.
  * ------------------------------------------------------------------------------------------ */
 

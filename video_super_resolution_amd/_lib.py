@@ -49,7 +49,8 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(LIB_PATH)
         lib.vsr_last_error.restype = ctypes.c_char_p
         lib.vsr_last_route.restype = ctypes.c_char_p
-        for fn in ("vsr_sr_utd_blob_bytes", "vsr_sr_utd_s2_blob_bytes", "vsr_sr_tail_s2_blob_bytes"):
+        for fn in ("vsr_sr_utd_blob_bytes", "vsr_sr_utd_s2_blob_bytes", "vsr_sr_tail_s2_blob_bytes", "vsr_train_corr_dw_ws_floats",
+                   "vsr_train_prelu_bwd_ws_floats"):
             if hasattr(lib, fn):
                 getattr(lib, fn).restype = ctypes.c_size_t
         if lib.vsr_abi_version() != 1:

@@ -291,25 +291,28 @@ class SRProjectionModule(nn.Module):
     def forward(self, x: torch.Tensor, taps: Optional[dict] = None, decimate: bool = False, shared: Optional[dict] = None) -> torch.Tensor:
         """`shared`: see _forward_f16 (planes two calls have in common are evaluated once).
 
-        Inference (eval mode, or any call under no_grad): the hand-written HIP kernels, `_forward_kernels`.
+        Inference (eval mode, or any call under no_grad): the hand-written HIP inference kernels, `_forward_kernels`.
         A call in TRAINING mode with autograd enabled -- the one differentiable call of the reference's train step,
-        video_super_resolution.py:64 via main.py:205-210 -- is evaluated by `_forward_autograd` on stock PyTorch-ROCm
-        operators so that `loss.backward()` reaches the SR net's parameters (SURVEY.md 8(b) "autograd": backward kernels are
-        not built).  The benchmark and every parity test of the kernels run the first path."""
+        video_super_resolution.py:64 via main.py:205-210 -- is evaluated by `sr_train.forward_train`: float32, every value and
+        every gradient from the kernels of csrc/sr_train.hip (torch.autograd only walks the graph), so that `loss.backward()`
+        reaches the SR net's parameters.  The benchmark and every parity test of the inference kernels run the first path."""
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
             if not getattr(self, "_warned_autograd", False):   # modules are born in training mode: say so once (ADVICE r2)
                 import warnings
                 warnings.warn("SRProjectionModule: training mode with autograd enabled -> this call runs the differentiable "
-                              "stock-operator path in float32 (the train step of main.py:205-210), not the HIP kernels; "
-                              "call .eval() or wrap the call in torch.no_grad() for inference", stacklevel=2)
+                              "float32 train-step kernels (csrc/sr_train.hip; the train step of main.py:205-210), not the inference "
+                              "kernels; call .eval() or wrap the call in torch.no_grad() for inference", stacklevel=2)
                 self._warned_autograd = True
-            out = self._forward_autograd(x)
+            from .sr_train import forward_train
+            out = forward_train(self, x)
             S = self.upscale_factor
             return out[..., ::S, ::S] if decimate else out
         return self._forward_kernels(x, taps, decimate, shared)
 
     def _forward_autograd(self, x: torch.Tensor) -> torch.Tensor:
-        """SRProjectionModule.forward (SRProjectionModule.py:133-147) with the zero-fill FeedbackBlock (:44-90, D1) on stock
+        """CROSS-CHECK ONLY (tests): the same graph on stock differentiable operators -- `forward` never calls it; the train
+        step runs `sr_train.forward_train` on the HIP kernels.
+        SRProjectionModule.forward (SRProjectionModule.py:133-147) with the zero-fill FeedbackBlock (:44-90, D1) on stock
         differentiable operators, device-agnostic, float32.  Group `idx` sees only slice `idx` of its 1x1 "tran" conv, fed by
         the previous group's tensor (the reference's slice-copy loop keeps the last copy); group 0 sees zeros."""
         import torch.nn.functional as F
