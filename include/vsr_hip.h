@@ -102,6 +102,11 @@ int vsr_flownet_prepare_pairs(const float* frames, int F, int h, int w, const in
                               int W, float* partial_ws, float* x, void* x6h, void* both4, vsr_stream_t stream);
 int vsr_flownet_up_warp_concat16_f16(const float* x6, const void* flow2_nhwc, int ld, int bilinear, float mul, float inv_div, void* out16,
                                      int B, int H, int W, vsr_stream_t stream);
+/* Build of the warp inside vsr_flownet_up_warp_concat16_f16: 1 (default) the thread-per-pixel gather build (lanes along x, the 2x2
+ * neighbourhood served by L1 / L2); 0 an LDS-staged source tile with a halo of 8 pixels, the right column of each lane's 2x2
+ * neighbourhood handed over from the next lane by DPP where the flow is smooth, global fallback beyond the halo (BASELINE.json's
+ * north_star wording; measured 1.0 - 1.9 x slower).  Bit-identical (resample2d_kernel.cu:16-72's arithmetic). */
+int vsr_flownet_warp_variant(int variant);
 int vsr_flownet_fusion_input_f16(const float* x6, const void* flow_sd2, int ld_sd, const void* flow_s22, int ld_s2, float div_flow,
                                  void* out32, int B, int H, int W, vsr_stream_t stream);
 

@@ -200,3 +200,37 @@ def test_plane_assembly_matches_the_reference_expressions(first_call):
         ref = torch.cat((frames, fl, depth, masked), 0)
         got = VSR._assemble(d, pics, z, est, mask)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 36, 200), (2, 132, 76), (1, 512, 960)])
+@pytest.mark.parametrize("bilinear", [1, 0])
+@pytest.mark.parametrize("sigma", [0.05, 0.6, 8.0])
+def test_lds_staged_warp_equals_the_gather_build(shape, bilinear, sigma):
+    """The warp of vsr_flownet_up_warp_concat16_f16 as BASELINE.json's north_star words it (LDS-staged source tile with a halo of
+    8 pixels, the right column of each lane's 2x2 neighbourhood handed over from the next lane by DPP, global fallback beyond the
+    halo) against the thread-per-pixel gather build: the same values into the same arithmetic (resample2d_kernel.cu:16-72), bit for
+    bit -- flows of a fraction of a pixel (every lane takes its neighbour's column), of ~12 pixels (mixed) and of ~160 pixels
+    (fallback, clamping at the borders), sizes that are not multiples of the 4 x 64 tile."""
+    from video_super_resolution_amd import _lib as L
+    B, H, W = shape
+    rs = np.random.RandomState(H + W + bilinear)
+    x = torch.from_numpy(rs.rand(B, 6, H, W).astype(np.float32)).cuda()
+    f2 = torch.zeros((B, H // 4, W // 4, 32), dtype=torch.float16, device="cuda")
+    f2[..., :2] = torch.from_numpy((rs.randn(B, H // 4, W // 4, 2) * sigma).astype(np.float16)).cuda()
+    if sigma > 1:
+        f2[0, 0, 0, 0] = float("nan")      # a NaN flow: float -> int saturates / NaN -> 0, the clamps keep the index in range
+        f2[0, 1, 1, 1] = 60000.0
+    lib = L.load()
+    outs = []
+    try:
+        for variant in (1, 0):
+            L.check(lib.vsr_flownet_warp_variant(variant))
+            out16 = torch.full((B, H, W, 16), 7.0, dtype=torch.float16, device="cuda")
+            L.check(lib.vsr_flownet_up_warp_concat16_f16(L.dptr(x), L.dptr(f2, torch.float16), 32, bilinear, L.cf(20.0), L.cf(1 / 20.0),
+                                                         L.dptr(out16, torch.float16), B, H, W, L.stream()))
+            outs.append(out16)
+    finally:
+        lib.vsr_flownet_warp_variant(1)   # (the default: the gather build is the faster one, DESIGN.md 5.4)
+    a, b = outs
+    same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+    assert bool(same.all()), int((~same).sum())

@@ -467,6 +467,85 @@ __global__ void __launch_bounds__(kBlock) k_flow_up_warp_concat16(const float* _
     }
 }
 
+// The same pass as BASELINE.json's north_star words it: "the bilinear flow warp as coalesced HBM reads with LDS-staged input tiles
+// and wavefront shuffles for the 2x2 neighbourhood".  A workgroup owns 4 rows x 64 columns of output (wave = one row, lanes along
+// x) and stages frame b's three planes over the tile plus a halo of WT_R pixels in LDS with coalesced row reads.  A lane reads
+// only the LEFT column of its 2x2 neighbourhood, (yT, xL) and (yB, xL), from the tile; the RIGHT column is lane + 1's left column
+// whenever that lane's (yT, yB, xL) equal this lane's (yT, yB, xR) -- a smooth flow: nearly always -- and comes over with one DPP
+// move per value (`row_shl:1`; the last lane of each 16-lane row and lanes whose neighbour samples elsewhere read it themselves).
+// A sample outside the staged tile (displacement beyond the halo) falls back to the global load of the gather build.  Same values
+// into the same arithmetic: bit-identical to k_flow_up_warp_concat16 (tests/test_gpu_flow_ops.py).
+constexpr int WT_Y = 4, WT_X = 64, WT_R = 8, WP_H = WT_Y + 2 * WT_R, WP_W = WT_X + 2 * WT_R;
+__device__ __forceinline__ float dpp_next_lane(float v) {   // lane i <- lane i + 1 inside each row of 16 lanes (lane 15: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int dpp_next_lane(int v) { return __builtin_amdgcn_mov_dpp(v, 0x101, 0xF, 0xF, true); }
+
+__global__ void __launch_bounds__(kBlock) k_flow_up_warp_concat16_lds(const float* __restrict__ x6, const _Float16* __restrict__ flow2, int ld,
+                                                                      int bilinear, float mul, float inv_div, _Float16* __restrict__ out16,
+                                                                      int H, int W) {
+    __shared__ float tile[3][WP_H][WP_W + 1];
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * WT_Y, x0 = blockIdx.x * WT_X;
+    const size_t hw = (size_t)H * W;
+    const int h4 = H / 4, w4 = W / 4;
+    const float* xb = x6 + (size_t)b * 6 * hw;
+    const _Float16* fl = flow2 + (size_t)b * h4 * w4 * ld;
+    const int tid = threadIdx.x;
+    // ---- stage frame b's planes over rows y0 - R .. y0 + 3 + R, columns x0 - R .. x0 + 63 + R (in-image part; the sample indices
+    //      are clamped to the image before the look-up, so positions outside it are never read)
+    for (int i = tid; i < 3 * WP_H * WP_W; i += kBlock) {
+        const int c = i / (WP_H * WP_W), rem = i - c * (WP_H * WP_W);
+        const int r = rem / WP_W, col = rem - r * WP_W;
+        const int gy = y0 - WT_R + r, gx = x0 - WT_R + col;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) tile[c][r][col] = xb[(size_t)(3 + c) * hw + (size_t)gy * W + gx];
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int yy = y0 + (tid >> 6), xx = x0 + lane;
+    const bool live = yy < H && xx < W;
+    const int y = min(yy, H - 1), x = min(xx, W - 1);   // (lanes past the image compute on a clamped pixel: every lane runs the DPP moves)
+    float u, v;
+    flow_up4(fl, ld, h4, w4, y, x, bilinear, u, v);
+    const float dx = u * mul, dy = v * mul;
+    const Bilerp s = bilerp_setup(x, y, dx, dy, H, W);
+    const int tT = s.yT - (y0 - WT_R), tB = s.yB - (y0 - WT_R), tL = s.xL - (x0 - WT_R), tR = s.xR - (x0 - WT_R);
+    const bool rows_in = (unsigned)tT < (unsigned)WP_H && (unsigned)tB < (unsigned)WP_H;
+    const bool left_in = rows_in && (unsigned)tL < (unsigned)WP_W, right_in = rows_in && (unsigned)tR < (unsigned)WP_W;
+    // the neighbour's left column is my right column?
+    const int nT = dpp_next_lane(s.yT), nB = dpp_next_lane(s.yB), nL = dpp_next_lane(s.xL);
+    const bool from_next = (lane & 15) != 15 && nT == s.yT && nB == s.yB && nL == s.xR;
+    const size_t p = (size_t)y * W + x;
+    float acc = 0.0f, a[3], bb[3], wv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* plane = xb + (size_t)(3 + c) * hw;
+        const float vTL = left_in ? tile[c][tT][tL] : plane[(size_t)s.yT * W + s.xL];
+        const float vBL = left_in ? tile[c][tB][tL] : plane[(size_t)s.yB * W + s.xL];
+        const float sTR = dpp_next_lane(vTL), sBR = dpp_next_lane(vBL);
+        float vTR, vBR;
+        if (from_next) { vTR = sTR; vBR = sBR; }
+        else if (right_in) { vTR = tile[c][tT][tR]; vBR = tile[c][tB][tR]; }
+        else { vTR = plane[(size_t)s.yT * W + s.xR]; vBR = plane[(size_t)s.yB * W + s.xR]; }
+        float wsum = 0.0f;   // bilerp_sample's order and roundings (resample2d_kernel.cu:56-59)
+        wsum += (float)(s.w00 * (double)vTL);
+        wsum += (float)(s.w01 * (double)vTR);
+        wsum += (float)(s.w10 * (double)vBL);
+        wsum += s.w11 * vBR;
+        wv[c] = wsum;
+        a[c] = xb[(size_t)c * hw + p];
+        bb[c] = (unsigned)(tid >> 6) + WT_R < (unsigned)WP_H ? tile[c][(tid >> 6) + WT_R][lane + WT_R] : 0.0f;   // frame b at (y, x): staged
+        const float d = a[c] - wv[c];
+        acc += d * d;
+    }
+    if (!live) return;
+    _Float16* o = out16 + ((size_t)b * hw + p) * 16;
+    *reinterpret_cast<h8g*>(o) = h8g{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)bb[0], (_Float16)bb[1], (_Float16)bb[2],
+                                     (_Float16)wv[0], (_Float16)wv[1]};
+    *reinterpret_cast<h8g*>(o + 8) = h8g{(_Float16)wv[2], (_Float16)(dx * inv_div), (_Float16)(dy * inv_div), (_Float16)sqrtf(acc),
+                                         (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+}
+
 // models.py:106-125 in one pass: the two nearest-upsampled flows (FlowNetS #2 x div_flow, FlowNetSD / div_flow), their norms,
 // the two brightness errors of the warps, concatenated with frame a -- straight into the NHWC half map [B,H,W,32] the fusion
 // network reads (11 live channels: img0 3, flow_sd 2, flow_s2 2, |flow_sd|, |flow_s2|, diff_sd, diff_s2).
@@ -569,9 +648,21 @@ inline unsigned grid_for(size_t n) {
     return (unsigned)(g < 2048 ? (g ? g : 1) : 2048);  // cap + grid-stride (guide 6, Guideline 11)
 }
 
+// 1 (default): thread-per-pixel gathers served by L1 / L2; 0: the LDS-staged tile + DPP hand-over of north_star's wording.
+// Measured at 2 x 512 x 960, rounds interleaved (tools/warp_rates.py): smooth flow 16.6 us (gathers) vs 31.3 us (LDS-staged), ~2 px
+// 19.1 vs 29.9, ~20 px 39.5 vs 39.5, ~160 px 50.6 vs 67.1 -- a 4 x 64 tile with a halo of 8 stages 6.25 x its own pixels, while the
+// gathers' neighbour re-reads hit L1 (FETCH = 2 x the planes read once, profiles/r02_frame_hbm_table.txt): the gather build stays.
+static int g_warp_variant = 1;
+
 }  // namespace
 
 extern "C" {
+
+int vsr_flownet_warp_variant(int v) {
+    VSR_REQUIRE(v == 0 || v == 1, "flownet_warp_variant: 0 LDS-staged tile + wave shuffles, 1 gathers");
+    g_warp_variant = v;
+    return VSR_OK;
+}
 
 int vsr_abi_version(void) { return VSR_ABI_VERSION; }
 const char* vsr_last_error(void) { return vsr::err_buf(); }
@@ -703,6 +794,11 @@ int vsr_flownet_up_warp_concat16_f16(const float* x6, const void* flow2_nhwc, in
                                      int B, int H, int W, vsr_stream_t stream) {
     VSR_REQUIRE(x6 && flow2_nhwc && out16, "up_warp_concat16: null pointer");
     VSR_REQUIRE(B > 0 && H >= 4 && W >= 4 && (H & 3) == 0 && (W & 3) == 0 && ld >= 2, "up_warp_concat16: bad shape (H, W multiples of 4)");
+    if (g_warp_variant == 0 && B <= 65535 && (H + WT_Y - 1) / WT_Y <= 65535) {   // LDS-staged tile + DPP neighbour hand-over
+        hipLaunchKernelGGL(k_flow_up_warp_concat16_lds, dim3((W + WT_X - 1) / WT_X, (H + WT_Y - 1) / WT_Y, B), dim3(kBlock), 0, vsr::S(stream), x6,
+                           (const _Float16*)flow2_nhwc, ld, bilinear, mul, inv_div, (_Float16*)out16, H, W);
+        return vsr::launched("up_warp_concat16/lds");
+    }
     hipLaunchKernelGGL(k_flow_up_warp_concat16, dim3(grid_for((size_t)H * W), B), dim3(kBlock), 0, vsr::S(stream), x6,
                        (const _Float16*)flow2_nhwc, ld, bilinear, mul, inv_div, (_Float16*)out16, H, W);
     return vsr::launched("up_warp_concat16");
