@@ -314,3 +314,42 @@ def test_splitk_runs_are_bit_identical():
             assert torch.equal(conv(x), first)
         ref = F.leaky_relu(F.conv2d(igemm.to_nchw_float(x, cin), w.half().float(), None, stride=s, padding=1), 0.1)
         assert (igemm.to_nchw_float(first, cout) - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [  # (N, Cin, H, W, Cout, k, act)
+    (2, 64, 33, 50, 128, 3, igemm.ACT_LEAKY), (1, 128, 40, 70, 64, 3, igemm.ACT_RELU), (1, 96, 19, 33, 70, 3, igemm.ACT_NONE),
+    (1, 64, 37, 61, 32, 3, igemm.ACT_RELU), (1, 64, 19, 33, 64, 5, igemm.ACT_RELU), (1, 64, 41, 77, 32, 7, igemm.ACT_RELU),
+    (2, 256, 68, 120, 256, 3, igemm.ACT_RELU)])
+def test_patch_kernel_with_weights_in_lds(case):
+    """k_conv_patch_lw (the chunk's weight block staged in LDS once per workgroup, 64 out-channels per workgroup for 3x3) against
+    the stock operator and against k_conv_patch_r8 (weight fragments per wave from L2): the same loop nest per accumulator, so
+    the same bits."""
+    from video_super_resolution_amd import _lib as L
+    N, cin, H, W, cout, k, act = case
+    rs = np.random.RandomState(cin + 17 * cout + k)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.conv2d(x.float(), w, b, stride=1, padding=k // 2)
+    ref = F.relu(ref) if act == igemm.ACT_RELU else (F.leaky_relu(ref, 0.1) if act == igemm.ACT_LEAKY else ref)
+    conv = igemm.HConv(w, b, stride=1, pad=k // 2, act=act)
+    lib = L.load()
+    xs = igemm.to_nhwc_half(x)
+    try:
+        lib.vsr_conv2d_tuning(2)        # every legal layer through the patch builds
+        lib.vsr_conv2d_tuning(2000)     # (not the tile kernel)
+        lib.vsr_conv2d_tuning(6002)
+        out = conv(xs).clone()
+        assert lib.vsr_last_route().decode().startswith("patch_lw<"), lib.vsr_last_route().decode()
+        lib.vsr_conv2d_tuning(6000)
+        out_r8 = conv(xs).clone()
+        assert lib.vsr_last_route().decode().startswith("patch_r8<"), lib.vsr_last_route().decode()
+    finally:
+        lib.vsr_conv2d_tuning(0)
+        lib.vsr_conv2d_tuning(2001)
+        lib.vsr_conv2d_tuning(6001)
+    got = igemm.to_nchw_float(out, cout)
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    if out.shape[3] > cout:
+        assert float(out[..., cout:].abs().max()) == 0.0
+    assert torch.equal(out, out_r8)

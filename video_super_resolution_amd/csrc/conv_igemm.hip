@@ -1029,6 +1029,108 @@ __global__ void __launch_bounds__(256) k_conv_patch_r8(const ConvP p) {
                              [&](int r, int li) { return r < rows_ok && li < cols_ok ? wbase + r * rstride + li * cstride : -1ll; });
 }
 
+// k_conv_patch_r8 with the chunk's WEIGHT BLOCK staged in LDS once per workgroup.  In k_conv_patch_r8 every wave fetches every
+// weight fragment of its column from L2 (1 KiB per fragment): a 3x3 layer at 32 out-channels per workgroup moves 72 KB of
+// fragments per 32-channel chunk beside a 39-KB patch -- at three workgroups per CU that is ~100 GB/s per CU of L2 -> CU traffic,
+// above what the chip delivers (55-70 GB/s per CU measured on the LDS-DMA tile kernel), so the 3x3 layers with many
+// channels sat at 600-990 TFLOP/s while the 11x11 ones (the same patch feeds 13x the MFMAs) reach 1100-1400.  Here the block
+// [kh*kw][16 MT][32] of a chunk goes to LDS once (18 KB at 32 out-channels, 36 KB at 64, by LDS-DMA: the packed slab of a
+// (tap, chunk) is contiguous), the four waves read their column's fragments from there, and with no weight traffic per wave a
+// workgroup can own 64 out-channels (MT = 4: the patch is staged once for twice the MFMAs; round 2's MT = 4 build kept 12
+// fragments in registers per column, needed 266, and lost).  Same loop nest per accumulator as k_conv_patch_r8: bit-identical.
+__device__ __forceinline__ void lw_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, off, 0, 0, 0);
+}
+template <int KH, int MT>
+__global__ void __launch_bounds__(256, 2) k_conv_patch_lw(const ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    const int KW = KH;
+    const int PH = P8_H + KH - 1, PW = P8_W + KW - 1;
+    constexpr int PATCH_BYTES = (P8_H + KH - 1) * (P8_W + KH - 1) * 64;
+    constexpr int WROWS = 16 * MT;                    // weight rows (out-channels) of this workgroup
+    constexpr int WTAP = WROWS * 64;                  // one tap's block [16 MT][32] fp16
+    unsigned char* const patch = psm;                 // [PH][PW] pixels of 64 B (chunk XOR pixel-column bits 1-2)
+    unsigned char* const wts = psm + PATCH_BYTES;     // [KH*KW][16 MT] rows of 64 B, 16-byte pieces XOR row bits 1-2 (sw_off)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tiles_x = (p.Wo + P8_W - 1) / P8_W;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int n = blockIdx.y;
+    const int co0 = blockIdx.z * WROWS;
+    const int oy0 = ty * P8_H, ox0 = tx * P8_W;
+    const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+    const int nchunk = p.cin >> 5;
+    const int ry0 = P8_R * (wv >> 1), cx0 = 16 * (wv & 1);
+
+    f4 acc[P8_R][MT];
+#pragma unroll
+    for (int r = 0; r < P8_R; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int NPC = ((P8_H + KH - 1) * (P8_W + KH - 1) * 4 + 255) / 256;
+    unsigned poff[NPC];
+    int pdst[NPC];
+    patch_pieces(p, iy0, ix0, PH, PW, tid, poff, pdst);
+    // weight DMA: piece q (1 KiB = 16 rows) of tap t: rows 16 q .. of the block; lane L -> row 16 q + (L >> 2), slot L & 3, which
+    // under the read swizzle holds chunk (L & 3) ^ ((row >> 1) & 3).  WPW pieces per wave and chunk, round-robin over the waves.
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(p.wpk), 0, (int)((size_t)KH * KW * nchunk * p.cout_pad * 64), 0x00020000);
+    constexpr int WPIECES = KH * KH * MT;             // 1-KiB pieces of a chunk's block
+    const int wrow_l = lane >> 2, wslot = lane & 3;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();
+        for (int q = wv; q < WPIECES; q += 4) {       // (wave-uniform)
+            const int tap = q / MT, blk = q - tap * MT;
+            const int row = 16 * blk + wrow_l;
+            const unsigned off = (unsigned)(((size_t)(tap * nchunk + ch) * p.cout_pad + co0 + row) * 64 + ((wslot ^ ((row >> 1) & 3)) << 4));
+            lw_dma16(w_rsrc, wts + tap * WTAP + 1024 * blk, off);
+        }
+        stage_patch_cached(p, patch, n, ch, iy0, poff, pdst);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kx = 0; kx < KW; ++kx) {
+            h8 A[KH][MT];
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    A[ky][mt] = *reinterpret_cast<const h8*>(wts + (ky * KW + kx) * WTAP + sw_off(16 * mt + l15, g));
+            const int px = cx0 + l15 + kx;
+            const unsigned char* src = patch + (ry0 * PW + px) * 64 + ((g ^ ((px >> 1) & 3)) << 4);
+#pragma unroll
+            for (int pr = 0; pr < KH + P8_R - 1; ++pr) {
+                const h8 bf = *reinterpret_cast<const h8*>(src + pr * PW * 64);
+#pragma unroll
+                for (int r = 0; r < P8_R; ++r) {
+                    const int ky = pr - r;
+                    if (ky < 0 || ky >= KH) continue;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ky][mt], bf, acc[r][mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const long long wbase = (((long long)n * p.outH + (oy0 + ry0) * p.oy_mul + p.oy_off) * p.outW + (ox0 + cx0) * p.ox_mul + p.ox_off) * p.out_ld;
+    const int rstride = p.oy_mul * p.outW * p.out_ld, cstride = p.ox_mul * p.out_ld;
+    const int rows_ok = p.Ho - (oy0 + ry0), cols_ok = p.Wo - (ox0 + cx0);
+    patch_epilogue<MT, P8_R>(p, psm + wv * (P8_R * 16 * 32 * MT), co0, lane, [&](int r, int mt) { return acc[r][mt]; },
+                             [&](int r, int li) { return r < rows_ok && li < cols_ok ? wbase + r * rstride + li * cstride : -1ll; });
+}
+
+template <int KH, int MT>
+static void launch_patch_lw(const ConvP& p, int N, hipStream_t stream) {
+    const int lds_patch = (P8_H + KH - 1) * (P8_W + KH - 1) * 64 + KH * KH * 16 * MT * 64, lds_out = 4 * P8_R * 16 * 32 * MT;
+    const int lds = lds_patch > lds_out ? lds_patch : lds_out;
+    static unsigned long long raised = 0;
+    if (lds > 64 * 1024 && !vsr::device_marked(raised)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch_lw<KH, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        vsr::mark_device(raised);
+    }
+    const unsigned tiles = vsr::cdiv(p.Ho, P8_H) * vsr::cdiv(p.Wo, P8_W);
+    hipLaunchKernelGGL((k_conv_patch_lw<KH, MT>), dim3(tiles, N, p.cout_pad / (16 * MT)), dim3(256), lds, stream, p);
+}
+
 template <int KH, int MT>
 static void launch_patch_r8(const ConvP& p, int N, hipStream_t stream) {
     const int lds_patch = (P8_H + KH - 1) * (P8_W + p.kw - 1) * 64, lds_out = 4 * P8_R * 16 * 32 * MT;
@@ -1426,6 +1528,7 @@ static int launch_gather_lds(const ConvP& p, dim3 grid, hipStream_t stream) {
 static int g_splitk_fill = 128;   // split K when a launch has fewer workgroups than this, into ~2x as many (tools/probe_splitk.py; 256 until the
                                    // round-2 rebuild made a K step cheap: FlowNet2 3.7 -> 3.45 ms, hourglass 5.03 -> 4.88, OSVOS 1.25 -> 1.29)
 static int g_tile_mode = 1;   // conv_tile.hip (two-operand LDS-DMA tile): 0 never, 1 (default) where tile_choice says it wins over the gather kernel, 3 every layer it can run, the patch kernels' too (tests) (vsr_conv2d_tuning(2000 + n))
+static int g_lw_mode = 1;     // k_conv_patch_lw (weight block in LDS): 0 never, 1 heuristic, 2 wherever a build exists (vsr_conv2d_tuning(6000 + n))
 static int g_tile_bn = 0, g_tile_splits = 0;   // experiments: force the tile width (64 / 128) / the split count (vsr_conv2d_tuning(4000 + bn), (5000 + n)); 0 = heuristic
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
 
@@ -1494,6 +1597,7 @@ extern "C" {
 
 int vsr_conv2d_tuning(int patch_mode) {
     const int old = g_patch_mode;
+    if (patch_mode >= 6000) { g_lw_mode = patch_mode - 6000; return old; }
     if (patch_mode >= 5000) { g_tile_splits = patch_mode - 5000; return old; }
     if (patch_mode >= 4000) { g_tile_bn = patch_mode - 4000; return old; }
     if (patch_mode >= 2000) { g_tile_mode = patch_mode - 2000; return old; }
@@ -1771,6 +1875,25 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         const int r8_mt = (cout_pad & 31) == 0 ? 2 : (cout_pad == 16 ? 1 : 0);
         if (!no_r8 && r8_mt && r8_lds <= 80 * 1024 && Ho >= 12 && (kh == 3 || kh == 5 || kh == 7 || kh == 11)) {
             hipStream_t st = vsr::S(stream);
+            // 3x3 layers on many pixels: the build with the weight block in LDS (k_conv_patch_lw), 64 out-channels per workgroup
+            // (32 for a 32-channel layer with >= 64 inputs).  Measured per layer inside the trunks (tools/trunk_layers.sh,
+            // profiles/r03_patch_lw_layers.txt): 540 x 960 64 -> 64 130 -> 97 us, 270 x 480 128 -> 128 110 -> 79, 64 -> 128 68 -> 54,
+            // 256 x 480 64 -> 128 60 -> 51, 270 x 480 64 -> 32 42 -> 36; it LOSES below ~500 workgroups (128 x 240 224 -> 64 29 -> 37:
+            // half as many workgroups as the 32-channel build) and for 5x5 / 7x7 (their weight block leaves one workgroup per CU).
+            // g_lw_mode: 0 never, 1 this heuristic, 2 wherever a build exists (tests / A-B).
+            if (g_lw_mode >= 1 && kh == kw && g_patch_mode != 5) {
+                const int lw_mt = (kh == 3 && (cout_pad & 63) == 0) ? 4 : ((cout_pad & 31) == 0 && (kh == 3 || kh == 5 || kh == 7) ? 2 : 0);
+                const long long lw_wgs = lw_mt ? (long long)vsr::cdiv(Ho, P8_H) * vsr::cdiv(Wo, P8_W) * N * (cout_pad / (16 * lw_mt)) : 0;
+                const bool lw_pays = g_lw_mode >= 2 || (kh == 3 && lw_wgs >= 500 && (lw_mt == 4 || (cin >> 5) >= 2));
+                if (lw_mt && lw_pays) {
+                    vsr::route("patch_lw<%d,%d>", kh, lw_mt);
+                    if (kh == 3 && lw_mt == 4) launch_patch_lw<3, 4>(p, N, st);
+                    else if (kh == 3) launch_patch_lw<3, 2>(p, N, st);
+                    else if (kh == 5) launch_patch_lw<5, 2>(p, N, st);
+                    else launch_patch_lw<7, 2>(p, N, st);
+                    return vsr::launched("conv2d_nhwc_f16/patch_lw");
+                }
+            }
             vsr::route("patch_r8<%d,%d>", kh, r8_mt);
 #define VSR_R8(KH_) \
             if (kh == KH_) { if (r8_mt == 2) launch_patch_r8<KH_, 2>(p, N, st); else launch_patch_r8<KH_, 1>(p, N, st); }
