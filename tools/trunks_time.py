@@ -8,7 +8,7 @@ torch.set_grad_enabled(False)
 from video_super_resolution_amd import _lib as L
 for _t in os.environ.get('VSR_TUNING', '').split(','):
     if _t: L.load().vsr_conv2d_tuning(int(_t))
-h, w = 540, 960
+h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (540, 960)
 m = fill_module_(VSR().eval(), 0).cuda()
 fr = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (4, h, w, 3)).astype(np.float32)).cuda()
 fx, hx, ox = m._flow_exec.get(), m._depth_exec.get(), m._vos_exec.get()
