@@ -393,8 +393,13 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
 int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, int ld, const void* const* weff, const int* strides,
                        int nbranch, float bias, float* out, int N, int h, int w, vsr_stream_t stream);
 
-/* Tuning hook for benchmarks: 0 heuristic choice between the gather kernel and the LDS-patch kernel (cout <= 16,
- * stride 1), 1 never the patch kernel, 2 whenever legal.  Returns the previous mode. */
+/* Tuning hook for benchmarks and cross-checks (not part of the path).  0 heuristic kernel choice, 1 never the LDS-patch kernels
+ * (nor the tile kernel), 2 the patch kernels whenever legal, 3 / 5 / 6 / 7 subsets of the patch builds, 8 the first gather build
+ * (pixel operand through LDS), 10 / 11 128-channel gather tiles always / never.  Ranges set one knob each and leave the mode:
+ * 1000 + n split-K fill threshold of the gather kernel (default 128); 2000 + m tile kernel (conv_tile.hip) 0 never, 1 where it
+ * wins (default), 3 every layer it can run; 4000 + bn / 5000 + n force the tile width (64 / 128) / split count (0 = heuristic);
+ * 6000 + m k_conv_patch_lw (weight block in LDS) 0 never, 1 heuristic (default), 2 wherever a build exists.
+ * Returns the previous mode. */
 int vsr_conv2d_tuning(int patch_mode);
 
 /* ------------------------------------------------------------------------------------------
