@@ -16,10 +16,17 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
 _CHILD = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29547")
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
 import torch, torch.distributed as dist
 from video_super_resolution_amd.distributed import ClipGather, gather_frames, run_sharded_clips
 dev = torch.device("cuda", 0)
@@ -58,7 +65,7 @@ print("RCCL_SINGLE_RANK_OK")
 
 
 def test_gather_helpers_on_a_one_rank_rccl_group():
-    p = subprocess.run([sys.executable, "-c", _CHILD, ROOT], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, "-c", _CHILD, ROOT, str(_free_port())], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_SINGLE_RANK_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
 
 
@@ -67,7 +74,7 @@ def test_bench_under_the_distributed_launcher_with_one_rank(extra):
     """bench.py exactly as the driver launches N > 1 (`python -m torch.distributed.run --nproc-per-node N ...`), N = 1, with
     --force-dist: init_process_group("nccl"), barrier, the gathers, all_reduce(MAX), destroy -- all executed."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29551", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--lr-h", "64",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--lr-h", "64",
            "--lr-w", "96", "--no-cpu-baseline", "--no-extras", "--force-dist"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]

@@ -117,3 +117,44 @@ def test_whole_forward_at_540x960_fp16_vs_fp32_configuration(gpu_vsr, gpu_vsr_f1
         span = float(b.max() - b.min())
         print(f"[forward {H}x{W} frame {t}] fp16 vs fp32 configuration: PSNR(255) {psnr:.2f} dB, p99 |diff| {p99:.3f}, frame span {span:.1f}")
         assert psnr > 70.0 and p99 < 0.5, (t, psnr, p99)      # measured 79.9 / 79.6 dB, p99 0.09 grey levels
+
+
+# ---- the same at the C3-B / C2 frame size (LR 1080x1920; FlowNet2 crop 1024x1920): more layers clear the thresholds of the tile
+#      kernel (>= 384 workgroups of 128 channels) and of k_conv_patch_lw (>= 500 workgroups), the hourglass's 224-channel map
+#      passes 1.8 GB.  One frame / one pair / two frames keep the float32 masters (stock convolutions) within seconds.
+H2, W2 = 1080, 1920
+
+
+def test_trunks_at_1080x1920(gpu_vsr):
+    with torch.no_grad():
+        fr = torch.from_numpy(_smooth_frames(3, H2, W2, 5)).cuda()
+        # hourglass, one frame
+        netg = gpu_vsr.DepthModule.model.netG
+        got, hist = _logged(lambda: HourglassExec(netg)(fr[:1]))
+        ref = netg(fr[:1].permute(0, 3, 1, 2))
+        e = _rel(got, ref)
+        print(f"[hourglass 1x{H2}x{W2}] max {e:.3e} of range")
+        assert e < 1e-2 and "stem7_rows" in hist
+        del got, ref
+        torch.cuda.empty_cache()
+        # OSVOS, two frames
+        net = gpu_vsr.VOSModule.net
+        x = (fr[:2] - gpu_vsr.VOSModule.meanval.to("cuda")).permute(0, 3, 1, 2).contiguous()
+        got, hist = _logged(lambda: OSVOSExec(net)(x))
+        ref = net(x)
+        e = _rel(got, ref)
+        print(f"[OSVOS 2x{H2}x{W2}] max {e:.3e} of range")
+        assert e < 1e-2
+        assert any(k.startswith("patch_lw<3,4>") for k in hist) and any(k.startswith("tile<128>") for k in hist), hist
+        del got, ref, x
+        torch.cuda.empty_cache()
+        # FlowNet2, one pair of 1024 x 1920
+        fnet = gpu_vsr.FlowModule.net
+        fc = fr[:2, 28:28 + 1024]                                       # StaticCenterCrop to multiples of 64 (tools.py:8-14)
+        xp = fc.permute(3, 0, 1, 2).unsqueeze(0).contiguous()           # [1,3,2,1024,1920]
+        got, hist = _logged(lambda: FlowNet2Exec(fnet)(xp))
+        ref = fnet(xp)
+        mx, mean = _rel(got, ref), (got - ref).abs().mean().item() / ref.abs().max().item()
+        print(f"[FlowNet2 1x1024x{W2}] max {mx:.3e} mean {mean:.3e} of range")
+        assert mx < 2e-2 and mean < 2e-3
+        assert any(k.startswith("tile<128>") for k in hist), hist
