@@ -353,3 +353,40 @@ def test_patch_kernel_with_weights_in_lds(case):
     if out.shape[3] > cout:
         assert float(out[..., cout:].abs().max()) == 0.0
     assert torch.equal(out, out_r8)
+
+
+@pytest.mark.parametrize("case", [  # (N, H, W, Cout, act, out_ld extra, out_coff)
+    (1, 259, 271, 208, igemm.ACT_RELU, 0, 0), (2, 190, 181, 128, igemm.ACT_LEAKY, 0, 0), (1, 300, 230, 112, igemm.ACT_NONE, 0, 0),
+    (1, 270, 250, 224, igemm.ACT_RELU, 32, 32), (3, 160, 140, 160, igemm.ACT_RELU, 0, 0)])
+def test_conv1x1_transposing_build(case):
+    """k_conv1x1_t (128 input channels; contiguous KiB accesses through per-wave LDS slots, LDS-DMA input one block ahead) against
+    the stock operator and against k_conv1x1_stream: the same products in the same order per accumulator, so the same bits; ragged
+    last blocks, a channel-slice destination."""
+    from video_super_resolution_amd import _lib as L
+    N, H, W, cout, act, extra, coff = case
+    cin = 128
+    rs = np.random.RandomState(H + cout)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cout, cin, 1, 1) / np.sqrt(cin)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.conv2d(x.float(), w, b)
+    ref = F.relu(ref) if act == igemm.ACT_RELU else (F.leaky_relu(ref, 0.1) if act == igemm.ACT_LEAKY else ref)
+    conv = igemm.HConv(w, b, stride=1, pad=0, act=act)
+    lib = L.load()
+    xs = igemm.to_nhwc_half(x)
+    ld = igemm.pad32(coff + cout) + extra
+    outs = []
+    try:
+        for mode in (7001, 7000):
+            lib.vsr_conv2d_tuning(mode)
+            dst = torch.full((N, H, W, ld), 3.0, dtype=torch.float16, device="cuda")
+            conv(xs, out=dst, out_coff=coff)
+            outs.append((dst, lib.vsr_last_route().decode()))
+    finally:
+        lib.vsr_conv2d_tuning(7000)   # (the default: the streaming build; DESIGN.md 5.3)
+    (new, r_new), (old, r_old) = outs
+    assert r_new == "conv1x1_t" and r_old.startswith("conv1x1_stream<4>"), (r_new, r_old)
+    got = new[..., coff:coff + cout].permute(0, 3, 1, 2).float()
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert torch.equal(new, old)                                   # incl. the untouched channels outside the slice (3.0)
+    assert float((new[..., :coff] - 3.0).abs().max() if coff else 0.0) == 0.0

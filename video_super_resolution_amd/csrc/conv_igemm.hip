@@ -651,6 +651,143 @@ __global__ void __launch_bounds__(512) k_conv1x1_stream(const ConvP p) {
     }
 }
 
+// k_conv1x1_stream with CONTIGUOUS memory accesses on both sides (128 input channels: the hourglass's fused inception 1x1s).
+// Ablation of k_conv1x1_stream<4> on 128 -> 208 at 4 x 540 x 960 (434 us): its loads alone need ~200 us for 531 MB and its stores +
+// MFMAs 336 us for 863 MB -- a pixel is 256 B in and 448 B out, and in the MFMA fragment layout every load / store instruction
+// touches 64 B of each of 16 pixels: 16 separate segments per KiB, where the 32-channel 1x1 chains of the SR net (16 pixels = 1 KiB
+// contiguous) run at the device's copy rate.  Here a wave owns 32 pixels per block and two 8-KB LDS slots:
+//   in : the block's [32 px][256 B] by LDS-DMA, 4 whole pixels (1 KiB contiguous) per instruction, one block ahead; the 16-byte
+//        pieces are permuted INSIDE each pixel's 256 B on the source side (piece j at slot j ^ (pixel & 15)), so the B-fragment
+//        ds_read_b128 of (pixel l15, piece 4 c + g) is conflict-free while every DMA instruction still reads 1 KiB contiguous;
+//   out: once the block's fragments sit in registers its slot is free: the results of 128 out-channels go there as
+//        [32 px][256 B] (same permutation), are read back lane-linearly and leave as 4 x 256 contiguous bytes per instruction.
+// A wave synchronises with nobody after the weights are staged (its slots are its own; LDS executes a wave's accesses in order).
+// Same products in the same order per accumulator as k_conv1x1_stream: bit-identical.
+__device__ __forceinline__ void c1t_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, off, 0, 0, 0);
+}
+constexpr int C1T_SLOT = 32 * 256;   // one wave's [32 px][256 B] image
+__global__ void __launch_bounds__(256) k_conv1x1_t(const ConvP p) {
+    constexpr int NCH = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const int rows = NCH * p.cout_pad;
+    for (int q = tid; q < rows * 4; q += 256)
+        *reinterpret_cast<uint4*>(wsm + sw_off(q >> 2, q & 3)) = *reinterpret_cast<const uint4*>(p.wpk + (size_t)q * 8);
+    float* const bsm = reinterpret_cast<float*>(wsm + (size_t)rows * 64);
+    for (int q = tid; q < p.cout_pad; q += 256) bsm[q] = (p.bias && q < p.cout) ? p.bias[q] : 0.0f;
+    unsigned char* const slots = wsm + (size_t)rows * 64 + (size_t)p.cout_pad * 4 + (size_t)wv * 2 * C1T_SLOT;   // this wave's two slots
+    __syncthreads();
+    const long long nblk = (M + 127) / 128;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(p.in), 0, (int)((size_t)M * p.in_ld * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)M * p.out_ld * 2), 0x00020000);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    // DMA piece k (0..7) of a block: pixels 4 k .. 4 k + 3 of the wave's 32; lane L -> pixel 4 k + (L >> 4), slot L & 15
+    const int dq = lane >> 4, ds = lane & 15;
+    auto fetch = [&](long long blk, int slot) __attribute__((always_inline)) {
+        const long long m0 = blk * 128 + 32 * wv;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pl = 4 * k + dq;
+            const long long m = m0 + pl;
+            const unsigned off = m < M ? (unsigned)(((size_t)m * p.in_ld + p.in_coff) * 2 + ((ds ^ (pl & 15)) << 4)) : 0xFFFFFFFFu;
+            c1t_dma16(in_rsrc, slots + slot * C1T_SLOT + 1024 * k, off);
+        }
+    };
+    const float nslope = p.act == 1 ? 0.0f : (p.act == 2 ? p.slope : 1.0f);
+    const int ngroup = (p.cout + 127) >> 7;            // groups of 128 out-channels
+    // the [32 px][256 B] output tile of one 128-channel group -> global memory, 4 x 256 contiguous bytes per instruction:
+    // lane L of piece k holds pixel 4 k + (L >> 4), channels 128 grp + 8 (L & 15) .. + 7
+    auto store_group = [&](const unsigned char* tile, long long mbase, int grp) __attribute__((always_inline)) {
+        const int npair = min(4, (p.cout_pad - 128 * grp) >> 5);
+        const int ch = 128 * grp + 8 * ds;
+        const bool ch_ok = ch + 8 <= p.cout && ds < 4 * npair;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pl = 4 * k + dq;
+            const long long m = mbase + pl;
+            const u4 v = *reinterpret_cast<const u4*>(tile + pl * 256 + ((ds ^ (pl & 15)) << 4));
+            const unsigned off = (ch_ok && m < M) ? (unsigned)(((size_t)m * p.out_ld + p.out_coff + ch) * 2) : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, off, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile has been read back: its slot may be rewritten
+    };
+    // Order of a trip (vector-memory loads and stores retire out of order with respect to each other, so there is no counted
+    // wait that leaves "the stores" in flight: every wait is vmcnt(0), and the trip is ordered so that whatever is youngest
+    // before that wait was issued at least half a block of MFMAs earlier):
+    //   wait | fragments of block b -> registers | LAST group of block b-1: tile (other slot) -> stores | DMA of block b+1 into
+    //   that slot | groups of block b: MFMAs -> tile (this block's own slot); all but the last group stored at once
+    int cur = 0;
+    bool have_prev = false;
+    long long prev_mbase = 0;
+    if ((long long)blockIdx.x >= nblk) return;
+    fetch(blockIdx.x, 0);
+    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x, cur ^= 1) {
+        unsigned char* const img = slots + cur * C1T_SLOT;
+        unsigned char* const oth = slots + (cur ^ 1) * C1T_SLOT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        h8 bf[NCH][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int pl = 16 * nt + l15;
+                bf[c][nt] = *reinterpret_cast<const h8*>(img + pl * 256 + (((4 * c + g) ^ (pl & 15)) << 4));
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments are in registers: the slot is free for the output tile
+        if (have_prev) store_group(oth, prev_mbase, ngroup - 1);
+        fetch(blk + gridDim.x, cur ^ 1);   // (past the last block: out-of-range offsets, zeros, no traffic)
+        const long long mbase = blk * 128 + 32 * wv;
+        for (int grp = 0; grp < ngroup; ++grp) {
+            const int npair = min(4, (p.cout_pad - 128 * grp) >> 5);
+            for (int tp = 0; tp < npair; ++tp) {
+                const int t = 8 * grp + 2 * tp;            // first of the pair's two 16-row tiles
+                const int rowA = 16 * t + 8 * (l15 >> 2) + (l15 & 3);
+                h8 a0[NCH], a1[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    a0[c] = *reinterpret_cast<const h8*>(wsm + sw_off(c * p.cout_pad + rowA, g));
+                    a1[c] = *reinterpret_cast<const h8*>(wsm + sw_off(c * p.cout_pad + rowA + 4, g));
+                }
+                const int c0 = 16 * t + 8 * g;
+                const f4 b0 = *reinterpret_cast<const f4*>(bsm + c0), b1 = *reinterpret_cast<const f4*>(bsm + c0 + 4);
+                f4 acc[2][2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) { acc[0][nt] = b0; acc[1][nt] = b1; }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[c], bf[c][nt], acc[0][nt], 0, 0, 0);
+                        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[c], bf[c][nt], acc[1][nt], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float x = acc[r >> 2][nt][r & 3];
+                        v[r] = fmaxf(x, 0.0f) + nslope * fminf(x, 0.0f);
+                    }
+                    const int pl = 16 * nt + l15;
+                    *reinterpret_cast<h8*>(img + pl * 256 + (((4 * tp + g) ^ (pl & 15)) << 4)) =
+                        h8{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+                }
+            }
+            asm volatile("" ::: "memory");   // (same wave, in-order LDS: the read-back sees the writes above)
+            if (grp + 1 < ngroup) store_group(img, mbase, grp);
+        }
+        have_prev = true;
+        prev_mbase = mbase;
+    }
+    // the last block's last group is still in its slot (cur has flipped once more)
+    store_group(slots + (cur ^ 1) * C1T_SLOT, prev_mbase, ngroup - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the zero-fill DMA past the last block has landed before the wave ends)
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Stride-1 convolutions with a spatial kernel (the hourglass's 3x3..11x11 inception branches and final conv, FlowNet's
 // 3x3 layers and predict_flow, OSVOS's VGG stages): the tap-by-tap gather of k_conv_igemm re-reads every input pixel
@@ -1528,6 +1665,12 @@ static int launch_gather_lds(const ConvP& p, dim3 grid, hipStream_t stream) {
 static int g_splitk_fill = 128;   // split K when a launch has fewer workgroups than this, into ~2x as many (tools/probe_splitk.py; 256 until the
                                    // round-2 rebuild made a K step cheap: FlowNet2 3.7 -> 3.45 ms, hourglass 5.03 -> 4.88, OSVOS 1.25 -> 1.29)
 static int g_tile_mode = 1;   // conv_tile.hip (two-operand LDS-DMA tile): 0 never, 1 (default) where tile_choice says it wins over the gather kernel, 3 every layer it can run, the patch kernels' too (tests) (vsr_conv2d_tuning(2000 + n))
+// k_conv1x1_t (contiguous accesses through per-wave LDS slots) for 128-input-channel 1x1 layers: 0 never (default), 1 yes
+// (vsr_conv2d_tuning(7000 + n)).  Measured per layer inside the hourglass (tools/trunk_layers.sh): level with k_conv1x1_stream
+// (4 x 270 x 480 128 -> 128 57 vs 55 us, 128 -> 224 89-93 vs 90-91) and SLOWER on the largest layer (4 x 540 x 960 128 -> 208: 336 vs
+// 371 us) -- inside the network the streaming kernel already moves that layer's 1.39 GB at 4.1 TB/s, i.e. at the device's copy
+// rate; the contiguity of the accesses was not what held it.  Kept as the bit-identical cross-check build.
+static int g_c1t_mode = 0;
 static int g_lw_mode = 1;     // k_conv_patch_lw (weight block in LDS): 0 never, 1 heuristic, 2 wherever a build exists (vsr_conv2d_tuning(6000 + n))
 static int g_tile_bn = 0, g_tile_splits = 0;   // experiments: force the tile width (64 / 128) / the split count (vsr_conv2d_tuning(4000 + bn), (5000 + n)); 0 = heuristic
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
@@ -1597,6 +1740,7 @@ extern "C" {
 
 int vsr_conv2d_tuning(int patch_mode) {
     const int old = g_patch_mode;
+    if (patch_mode >= 7000) { g_c1t_mode = patch_mode - 7000; return old; }
     if (patch_mode >= 6000) { g_lw_mode = patch_mode - 6000; return old; }
     if (patch_mode >= 5000) { g_tile_splits = patch_mode - 5000; return old; }
     if (patch_mode >= 4000) { g_tile_bn = patch_mode - 4000; return old; }
@@ -1926,6 +2070,22 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         g_patch_mode != 1) {
         p.ws = nullptr;
         p.splits = 1;
+        // 128 input channels, 8-aligned output slice: the build with contiguous KiB accesses on both sides (k_conv1x1_t)
+        const size_t t_lds = w_lds + (size_t)cout_pad * 4 + (size_t)4 * 2 * C1T_SLOT;
+        if (g_c1t_mode >= 1 && cin == 128 && (cout & 7) == 0 && (out_ld & 7) == 0 && (out_coff & 7) == 0 && t_lds <= 160 * 1024 &&
+            (unsigned long long)M * in_ld * 2 < kGatherLimit && (unsigned long long)M * out_ld * 2 < kGatherLimit && cout <= 256) {
+            static unsigned long long raised = 0;
+            if (!vsr::device_marked(raised)) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1x1_t), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                vsr::mark_device(raised);
+            }
+            const int per_cu = (int)((160 * 1024) / t_lds) < 2 ? 1 : 2;
+            const long long nblk = (M + 127) / 128;
+            const unsigned grid = (unsigned)(nblk < 256LL * per_cu ? nblk : 256LL * per_cu);
+            vsr::route("conv1x1_t");
+            hipLaunchKernelGGL(k_conv1x1_t, dim3(grid), dim3(256), t_lds, vsr::S(stream), p);
+            return vsr::launched("conv2d_nhwc_f16/1x1t");
+        }
         typedef void (*k1_t)(const ConvP);
         static const k1_t k1[C1_MAX_CHUNKS] = {k_conv1x1_stream<1>, k_conv1x1_stream<2>, k_conv1x1_stream<3>, k_conv1x1_stream<4>,
                                                k_conv1x1_stream<5>, k_conv1x1_stream<6>, k_conv1x1_stream<7>, k_conv1x1_stream<8>};
