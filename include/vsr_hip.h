@@ -399,7 +399,8 @@ int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, in
  * 1000 + n split-K fill threshold of the gather kernel (default 128); 2000 + m tile kernel (conv_tile.hip) 0 never, 1 where it
  * wins (default), 3 every layer it can run; 4000 + bn / 5000 + n force the tile width (64 / 128) / split count (0 = heuristic);
  * 6000 + m k_conv_patch_lw (weight block in LDS) 0 never, 1 heuristic (default), 2 wherever a build exists; 7000 + m k_conv1x1_t
- * (128-input-channel 1x1 layers through per-wave LDS slots, contiguous accesses) 0 never (default), 1 where legal.
+ * (128-input-channel 1x1 layers through per-wave LDS slots, contiguous accesses) 0 never (default), 1 where legal; 8000 + m the
+ * gather kernel's five-set register ring 0 never (default), 1 launches of at most one workgroup per CU, 2 always.
  * Returns the previous mode. */
 int vsr_conv2d_tuning(int patch_mode);
 

@@ -390,3 +390,40 @@ def test_conv1x1_transposing_build(case):
     assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
     assert torch.equal(new, old)                                   # incl. the untouched channels outside the slice (3.0)
     assert float((new[..., :coff] - 3.0).abs().max() if coff else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("case", [  # (N, Cin, H, W, Cout, k, stride, pad, act)
+    (1, 64, 17, 30, 64, 3, 1, 1, igemm.ACT_LEAKY), (1, 512, 9, 15, 512, 3, 1, 1, igemm.ACT_LEAKY), (2, 256, 34, 30, 512, 3, 2, 1, igemm.ACT_RELU),
+    (1, 1024, 9, 15, 1024, 3, 1, 1, igemm.ACT_LEAKY), (1, 96, 23, 19, 48, 5, 1, 2, igemm.ACT_NONE), (1, 32, 40, 56, 16, 3, 1, 1, igemm.ACT_RELU),
+    (1, 128, 12, 10, 128, 7, 2, 3, igemm.ACT_RELU), (1, 64, 5, 7, 96, 1, 1, 0, igemm.ACT_NONE)])
+def test_gather_kernel_five_set_ring(case):
+    """k_conv_igemm_d with five register sets (four K steps in flight; launches of at most one workgroup per CU) against the
+    stock operator and against the three-set build: the same products in the same order, so the same bits -- K ranges that are
+    not multiples of five or three, split K, the tail pair, fewer K steps than sets."""
+    from video_super_resolution_amd import _lib as L
+    N, cin, H, W, cout, k, stride, pad, act = case
+    rs = np.random.RandomState(cin + cout + k)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.conv2d(x.float(), w, b, stride=stride, padding=pad)
+    ref = F.relu(ref) if act == igemm.ACT_RELU else (F.leaky_relu(ref, 0.1) if act == igemm.ACT_LEAKY else ref)
+    conv = igemm.HConv(w, b, stride=stride, pad=pad, act=act)
+    lib = L.load()
+    xs = igemm.to_nhwc_half(x)
+    outs = []
+    try:
+        lib.vsr_conv2d_tuning(2000)      # (the gather kernel on every layer)
+        old_patch = lib.vsr_conv2d_tuning(1)     # (and no patch kernels)
+        for mode in (8002, 8000):
+            lib.vsr_conv2d_tuning(mode)
+            outs.append((conv(xs).clone(), lib.vsr_last_route().decode()))
+    finally:
+        lib.vsr_conv2d_tuning(8000)      # (the default)
+        lib.vsr_conv2d_tuning(2001)
+        lib.vsr_conv2d_tuning(old_patch)
+    (new, r_new), (old, r_old) = outs
+    assert "gather" in r_new and "gather" in r_old, (r_new, r_old)
+    got = new[..., :cout].permute(0, 3, 1, 2).float()
+    assert (got - ref).abs().max().item() <= 3e-3 * ref.abs().max().item()
+    assert torch.equal(new, old)

@@ -26,6 +26,8 @@ using vsrc::sw_off;
 struct C0 { static constexpr int value = 0; };
 struct C1 { static constexpr int value = 1; };
 struct C2 { static constexpr int value = 2; };
+struct C3 { static constexpr int value = 3; };
+struct C4 { static constexpr int value = 4; };
 
 // Epilogue of the convolution kernels: bias + activation + fp16, then out through LDS so that a pixel's 16 MT channels leave
 // as whole 16-byte pieces from adjacent lanes (a full 128-byte line per pixel at MT = 4).  Straight from the MFMA
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
 // straight in fragment layout -- the same 16-byte pieces the staging threads fetched -- three K steps deep in registers.
 // Only the weight tile, shared by the four waves, still goes through LDS.  Per K step the LDS moves 40 KB instead of
 // 72 KB against 256 MFMA cycles per wave, which is what bounded the gather kernel (LDS busy ~2x the MFMA time).
-template <int BN, bool STEM = false>
+template <int BN, bool STEM = false, int D = 3>
 __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
     constexpr int MT = BN / 16;                 // out-channel tiles per wave
     constexpr int A_HALF = BN * 64;             // weight tile of one (tap, chunk)
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
     //      (Measured, tools/gather_steps.py: with the addresses computed per step from (pair / nchunk, tap / kw, ...) a K step of
     //      an otherwise EMPTY loop -- loads and MFMAs switched off -- cost 500-620 cycles per workgroup, half of the step.)
     {
-        const int pr0 = 2 * ks0, ntab = 2 * (ks_per + 5);   // range + rounding to 3-step groups + two steps of prefetch + one of table read-ahead
+        const int pr0 = 2 * ks0, ntab = 2 * (ks_per + 2 * D - 1);   // range + rounding to D-step groups + D-1 steps of prefetch + one of table read-ahead
         const unsigned wstep = (unsigned)p.cout_pad * 64u;
         for (int i = tid; i < ntab; i += 256) {
             const int pr = pr0 + i;
@@ -419,7 +421,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
     // LDS at the end of step ks+1.  Every load is a buffer load whose offset is out of range when the piece does not
     // exist (padding, tail, idle thread) -- the hardware returns zeros -- so a step issues a FIXED number of loads and
     // hipcc can wait with a vmcnt for the older set only.
-    u4 ra[3][2][AP], rb[3][2][2];
+    u4 ra[D][2][AP], rb[D][2][2];
     unsigned wlane[AP];   // this thread's piece of a weight slab [cout_pad][32] fp16 (rows co0.. contiguous); an idle thread points past the slabs
 #pragma unroll
     for (int ap = 0; ap < AP; ++ap) wlane[ap] = tid + 256 * ap < A_PIECES ? (unsigned)(co0 * 64 + (tid + 256 * ap) * 16) : 0x40000000u;
@@ -477,6 +479,10 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
     gload(C0{}, C0{});
     lstore(ks0 & 1, C0{});
     gload(C1{}, C1{});
+    if constexpr (D == 5) {
+        gload(C2{}, C2{});
+        gload(C3{}, C3{});
+    }
     __syncthreads();
     // step ks (i = ks - ks0): weights in LDS buffer ks&1, pixels in register set i%3; step ks+1 is in flight (weights in
     // register set (i+1)%3, pixels in set (i+1)%3); step ks+2 is requested at the top of the step into set (i+2)%3
@@ -512,10 +518,22 @@ __global__ void __launch_bounds__(256) k_conv_igemm_d(const ConvP p) {
         lstore(buf ^ 1, nxt);
         __syncthreads();
     };
-    for (int ks = ks0; ks < nk; ks += 3) {
-        body(ks, C0{}, C1{}, C2{});
-        body(ks + 1, C1{}, C2{}, C0{});
-        body(ks + 2, C2{}, C0{}, C1{});
+    if constexpr (D == 5) {
+        // five sets: step ks+4 is requested at the top of step ks (four memory latencies in flight per wave -- for the launches
+        // that put ONE workgroup on a CU, where no other wave hides them)
+        for (int ks = ks0; ks < nk; ks += 5) {
+            body(ks, C0{}, C1{}, C4{});
+            body(ks + 1, C1{}, C2{}, C0{});
+            body(ks + 2, C2{}, C3{}, C1{});
+            body(ks + 3, C3{}, C4{}, C2{});
+            body(ks + 4, C4{}, C0{}, C3{});
+        }
+    } else {
+        for (int ks = ks0; ks < nk; ks += 3) {
+            body(ks, C0{}, C1{}, C2{});
+            body(ks + 1, C1{}, C2{}, C0{});
+            body(ks + 2, C2{}, C0{}, C1{});
+        }
     }
 
     if (p.splits > 1 || p.act == 0) gather_store<BN, 0>(p, acc, M, m0, co0, tid, zsplit, ph, oy_off, ox_off);
@@ -1639,15 +1657,24 @@ __global__ void __launch_bounds__(256) k_corr_mfma(const _Float16* __restrict__ 
     }
 }
 
+// k_conv_igemm_d<.., 5>: five register sets, four K steps in flight, for launches of at most one workgroup per CU (0 never -- the
+// default --, 1 that rule, 2 always; vsr_conv2d_tuning(8000 + n)).  Measured (tools/trunks_time.py, one box): FlowNet2 3.06 / 3.09 /
+// 3.16 ms, hourglass x4 4.76 / 4.66 / 4.70, OSVOS 1.186 / 1.177 / 1.230 for n = 0 / 1 / 2 -- inside the run-to-run spread: the
+// low-resolution layers are not waiting on the depth of the prefetch.  Bit-identical to the three-set build (tests).
+static int g_gather_deep = 0;
 // k_conv_igemm_d's dynamic LDS: the double-buffered weight ring + the K-walk table of one workgroup's range of steps
 template <int BN, bool STEM>
 static int launch_gather(const ConvP& p, dim3 grid, hipStream_t stream) {
     const int nchunk = STEM ? 1 : p.cin >> 5, npair = STEM ? p.kh : p.kh * p.kw * nchunk;
     const int nk_all = (npair + 1) >> 1, ks_per = (nk_all + p.splits - 1) / p.splits;
-    const size_t lds = (size_t)BN * 256 + (size_t)2 * (ks_per + 5) * 16;
+    // five register sets (four K steps in flight) where the launch leaves one workgroup on a CU: nothing else hides the
+    // memory latency there and the registers are free (g_gather_deep: 0 never, 1 that rule, 2 always)
+    const bool deep = g_gather_deep == 2 || (g_gather_deep == 1 && (long long)grid.x * grid.y * grid.z <= 256 && ks_per >= 8);
+    const size_t lds = (size_t)BN * 256 + (size_t)2 * (ks_per + (deep ? 9 : 5)) * 16;
     if (lds > 64 * 1024) return vsr::fail(VSR_E_ARG, "conv2d: %d K steps per workgroup exceed the kernel's walk table (split K further)", ks_per);
     if ((unsigned long long)npair * p.cout_pad * 64 >= (1ull << 30)) return vsr::fail(VSR_E_ARG, "conv2d: packed weights beyond 1 GiB");
-    hipLaunchKernelGGL((k_conv_igemm_d<BN, STEM>), grid, dim3(256), lds, stream, p);
+    if (deep) hipLaunchKernelGGL((k_conv_igemm_d<BN, STEM, 5>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((k_conv_igemm_d<BN, STEM, 3>), grid, dim3(256), lds, stream, p);
     return VSR_OK;
 }
 
@@ -1740,6 +1767,7 @@ extern "C" {
 
 int vsr_conv2d_tuning(int patch_mode) {
     const int old = g_patch_mode;
+    if (patch_mode >= 8000) { g_gather_deep = patch_mode - 8000; return old; }
     if (patch_mode >= 7000) { g_c1t_mode = patch_mode - 7000; return old; }
     if (patch_mode >= 6000) { g_lw_mode = patch_mode - 6000; return old; }
     if (patch_mode >= 5000) { g_tile_splits = patch_mode - 5000; return old; }
