@@ -30,7 +30,19 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 
 #define VSR_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-constexpr int UTD3_LDS = PART_BYTES + LR_BYTES;   // no HR ring: the x4 map never leaves the registers
+// act_stage with its result pinned to the MFMA gap it is written in (an empty asm is ordered against the gap's fences; the plain
+// stage is a pure value that instruction selection is free to sink to its first use -- seen: a unit's 12 stages behind the last MFMA)
+__device__ __forceinline__ void act_stage_p(ActU& u, int j, const f4& lo, const f4& hi, h2 a, bool use_max) {
+    act_stage(u, j, lo, hi, a, use_max);
+    // (an asm that only READS the value: "+v" would make it opaque, and the max of two opaque values is preceded by a quieting
+    // v_pk_max_f16 x, x of each)
+    if (j < 4) asm volatile("" : : "v"(u.c[j]));
+    else if (j < 8) asm volatile("" : : "v"(u.m[j - 4]));
+    else asm volatile("" : : "v"(u.r[j - 8]));
+}
+
+constexpr int UTD3_LR_PAD = 2 * LR_SLOT + 16 * (256 - LR_COLS * 4);   // where the lanes without an LR piece store (slot offset + lane)
+constexpr int UTD3_LDS = PART_BYTES + LR_BYTES + UTD3_LR_PAD;   // no HR ring: the x4 map never leaves the registers
 
 template <bool ALLMAX, int DIAG>
 __global__ void __launch_bounds__(256)
@@ -114,14 +126,17 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     const bool lr_loader = tid < LR_COLS * 4;  // waves 0,1 and four lanes of wave 2
     const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 1 + lr_px;
     const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
-    const int lr_st = lr_off(lr_px, lr_ch);
+    // (the steady state stores unconditionally: the lanes without a piece into a pad behind the rows)
+    const int lr_st = lr_loader ? lr_off(lr_px, lr_ch) : LR_BYTES + 16 * (tid - LR_COLS * 4);
     // LR row r -> 16-byte piece of this thread.  A buffer load: lanes outside the image (or without a piece) read from
     // an out-of-range offset and get zeros -- no branch, so the value is not a phi and hipcc waits for it where it is
     // used (the LDS store at the end of the step), not at the top of the step
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     auto fetch_lr = [&](int r) __attribute__((always_inline)) -> u4 {
-        const unsigned off = (lr_col_ok && r >= 0 && r < h) ? (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
+        unsigned a = (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2);
+        asm volatile("" : "+v"(a));   // (computed by every lane: as the arm of the select below it became a branch around one add)
+        const unsigned off = (lr_col_ok && r >= 0 && r < h) ? a : 0xFFFFFFFFu;
         return __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
     };
     auto lr_slot = [&](int r) __attribute__((always_inline)) { return ((r + 1) % 3) * LR_SLOT; };
@@ -228,7 +243,9 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
         else if (j == 28) u.lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{u.s[0], u.s[1]}, h2));
         else if (j == 29) u.hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{u.s[2], u.s[3]}, h2));
         else {
-            const unsigned off = red_ok ? (unsigned)(((((size_t)n * h + i) * w + x0 + rj) * NF + 4 * rc4) * 2) : 0xFFFFFFFFu;
+            unsigned a = (unsigned)(((((size_t)n * h + i) * w + x0 + rj) * NF + 4 * rc4) * 2);
+            asm volatile("" : "+v"(a));
+            const unsigned off = red_ok ? a : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_buffer_store_b64(u2{u.lo, u.hi}, out_rsrc, off, 0, 0);
         }
         if (j < 20 || (j >= 24 && j < 28)) asm volatile("" : "+v"(u.s[e]));   // pin the stage where it is written (and keep
@@ -330,118 +347,146 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     // one LR row.  obP holds this wave's HR row of G(i-1) on entry and of G(i) on exit: with the tap order 0,4,1,5,...
     // the tile of column phase px has had both its uses before the new tile of that phase is finished, so the
     // registers are updated in place.
-    auto step = [&](int i, h8 (&obP)[4][2], auto edgec) __attribute__((always_inline)) {
-        {
-            const u4 nxt = fetch_lr(i + 3);
-            unsigned char* part_prev = part + (part_cur ^ PART_BUF);   // rows i-1 (written below) and i-3 (reduced above the barrier)
-            const int r_hr = 4 * i + 2 + wv;
-            const bool row_ok = r_hr >= 0 && r_hr < 4 * h;
-            f4 accd[2][2];
-            const unsigned long long t0 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
-            if (i >= r0 + 3 && r_hr < 4 * h) {
-                // ======================= steady state: the hand-ordered step (see the file header)
-                ShU sh[4];
-                f4 pr[4], accA[2][2][2], accB[2][2][2], a2A[2][2][2], a2B[2][2][2];
-                RedU ru;
-                ActU uA[4], uB[4], fA[4], fB[4];
-                VSR_FENCE();
-                // ---- A: partial tiles of row i-3 requested in the first gaps, reduced one VALU per gap from slot 6 on
+    // A row of the steady state (i >= r0 + 3, this wave's HR row inside the image): the hand-ordered step of the file header.
+    // It is its own loop: sharing a loop with the other rows cost ~300 of 3470 cycles per row in merges of the two paths'
+    // registers (16 v_mov_b64 at the loop end), exec-mask branches and the partial-tile stores behind the last MFMA.
+    auto step_steady = [&](int i, h8 (&obP)[4][2], auto edgec) __attribute__((always_inline)) {
+        const u4 nxt = fetch_lr(i + 3);
+        unsigned char* part_prev = part + (part_cur ^ PART_BUF);   // rows i-1 (written below) and i-3 (reduced above the barrier)
+        f4 accd[2][2];
+        const unsigned long long t0 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+        ShU sh[4];
+        f4 pr[4], accA[2][2][2], accB[2][2][2], a2A[2][2][2], a2B[2][2][2];
+        RedU ru;
+        ActU uA[4], uB[4], fA[4], fB[4];
+        VSR_FENCE();
+        // ---- A: partial tiles of row i-3 requested in the first gaps, reduced one VALU per gap from slot 6 on
 #pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    dmf(0, s, Bf, accA);
-                    if (s < 4) pr[s] = *reinterpret_cast<const f4*>(part_prev + part_rd + s * PART_W_PITCH);
-                    if (s >= 6) {
+        for (int s = 0; s < 32; ++s) {
+            dmf(0, s, Bf, accA);
+            if (s < 4) pr[s] = *reinterpret_cast<const f4*>(part_prev + part_rd + s * PART_W_PITCH);
+            if (s >= 6) {
 #pragma unroll
-                        for (int v = ((s - 6) * 31) / 26; v < ((s - 5) * 31) / 26; ++v) red_stage(v, i - 3, pr, ru);
-                    }
-                    VSR_FENCE();
-                }
-                const unsigned long long tA = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
-                __syncthreads();
-                const unsigned long long tBar = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
-                VSR_FENCE();
-                // ---- B: 48 VALU over 32 MFMAs
-#pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    dmf(1, s, Bf, accB);
-#pragma unroll
-                    for (int v = (3 * s) / 2; v < (3 * (s + 1)) / 2; ++v)
-                        act_stage(uA[v / 12], v % 12, accA[v / 24][0][(v / 12) & 1], accA[v / 24][1][(v / 12) & 1], a_up2, up_max);
-                    VSR_FENCE();
-                }
-                const unsigned long long tB = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
-                // ---- C: 8 1x1 MFMAs, down-conv groups 0..3; first PReLU of phases 2,3 (2 VALU per MFMA)
-#pragma unroll
-                for (int s = 0; s < 24; ++s) {
-                    if (s < 8) tmf(s, uA, a2A);
-                    else pmf(s - 8, obP, sh, accd);
-#pragma unroll
-                    for (int v = 2 * s; v < 2 * s + 2; ++v)
-                        act_stage(uB[v / 12], v % 12, accB[v / 24][0][(v / 12) & 1], accB[v / 24][1][(v / 12) & 1], a_up2, up_max);
-                    if (s >= 4 && s < 16) dpp_stage(sh[0], s - 4, obP[0]);   // tap 4 (first used in slot 16)
-                    VSR_FENCE();
-                }
-                const unsigned long long tC = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
-                // ---- D: down-conv groups 4,5 | 1x1 of phases 2,3 | groups 6..9; second PReLU of phases 0,1
-#pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    if (s < 8) pmf(16 + s, obP, sh, accd);
-                    else if (s < 16) tmf(s - 8, uB, a2B);
-                    else pmf(24 + (s - 16), obP, sh, accd);
-#pragma unroll
-                    for (int v = (3 * s) / 2; v < (3 * (s + 1)) / 2; ++v) {
-                        const int u = v / 12;
-                        act_stage(fA[u], v % 12, a2A[u >> 1][u & 1][0], a2A[u >> 1][u & 1][1], a_dt2, dt_max);
-                        if (v % 12 == 11) obP[u >> 1][u & 1] = ob_finish(u >> 1, u & 1, fA[u], edgec);
-                    }
-                    if (s >= 4 && s < 16) dpp_stage(sh[1], s - 4, obP[1]);   // tap 5 (first used in slot 16)
-                    if (s >= 20) dpp_stage(sh[2], s - 20, obP[2]);   // tap 6 (first used in slot 0 of E)
-                    VSR_FENCE();
-                }
-                const unsigned long long tD = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
-                // ---- E: down-conv groups 10..15; second PReLU of phases 2,3; LR operands of the next step
-#pragma unroll
-                for (int s = 0; s < 24; ++s) {
-                    pmf(40 + s, obP, sh, accd);
-#pragma unroll
-                    for (int v = 2 * s; v < 2 * s + 2; ++v) {
-                        const int u = v / 12;
-                        act_stage(fB[u], v % 12, a2B[u >> 1][u & 1][0], a2B[u >> 1][u & 1][1], a_dt2, dt_max);
-                        if (v % 12 == 11) obP[2 + (u >> 1)][u & 1] = ob_finish(2 + (u >> 1), u & 1, fB[u], edgec);
-                    }
-                    if (s >= 4 && s < 16) dpp_stage(sh[3], s - 4, obP[3]);   // tap 7 (first used in slot 16)
-                    if (s >= 16) {   // LR operands of step i+1 (rows i+1, i+2; the deconv of this step is done with Bf)
-                        const int t = (s - 16) >> 1, nt = (s - 16) & 1;
-                        Bf[t][nt] = *reinterpret_cast<const h8*>(lrr + ((t >> 1) ? s_i1 : s_i2) + lr_b[t & 1][nt]);
-                    }
-                    VSR_FENCE();
-                }
-                if (DIAG == 1) {
-                    const unsigned long long tE = __builtin_amdgcn_s_memtime();
-                    stamp[0] += tA - t0; stamp[1] += tB - tBar; stamp[2] += tC - tB; stamp[3] += tD - tC; stamp[4] += tE - tD;
-                    stamp[5] += tBar - tA;
-                }
-            } else {
-                if (i - 3 >= r0) reduce_store(i - 3, part_prev);
-                __syncthreads();
-                h8 obN[4][2];
-                if (row_ok) p1_plain(Bf, obN, edgec);
-                else zero_row(obN);
-                down_plain(obP, accd);   // (the partial row of i = r0 is row r0-1's: never reduced)
-#pragma unroll
-                for (int px = 0; px < 4; ++px)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) obP[px][nt] = obN[px][nt];
-                load_lr_frags(s_i1, s_i2, Bf);
+                for (int v = ((s - 6) * 31) / 26; v < ((s - 5) * 31) / 26; ++v) red_stage(v, i - 3, pr, ru);
             }
-            store_partials(part_prev, accd);
-            if (wv < 3 && lr_loader) *reinterpret_cast<u4*>(lrr + s_i + lr_st) = nxt;  // row i+3 -> slot of row i
-            const int t = s_i; s_i = s_i1; s_i1 = s_i2; s_i2 = t;
-            part_cur ^= PART_BUF;
+            VSR_FENCE();
         }
+        const unsigned long long tA = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+        __syncthreads();
+        const unsigned long long tBar = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+        VSR_FENCE();
+        // ---- B: 48 VALU over 32 MFMAs
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            dmf(1, s, Bf, accB);
+#pragma unroll
+            for (int v = (3 * s) / 2; v < (3 * (s + 1)) / 2; ++v)
+                act_stage_p(uA[v / 12], v % 12, accA[v / 24][0][(v / 12) & 1], accA[v / 24][1][(v / 12) & 1], a_up2, up_max);
+            VSR_FENCE();
+        }
+        const unsigned long long tB = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+        // LR operands of step i+1 (rows i+1, i+2; the deconv of this step is done with Bf): piece q = (t, nt)
+        auto next_lr_frag = [&](int q) __attribute__((always_inline)) {
+            const int t = q >> 1, nt = q & 1;
+            Bf[t][nt] = *reinterpret_cast<const h8*>(lrr + ((t >> 1) ? s_i1 : s_i2) + lr_b[t & 1][nt]);
+        };
+        // ---- C: 8 1x1 MFMAs, down-conv groups 0..3; first PReLU of phases 2,3 (2 VALU per MFMA)
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            if (s < 8) tmf(s, uA, a2A);
+            else pmf(s - 8, obP, sh, accd);
+#pragma unroll
+            for (int v = 2 * s; v < 2 * s + 2; ++v)
+                act_stage_p(uB[v / 12], v % 12, accB[v / 24][0][(v / 12) & 1], accB[v / 24][1][(v / 12) & 1], a_up2, up_max);
+            if (s >= 4 && s < 16) dpp_stage(sh[0], s - 4, obP[0]);   // tap 4 (first used in slot 16)
+            VSR_FENCE();
+        }
+        const unsigned long long tC = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+        // ---- D: down-conv groups 4,5 | 1x1 of phases 2,3 | groups 6..9; second PReLU of phases 0,1
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            if (s < 8) pmf(16 + s, obP, sh, accd);
+            else if (s < 16) tmf(s - 8, uB, a2B);
+            else pmf(24 + (s - 16), obP, sh, accd);
+#pragma unroll
+            for (int v = (3 * s) / 2; v < (3 * (s + 1)) / 2; ++v) {
+                const int u = v / 12;
+                act_stage_p(fA[u], v % 12, a2A[u >> 1][u & 1][0], a2A[u >> 1][u & 1][1], a_dt2, dt_max);
+                if (v % 12 == 11) obP[u >> 1][u & 1] = ob_finish(u >> 1, u & 1, fA[u], edgec);
+            }
+            if (s >= 4 && s < 16) dpp_stage(sh[1], s - 4, obP[1]);   // tap 5 (first used in slot 16)
+            if (s >= 20) dpp_stage(sh[2], s - 20, obP[2]);   // tap 6 (first used in slot 0 of E)
+            VSR_FENCE();
+        }
+        const unsigned long long tD = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+        // ---- E: down-conv groups 10..15; second PReLU of phases 2,3; LR row i+3 -> the slot of row i; the last tap's
+        //      MFMAs in the order [finish the current output row] x 4, [start the next] x 4 (each accumulator's own order
+        //      is unchanged) so that the four partial tiles are stored under the last four MFMAs, none behind them
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            if (s < 16) {
+                pmf(40 + s, obP, sh, accd);
+            } else {
+                const int j = s - 16, nt = (j >> 1) & 1, m = j & 1;
+                const h8 b = sh_tile(sh[3], nt);
+                if (j < 4) accd[m][nt] = mfma16(Adn[m][1][7], b, accd[m][nt]);
+                else carry[m][nt] = mfma16(Adn[m][0][7], b, carry[m][nt]);
+            }
+#pragma unroll
+            for (int v = 2 * s; v < 2 * s + 2; ++v) {
+                const int u = v / 12;
+                act_stage_p(fB[u], v % 12, a2B[u >> 1][u & 1][0], a2B[u >> 1][u & 1][1], a_dt2, dt_max);
+                if (v % 12 == 11) obP[2 + (u >> 1)][u & 1] = ob_finish(2 + (u >> 1), u & 1, fB[u], edgec);
+            }
+            if (s >= 4 && s < 16) dpp_stage(sh[3], s - 4, obP[3]);   // tap 7 (first used in slot 16)
+            if (s >= 16) next_lr_frag(s - 16);
+            if (s == 2) *reinterpret_cast<u4*>(lrr + s_i + lr_st) = nxt;   // (lanes without a piece: a pad behind the rows)
+            if (s >= 20) {
+                const int j = s - 20, nt = (j >> 1) & 1, m = j & 1;
+                *reinterpret_cast<f4*>(part_prev + part_wr + 64 * m + 16 * nt * PART_PX_PITCH) = accd[m][nt];
+            }
+            VSR_FENCE();
+        }
+        if (DIAG == 1) {
+            const unsigned long long tE = __builtin_amdgcn_s_memtime();
+            stamp[0] += tA - t0; stamp[1] += tB - tBar; stamp[2] += tC - tB; stamp[3] += tD - tC; stamp[4] += tE - tD;
+            stamp[5] += tBar - tA;
+        }
+        const int t = s_i; s_i = s_i1; s_i1 = s_i2; s_i2 = t;
+        part_cur ^= PART_BUF;
+    };
+    // Any other row: the first three of a segment (nothing to reduce yet / operands from the prologue) and, for waves 2 and 3,
+    // the image's last LR row (their HR row 4i+2+wv lies below the image: zeros)
+    auto step_plain = [&](int i, h8 (&obP)[4][2], auto edgec) __attribute__((always_inline)) {
+        const u4 nxt = fetch_lr(i + 3);
+        unsigned char* part_prev = part + (part_cur ^ PART_BUF);
+        const int r_hr = 4 * i + 2 + wv;
+        const bool row_ok = r_hr >= 0 && r_hr < 4 * h;
+        f4 accd[2][2];
+        if (i - 3 >= r0) reduce_store(i - 3, part_prev);
+        __syncthreads();
+        h8 obN[4][2];
+        if (row_ok) p1_plain(Bf, obN, edgec);
+        else zero_row(obN);
+        down_plain(obP, accd);   // (the partial row of i = r0 is row r0-1's: never reduced)
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) obP[px][nt] = obN[px][nt];
+        load_lr_frags(s_i1, s_i2, Bf);
+        store_partials(part_prev, accd);
+        if (wv < 3 && lr_loader) *reinterpret_cast<u4*>(lrr + s_i + lr_st) = nxt;  // row i+3 -> slot of row i
+        const int t = s_i; s_i = s_i1; s_i1 = s_i2; s_i2 = t;
+        part_cur ^= PART_BUF;
     };
     auto march = [&](auto edgec) __attribute__((always_inline)) {
-        for (int i = r0; i < r1; ++i) step(i, obP, edgec);
+        // (bounds per WAVE and said to be so: as vector values they made the loops divergent ones, counters and LDS slots in VGPRs)
+        const int i_st = __builtin_amdgcn_readfirstlane(min(r0 + 3, r1));
+        const int i_en = __builtin_amdgcn_readfirstlane(max(i_st, min(r1, h - (wv >= 2 ? 1 : 0))));   // every row has one barrier on either path
+        int i = r0;
+        for (; i < i_st; ++i) step_plain(i, obP, edgec);
+        for (; i < i_en; ++i) step_steady(i, obP, edgec);
+        for (; i < r1; ++i) step_plain(i, obP, edgec);
     };
     if (edge_strip) march(BoolC<true>{}); else march(BoolC<false>{});
     if (DIAG && g_stamp3_ptr && lane == 0) {
