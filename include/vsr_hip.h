@@ -208,6 +208,10 @@ int vsr_sr_chain_variant(int generic);
 /* Device buffer the stamped builds write to: [workgroup][wave 8][8] uint64 (phase cycle sums, loop cycles, loop time in
  * 10 ns ticks).  NULL detaches. */
 int vsr_sr_utd_stamp_buffer(void* device_buf);
+/* The same for the stamped build of the fused tail (full frames, folded compress_out, slopes <= 1): [workgroup][wave 8][8] uint64 =
+ * cycle sums of {LR requests, barrier, region A, C, B}, steps stamped, loop cycles, loop time in 10 ns ticks; totals_only: the
+ * build that stamps the whole march only (the per-region stamps cost cycles of their own). */
+int vsr_sr_tail_stamp_buffer(void* device_buf, int totals_only);
 
 /* The same fused stage with specialised wave roles (4 producer waves: deconv + 1x1 into the LDS ring; 4 consumer
  * waves: stride-4 conv out of it).  Measured 7 % slower than vsr_sr_utd_f16 on MI355X (the producer chain is the long

@@ -1300,6 +1300,7 @@ namespace vsr {
 int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                 int diag, hipStream_t stream);
 int utd3_set_stamps(void* buf);
+int tail3_set_stamps(void* buf, int totals_only);
 int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* prefc, int N,
                  int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream, const void* in2 = nullptr,
                  const float* cmap = nullptr);
@@ -1323,6 +1324,8 @@ int vsr_sr_utd_variant(int v) {
     g_utd_variant = v;
     return VSR_OK;
 }
+
+int vsr_sr_tail_stamp_buffer(void* buf, int totals_only) { return vsr::tail3_set_stamps(buf, totals_only); }
 
 int vsr_sr_utd_stamp_buffer(void* buf) {
     vsr::utd3_set_stamps(buf);

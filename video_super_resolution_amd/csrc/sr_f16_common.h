@@ -79,6 +79,16 @@ __device__ __forceinline__ void act_stage(ActU& u, int j, const f4& lo, const f4
 __device__ __forceinline__ h8 act_result(const ActU& u) {
     return h8{u.r[0][0], u.r[0][1], u.r[1][0], u.r[1][1], u.r[2][0], u.r[2][1], u.r[3][0], u.r[3][1]};
 }
+// act_stage with its result pinned to the MFMA gap it is written in (an empty asm is ordered against the gap's fences; the plain
+// stage is a pure value that instruction selection is free to sink to its first use -- seen: a unit's 12 stages behind the last MFMA)
+__device__ __forceinline__ void act_stage_p(ActU& u, int j, const f4& lo, const f4& hi, h2 a, bool use_max) {
+    act_stage(u, j, lo, hi, a, use_max);
+    // (an asm that only READS the value: "+v" would make it opaque, and the max of two opaque values is preceded by a quieting
+    // v_pk_max_f16 x, x of each)
+    if (j < 4) asm volatile("" : : "v"(u.c[j]));
+    else if (j < 8) asm volatile("" : : "v"(u.m[j - 4]));
+    else asm volatile("" : : "v"(u.r[j - 8]));
+}
 
 
 // byte offset of (column cc, 16-byte chunk) inside a ring row

@@ -23,7 +23,8 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 constexpr int T3_ROWS = 16;                              // output-row window of the partial sums
 constexpr int T3_PLANE = 128 * 16;                       // one (row, dy) plane: 128 HR columns x 16 B
 constexpr int T3_PART = (T3_ROWS * 3 + 1) * T3_PLANE;    // + one dump plane for the idle lane group
-constexpr int T3_LDS = T3_PART + LR_BYTES + 256;
+constexpr int T3_LR_PAD = 2 * LR_SLOT + 256 * 16;       // where the lanes without an LR piece store in the pipelined march (slot offset + lane)
+constexpr int T3_LDS = T3_PART + LR_BYTES + 256 + T3_LR_PAD;
 
 // DEC: only output pixels (4i, 4j) are wanted (pass 1 of VSR.forward): prefc is [N,3,h,w]
 // FOLD: the FeedbackBlock's last compress_out (1x1 over two LR maps + constant map + PReLU, SRProjectionModule.py:99) is
@@ -31,7 +32,10 @@ constexpr int T3_LDS = T3_PART + LR_BYTES + 256;
 // loader lanes sit in MFMA fragment layout (pixel l15 of the wave's 16 columns, 16-byte channel piece g), four MFMAs per
 // 16 pixels and row on three waves.  The rows then hold the accumulator's channel order, which the FOLD blob's deconv
 // fragments follow.  Saves the 1x1's own launch (0.2 ms: three 265 MB reads and a 265 MB write that this kernel re-reads).
-template <bool ALLMAX, bool DEC, bool FOLD>
+__device__ unsigned long long* g_stamp_t3_ptr = nullptr;
+
+// DIAG: stamped diagnostic build of the pipelined march (tools/tail_stamps.py): shader-clock sums per region and wave
+template <bool ALLMAX, bool DEC, bool FOLD, int DIAG = 0>
 __global__ void __launch_bounds__(256)
 k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const float* __restrict__ cmap,
         const unsigned char* __restrict__ blob, const unsigned char* __restrict__ acv3,
@@ -116,12 +120,15 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
     const bool co_max = a_co <= 1.0f;
     auto fetch_lr = [&](int r) __attribute__((always_inline)) -> RawRow {
         const bool ok = lr_col_ok && r >= 0 && r < h;
-        const unsigned off = ok ? (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
+        unsigned a0 = (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2);
+        unsigned c0 = (unsigned)((((size_t)r * w + lr_col) * NF + 4 * g) * 4);
+        asm volatile("" : "+v"(a0), "+v"(c0));   // (computed by every lane: as arms of the selects below they became branches around one add each)
+        const unsigned off = ok ? a0 : 0xFFFFFFFFu;
         RawRow v;
         v.a = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
         if (FOLD) {
             v.b = __builtin_amdgcn_raw_buffer_load_b128(in2_rsrc, off, 0, 0);
-            const unsigned coff = ok ? (unsigned)((((size_t)r * w + lr_col) * NF + 4 * g) * 4) : 0xFFFFFFFFu;
+            const unsigned coff = ok ? c0 : 0xFFFFFFFFu;
             v.c0 = __builtin_amdgcn_raw_buffer_load_b128(cm_rsrc, coff, 0, 0);
             v.c1 = __builtin_amdgcn_raw_buffer_load_b128(cm_rsrc, ok ? coff + 64 : 0xFFFFFFFFu, 0, 0);
         }
@@ -213,63 +220,6 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         const int c = k >> 4, t = (k >> 2) & 3, mt = (k >> 1) & 1, nt = k & 1;
         acc[c][mt][nt] = mfma16(Aup[2 * half + c][t][mt], Bf[t][nt], t == 0 ? bup[mt] : acc[c][mt][nt]);
     };
-    auto deconv_row_fast = [&](int i, const h8 (&Bf)[4][2], h8 (&ob)[4][2], int Rfin) __attribute__((always_inline)) {
-        f4 accA[2][2][2], accB[2][2][2];
-        ActU uA[4];
-        const bool fin = Rfin >= 4 * r0 && Rfin < 4 * r1;   // wave-uniform
-        const unsigned char* const fsrc = pb + ((Rfin & (T3_ROWS - 1)) * 3) * T3_PLANE;
-        f4 fs[2][3];
-        bool colok[4][2];
-#pragma unroll
-        for (int px = 0; px < 4; ++px)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
-                colok[px][nt] = (c_hr >= 0) && (c_hr < W);
-            }
-        VSR_FENCE();
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            dmf(0, s, Bf, accA);
-            if (fin) {
-                if (s < 6) { const int u = lane + 64 * (s / 3); fs[s / 3][s % 3] = *reinterpret_cast<const f4*>(fsrc + (s % 3) * T3_PLANE + (u ^ ((u >> 3) & 3)) * 16); }
-                if (s == 10 || s == 14) { const int q = (s - 10) >> 2; fs[q][0] += fs[q][1]; fs[q][0] += fs[q][2]; }
-                if (s == 18 || s == 24) {
-                    const int q = s == 18 ? 0 : 1;
-                    if (okq[q]) {
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) prefc[(((size_t)n * 3 + ch) * H + Rfin) * W + cq[q]] = fs[q][0][ch] + bo[ch];
-                    }
-                }
-            }
-            VSR_FENCE();
-        }
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            dmf(1, s, Bf, accB);
-#pragma unroll
-            for (int v = 2 * s; v < 2 * s + 2; ++v) {
-                const int u = v >> 4, st = v & 15, c = u >> 1, nt = u & 1;
-                if (st < 12) act_stage(uA[u], st, accA[c][0][nt], accA[c][1][nt], a_up2, up_max);
-                else {
-                    const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
-                    uA[u].r[st - 12] = colok[c][nt] ? uA[u].r[st - 12] : z;
-                    if (st == 15) ob[c][nt] = act_result(uA[u]);
-                }
-            }
-            VSR_FENCE();
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                h8 hb = act_pack(accB[c][0][nt], accB[c][1][nt], a_up2, up_max);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hb[e] = colok[2 + c][nt] ? hb[e] : (_Float16)0.0f;
-                ob[2 + c][nt] = hb;
-            }
-    };
-
     // ---- P3: contributions of this HR row to output rows R'+1 (dy 0), R' (dy 1), R'-1 (dy 2) -> partial planes
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     auto ror1 = [&](const h8& src) __attribute__((always_inline)) -> u4v {    // row_ror:1: lane i <- src[(i-1)%16]
@@ -365,7 +315,7 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         }
     };
 
-    // ---- march: groups G(r0-1) .. G(r1-1), then two more steps that only finish rows
+    // ---- prologue (both marches): LR rows r0-1, r0, r0+1 -> LDS
     if (FOLD ? wv < 3 : true) {
         const u4 ra = row_value(fetch_lr(r0 - 1), r0 - 1), rb = row_value(fetch_lr(r0), r0), rc = row_value(fetch_lr(r0 + 1), r0 + 1);
         if (lr_loader) {
@@ -376,28 +326,312 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
     }
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0);
-    for (int i = r0 - 1; i <= r1 + 1; ++i) {
-        const bool produce = i <= r1 - 1;
-        const RawRow nxt = fetch_lr(i + 3);
-        h8 Bf[4][2], ob[4][2];
-        if (produce) load_lr_frags(lr_slot(i), lr_slot(i + 1), Bf);
-        __syncthreads();
-        // rows whose last contribution was stored two steps ago (visible since the previous barrier; their planes are
-        // not rewritten before step i+2): anywhere in this step, so beside the MFMAs
-        const int r_hr = 4 * i + 2 + wv;
-        if (!DEC && produce && r_hr >= 0 && r_hr < H) {   // steady state of a full frame: the hand-ordered deconv, finish inside
-            deconv_row_fast(i, Bf, ob, 4 * i - 7 + wv);
-            conv_row(i, ob);
-        } else {
+    if constexpr (DEC) {
+        // ---- decimated pass: groups G(r0-1) .. G(r1-1), then two more steps that only finish rows
+        for (int i = r0 - 1; i <= r1 + 1; ++i) {
+            const bool produce = i <= r1 - 1;
+            const RawRow nxt = fetch_lr(i + 3);
+            h8 Bf[4][2], ob[4][2];
+            if (produce) load_lr_frags(lr_slot(i), lr_slot(i + 1), Bf);
+            __syncthreads();
+            // rows whose last contribution was stored two steps ago (visible since the previous barrier; their planes are
+            // not rewritten before step i+2)
             finish_row(4 * i - 7 + wv);
-            if (produce && !(DEC && wv == 0)) {   // DEC: HR row 4i+2 feeds output rows 4i+1..4i+3 only, none of them kept
+            if (produce && wv != 0) {   // HR row 4i+2 feeds output rows 4i+1..4i+3 only, none of them kept
                 deconv_row(i, Bf, ob);
                 conv_row(i, ob);
             }
+            if (produce && wv < 3) {
+                const u4 nv = row_value(nxt, i + 3);
+                if (lr_loader) *reinterpret_cast<u4*>(lrr + lr_slot(i + 3) + lr_st) = nv;   // over row i: read above the barrier
+            }
         }
-        if (produce && wv < 3) {
-            const u4 nv = row_value(nxt, i + 3);
-            if (lr_loader) *reinterpret_cast<u4*>(lrr + lr_slot(i + 3) + lr_st) = nv;   // over row i: read above the barrier
+    } else {
+        // ---- full frames: the march as a software pipeline.  Step i = BARRIER [A: deconv of column phases 0,1 of G(i) || PReLU of
+        //      phases 2,3 of G(i-1)] [C: the 3x3 over G(i-1) (+ FOLD: the 1x1 of LR row i+3) || its DPP shifts, the finish of output
+        //      row 4i-7+wv] [B: deconv of phases 2,3 of G(i) || PReLU of phases 0,1 of G(i), partial stores, LR row i+3, the next
+        //      step's LR operands]: every VALU / LDS / memory instruction sits in the gap of an MFMA, one instruction stream written
+        //      out slot by slot as k_utd3's.  (Before: deconv + PReLU 2000 cycles, 3x3 + DPP 700, partial stores 400, LR operands +
+        //      barrier 390, FOLD 390 per step, one after the other: 3880 for 92 MFMAs.)
+        //      Carried between steps: ob[0..1] (activated tiles of phases 0,1 of G(i-1)), accB (raw deconv accumulators of its
+        //      phases 2,3), Bf tiles 0..2 of rows i, i+1 (tile 3 reads row i's slot, rewritten in step i: loaded above the barrier),
+        //      the LR pieces of row i+3 (requested a step ahead).
+        h8 ob[4][2], Bf[4][2];
+        f4 accB[2][2][2];
+        {
+            h8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) ob[px][nt] = z;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) accB[c][mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        bool colok[4][2];
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
+                colok[px][nt] = (c_hr >= 0) && (c_hr < W);
+            }
+        const bool edge_strip = (x0 == 0) || (4 * (x0 + 32) - 2 >= W);
+        int s0 = lr_slot(r0 - 1), s1 = lr_slot(r0), s2 = lr_slot(r0 + 1);   // LDS slots of LR rows i, i+1, i+2
+        auto lr_tile = [&](int t, int nt, int s_lo, int s_hi) __attribute__((always_inline)) {   // tile t of the rows in slots (s_lo, s_hi)
+            Bf[t][nt] = *reinterpret_cast<const h8*>(lrr + ((t >> 1) ? s_lo : s_hi) + lr_b[t & 1][nt]);
+        };
+        // the steady state stores its LR piece unconditionally: the lanes without one into a pad behind the rows
+        const int lr_st_all = lr_loader ? lr_st : LR_BYTES + 256 + 16 * tid;
+        float* const pf_n = prefc + (size_t)n * 3 * H * W;
+        const __amdgpu_buffer_rsrc_t pf_rsrc = __builtin_amdgcn_make_buffer_rsrc(pf_n, 0, (int)((size_t)3 * H * W * 4), 0x00020000);
+        const h2 hz = {(_Float16)0.0f, (_Float16)0.0f};
+        const bool st_any[2] = {__builtin_amdgcn_ballot_w64(okq[0]) != 0, __builtin_amdgcn_ballot_w64(okq[1]) != 0};
+        RawRow nxt = fetch_lr(r0 + 2);
+        unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+        const unsigned long long rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0, ct0 = DIAG ? __builtin_amdgcn_s_memtime() : 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) lr_tile(t, nt, s0, s1);
+
+        // A row outside the steady state (first rows of a segment, rows below the image, the two finishing steps): same state,
+        // building blocks one after the other
+        auto step_plain = [&](int i) __attribute__((always_inline)) {
+            const RawRow cur = nxt;
+            nxt = fetch_lr(i + 4);
+            const bool produce = i <= r1 - 1;
+            __syncthreads();
+            finish_row(4 * i - 7 + wv);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    h8 hb = act_pack(accB[c][0][nt], accB[c][1][nt], a_up2, up_max);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hb[e] = colok[2 + c][nt] ? hb[e] : (_Float16)0.0f;
+                    ob[2 + c][nt] = hb;
+                }
+            if (i >= r0 && i <= r1) conv_row(i - 1, ob);
+            const int r_hr = 4 * i + 2 + wv;
+            if (produce && r_hr >= 0 && r_hr < H) {
+                f4 accA[2][2][2];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) dmf(0, k, Bf, accA);
+#pragma unroll
+                for (int k = 0; k < 32; ++k) dmf(1, k, Bf, accB);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        h8 hb = act_pack(accA[c][0][nt], accA[c][1][nt], a_up2, up_max);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hb[e] = colok[c][nt] ? hb[e] : (_Float16)0.0f;
+                        ob[c][nt] = hb;
+                    }
+            } else {   // (the conv's zero padding: zeros stay zeros through the PReLU)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ob[c][nt][e] = (_Float16)0.0f;
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) accB[c][mt][nt] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+            }
+            if (produce && wv < 3) {
+                const u4 nv = row_value(cur, i + 3);
+                if (lr_loader) *reinterpret_cast<u4*>(lrr + s0 + lr_st) = nv;   // over row i: its readers are above the barrier
+            }
+            const int t = s0; s0 = s1; s1 = s2; s2 = t;
+            // the next step's LR operands (tile 3 reads row i+1's slot, rewritten below the NEXT barrier: read here, above it)
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) lr_tile(t2, nt, s0, s1);
+        };
+
+        auto dmf3 = [&](int half, int k, const h8 (&b3)[2], f4 (&acc)[2][2][2]) __attribute__((always_inline)) {
+            const int c = k >> 4, t = (k >> 2) & 3, mt = (k >> 1) & 1, nt = k & 1;
+            acc[c][mt][nt] = mfma16(Aup[2 * half + c][t][mt], t == 3 ? b3[nt] : Bf[t][nt], t == 0 ? bup[mt] : acc[c][mt][nt]);
+        };
+        // (two steps per loop trip: the requested LR pieces and tile 3 of the LR operands alternate between two register sets --
+        // carried in one set they cost 8 v_mov_b64 behind a wait for the newest requests at the loop end and an LDS round trip
+        // in front of the barrier: ~200 of 2990 cycles per step)
+        auto step_steady = [&](int i, auto edgec, const RawRow& cur, RawRow& nx, const h8 (&b3)[2], h8 (&b3n)[2]) __attribute__((always_inline)) {
+            constexpr bool EDGE = decltype(edgec)::value;
+            constexpr int SU = EDGE ? 16 : 12;     // stages of a PReLU unit: 12 + the 4 column selects of an edge strip
+            constexpr int NC = FOLD ? 28 : 24;     // MFMA slots of region C
+            constexpr int QS = FOLD ? 12 : 8;      // first slot of the finish sums (after the LDS latency of the plane reads in slots 0..5)
+            constexpr int ND = FOLD ? 16 : 12;     // slots its 16 DPP moves are spread over (done before the shifted tiles' MFMAs)
+            const unsigned long long t0 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+            nx = fetch_lr(i + 4);
+            const unsigned long long t1 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+            __syncthreads();
+            const unsigned long long t2 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+            f4 accA[2][2][2], cacc[4][2], fs[2][3], facc[2];
+            float fr[2][3];
+            ActU u23[4], u01[4], uf;
+            u4v shl0, shl1, shr0, shr1;
+            const int Rfin = 4 * i - 7 + wv;
+            const unsigned char* const fsrc = pb + ((Rfin & (T3_ROWS - 1)) * 3) * T3_PLANE;
+            VSR_FENCE();
+            // ---- A: deconv of phases 0,1 of G(i) || PReLU of phases 3, 2 of G(i-1) (+ FOLD: bias + constant map of LR row i+3)
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                dmf3(0, s, b3, accA);
+#pragma unroll
+                for (int v = (s * 4 * SU) / 32; v < ((s + 1) * 4 * SU) / 32; ++v) {
+                    const int u = v / SU, st = v % SU, c = 1 - (u >> 1), nt = u & 1;
+                    if (st < 12) act_stage_p(u23[u], st, accB[c][0][nt], accB[c][1][nt], a_up2, up_max);
+                    else { u23[u].r[st - 12] = colok[2 + c][nt] ? u23[u].r[st - 12] : hz; asm volatile("" : : "v"(u23[u].r[st - 12])); }
+                    if (st == SU - 1) ob[2 + c][nt] = act_result(u23[u]);
+                }
+                if (FOLD && s >= 28) {
+                    const int mt = (s - 28) >> 1, hf = (s - 28) & 1;
+                    const f4 cm = __builtin_bit_cast(f4, mt ? cur.c1 : cur.c0);
+                    if (hf == 0) { facc[mt][0] = bco[mt][0] + cm[0]; facc[mt][1] = bco[mt][1] + cm[1]; }
+                    else { facc[mt][2] = bco[mt][2] + cm[2]; facc[mt][3] = bco[mt][3] + cm[3]; }
+                }
+                VSR_FENCE();
+            }
+            const unsigned long long t3 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+            // ---- C: the 3x3 over G(i-1): tiles of output column phases 1,2 first (no shifted operand), then 0,3
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                int k = q;   // conv MFMA index, or -1 - j for the FOLD MFMA j
+                if (FOLD) k = q < 2 ? -1 - q : (q < 4 ? q - 2 : (q < 6 ? -3 - (q - 4) : q - 4));
+                if (k < 0) {
+                    const int j = -1 - k, mt = j & 1, hf = j >> 1;
+                    facc[mt] = mfma16(Aco[hf][mt], __builtin_bit_cast(h8, hf ? cur.b : cur.a), facc[mt]);
+                } else {
+                    const int grp = k / 12, kk = k % 12, dx = kk >> 2, nt = kk & 1;
+                    const int pxo = grp == 0 ? 1 + ((kk >> 1) & 1) : (((kk >> 1) & 1) ? 3 : 0);
+                    const int ps = pxo + dx - 1;
+                    const h8 b = ps < 0 ? __builtin_bit_cast(h8, nt ? shr1 : shr0) : (ps > 3 ? __builtin_bit_cast(h8, nt ? shl1 : shl0) : ob[ps][nt]);
+                    cacc[pxo][nt] = mfma16(Ac[dx], b, dx == 0 ? f4{0.0f, 0.0f, 0.0f, 0.0f} : cacc[pxo][nt]);
+                }
+                // DPP moves: phase 0 one position to the right (shl: lane j reads j+1, lane 15 of tile 0 takes lane 0 of tile 1) for
+                // (pxo 3, dx 2), then phase 3 one position to the left (shr) for (pxo 0, dx 0)
+                if (q < ND) {
+#pragma unroll
+                    for (int d = (q * 16) / ND; d < ((q + 1) * 16) / ND; ++d) {
+                        const int e = d & 3;
+                        if (d < 4) shl1[e] = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(u4v, ob[0][1])[e], 0x12F, 0xF, 0xF, true);          // row_ror:15
+                        else if (d < 8) shl0[e] = __builtin_amdgcn_update_dpp(shl1[e], __builtin_bit_cast(u4v, ob[0][0])[e], 0x101, 0xF, 0xF, false);   // row_shl:1, lane 15 keeps tile1[0]
+                        else if (d < 12) shr0[e] = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(u4v, ob[3][0])[e], 0x121, 0xF, 0xF, true);    // row_ror:1
+                        else shr1[e] = __builtin_amdgcn_update_dpp(shr0[e], __builtin_bit_cast(u4v, ob[3][1])[e], 0x111, 0xF, 0xF, false);  // row_shr:1, lane 0 keeps tile0[15]
+                    }
+                }
+                // finish of output row Rfin: 6 partial-plane reads, 12 adds, 6 bias adds, 6 stores -- one a slot
+                if (q < 6) {
+                    const int u = lane + 64 * (q / 3);
+                    fs[q / 3][q % 3] = *reinterpret_cast<const f4*>(fsrc + (q % 3) * T3_PLANE + (u ^ ((u >> 3) & 3)) * 16);
+                } else if (q >= QS && q < QS + 12) {   // (plain floats: an asm operand that is an ext-vector ELEMENT was mis-compiled -- all three
+                    const int j = q - QS, qq = j / 6, p = 1 + (j % 6) / 3, ch = j % 3;   // channels of a pixel group stored channel 0's register)
+                    fr[qq][ch] = (p == 1 ? fs[qq][0][ch] : fr[qq][ch]) + fs[qq][p][ch];
+                    asm volatile("" : "+v"(fr[qq][ch]));
+                }
+                if (q >= NC - 4) {   // bias + stores of the row's two pixel groups in the last slots (and the first of B)
+                    const int j = q - (NC - 4);
+                    if (j < 2) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) { fr[j][ch] += bo[ch]; asm volatile("" : "+v"(fr[j][ch])); }
+                    } else if (!EDGE || st_any[j - 2]) {
+                        // lanes without an output pixel store to an out-of-range offset (dropped by the hardware).  A store with NO
+                        // lane in range is skipped as a whole (wave-uniform; last strip only): such a store can retire ahead of the
+                        // older LR-row loads, and the counted wait for those loads assumes it does not
+                        const int qq = j - 2;
+                        unsigned a0 = (unsigned)(((size_t)Rfin * W + cq[qq]) * 4);
+                        asm volatile("" : "+v"(a0));
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fr[qq][ch]), pf_rsrc, okq[qq] ? a0 + (unsigned)ch * (unsigned)(H * W * 4) : 0xFFFFFFFFu, 0, 0);
+                    }
+                }
+                // FOLD: PReLU of the 1x1's row (MFMAs in slots 0,1,4,5) + zero outside the image
+                if (FOLD && q >= 10 && q < 26) {
+                    const int st = q - 10;
+                    if (st < 12) act_stage_p(uf, st, facc[0], facc[1], a_co2, co_max);
+                    else {
+                        const bool ok = lr_col_ok && i + 3 < h;
+                        uf.r[st - 12] = ok ? uf.r[st - 12] : hz;
+                        asm volatile("" : : "v"(uf.r[st - 12]));
+                    }
+                }
+                VSR_FENCE();
+            }
+            // ---- B: deconv of phases 2,3 of G(i) || PReLU of its phases 0,1 (in place: the 3x3 has read the old tiles), partial
+            //      planes, LR row i+3 over row i, tiles 0..2 of the next step's LR operands as their last readers pass
+            const unsigned long long t4 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
+            const int Rp = 4 * (i - 1) + 2 + wv;
+            int pl3 = ((Rp + 1 - g) & (T3_ROWS - 1)) * 3 + g;
+            asm volatile("" : "+v"(pl3));   // (by every lane: as the arm of the select it was a branch in the middle of the step)
+            const int plane = g < 3 ? pl3 : T3_ROWS * 3;
+            unsigned char* const pdst = pb + plane * T3_PLANE + l15 * 64;
+            const int psw = (l15 >> 1) & 3;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                dmf3(1, s, b3, accB);
+#pragma unroll
+                for (int v = (s * 4 * SU) / 32; v < ((s + 1) * 4 * SU) / 32; ++v) {
+                    const int u = v / SU, st = v % SU, c = u >> 1, nt = u & 1;
+                    if (st < 12) act_stage_p(u01[u], st, accA[c][0][nt], accA[c][1][nt], a_up2, up_max);
+                    else { u01[u].r[st - 12] = colok[c][nt] ? u01[u].r[st - 12] : hz; asm volatile("" : : "v"(u01[u].r[st - 12])); }
+                    if (st == SU - 1) ob[c][nt] = act_result(u01[u]);
+                }
+                if (s < 16 && (s & 1) == 0) {   // rows 4 dy + co of a tile: lane groups 0..2 hold the three channels of one dy each (idle group 3 -> dump
+                    const int e = s >> 1;       // plane); every other slot: the four waves store in lockstep and share the LDS's store path
+                    const int pxo = e < 4 ? 1 + (e >> 1) : ((e >> 1) & 1 ? 3 : 0), nt = e & 1;
+                    typedef float f3 __attribute__((ext_vector_type(3)));
+                    *reinterpret_cast<f3*>(pdst + nt * 1024 + ((pxo ^ psw) << 4)) = f3{cacc[pxo][nt][0], cacc[pxo][nt][1], cacc[pxo][nt][2]};
+                }
+                if (s == 17) *reinterpret_cast<u4*>(lrr + s0 + lr_st_all) = FOLD ? __builtin_bit_cast(u4, act_result(uf)) : cur.a;
+                if (s >= 20 && (s & 3) < 2) lr_tile((s - 20) >> 2, s & 1, s1, s2);
+                if (s == 12 || s == 13) b3n[s - 12] = *reinterpret_cast<const h8*>(lrr + s1 + lr_b[1][s - 12]);   // tile 3 of step i+1: row i+1's slot
+                VSR_FENCE();
+            }
+            const int t = s0; s0 = s1; s1 = s2; s2 = t;
+            if (DIAG == 1) {
+                const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+                stamp[0] += t1 - t0; stamp[1] += t2 - t1; stamp[2] += t3 - t2; stamp[3] += t4 - t3; stamp[4] += t5 - t4; stamp[5] += 1;
+            }
+        };
+        auto march = [&](auto edgec) __attribute__((always_inline)) {
+            // (bounds per WAVE and said to be so; every step has one barrier on either path)
+            const int i_st = __builtin_amdgcn_readfirstlane(min(r0 + 2, r1 + 2));
+            const int i_en = __builtin_amdgcn_readfirstlane(max(i_st, min(r1, h - (wv >= 2 ? 1 : 0))));
+            int i = r0 - 1;
+            for (; i < i_st; ++i) step_plain(i);
+            if (i < i_en) {
+                RawRow rr0 = nxt, rr1 = nxt;
+                h8 b3a[2] = {Bf[3][0], Bf[3][1]}, b3b[2] = {Bf[3][0], Bf[3][1]};
+                for (; i + 1 < i_en; i += 2) {
+                    step_steady(i, edgec, rr0, rr1, b3a, b3b);
+                    step_steady(i + 1, edgec, rr1, rr0, b3b, b3a);
+                }
+                if (i < i_en) {
+                    step_steady(i, edgec, rr0, rr1, b3a, b3b);
+                    ++i;
+                    nxt = rr1; Bf[3][0] = b3b[0]; Bf[3][1] = b3b[1];
+                } else {
+                    nxt = rr0; Bf[3][0] = b3a[0]; Bf[3][1] = b3a[1];
+                }
+            }
+            for (; i <= r1 + 1; ++i) step_plain(i);
+        };
+        if (edge_strip) march(BoolC<true>{}); else march(BoolC<false>{});
+        if (DIAG && g_stamp_t3_ptr && lane == 0) {
+            unsigned long long* d = g_stamp_t3_ptr + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wv) * 8;
+            for (int k = 0; k < 6; ++k) d[k] = stamp[k];
+            d[6] = __builtin_amdgcn_s_memtime() - ct0;
+            d[7] = __builtin_amdgcn_s_memrealtime() - rt0;
         }
     }
 }
@@ -406,13 +640,19 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
 
 namespace vsr {
 
+static int g_t3_diag = 0;
+int tail3_set_stamps(void* buf, int totals_only) {
+    g_t3_diag = buf ? (totals_only ? 2 : 1) : 0;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_t3_ptr), &buf, sizeof(buf));
+}
+
 int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* prefc, int N,
                  int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream, const void* in2, const float* cmap) {
     typedef void (*kern_t)(const _Float16*, const _Float16*, const float*, const unsigned char*, const unsigned char*, const float*,
                            float*, int, int, int);
-    static const kern_t kerns[8] = {k_tail3<false, false, false>, k_tail3<true, false, false>, k_tail3<false, true, false>,
+    static const kern_t kerns[10] = {k_tail3<false, false, false>, k_tail3<true, false, false>, k_tail3<false, true, false>,
                                     k_tail3<true, true, false>,   k_tail3<false, false, true>, k_tail3<true, false, true>,
-                                    k_tail3<false, true, true>,   k_tail3<true, true, true>};
+                                    k_tail3<false, true, true>,   k_tail3<true, true, true>,   k_tail3<true, false, true, 1>, k_tail3<true, false, true, 2>};
     static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
     if (!vsr::device_marked(attr_devs)) {
         for (kern_t k : kerns)
@@ -423,7 +663,8 @@ int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags
     if ((size_t)N * h * w * NF * 2 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail3: input beyond 2 GiB");
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
     if (in2 && (size_t)h * w * NF * 4 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail3: constant map beyond 2 GiB");
-    hipLaunchKernelGGL(kerns[(in2 ? 4 : 0) + (dec ? 2 : 0) + (slopes_le_one ? 1 : 0)], dim3(strips, segs, N), dim3(256), T3_LDS, stream,
+    const int ki = (in2 ? 4 : 0) + (dec ? 2 : 0) + (slopes_le_one ? 1 : 0);
+    hipLaunchKernelGGL(kerns[g_t3_diag && ki == 5 ? 7 + g_t3_diag : ki], dim3(strips, segs, N), dim3(256), T3_LDS, stream,
                        (const _Float16*)hid_nhwc, (const _Float16*)in2, cmap, (const unsigned char*)blob,
                        (const unsigned char*)conv3_frags, tail_params, prefc, h, w, rows_per_seg);
     return vsr::launched("sr_tail3");

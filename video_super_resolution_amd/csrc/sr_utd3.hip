@@ -30,17 +30,6 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 
 #define VSR_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// act_stage with its result pinned to the MFMA gap it is written in (an empty asm is ordered against the gap's fences; the plain
-// stage is a pure value that instruction selection is free to sink to its first use -- seen: a unit's 12 stages behind the last MFMA)
-__device__ __forceinline__ void act_stage_p(ActU& u, int j, const f4& lo, const f4& hi, h2 a, bool use_max) {
-    act_stage(u, j, lo, hi, a, use_max);
-    // (an asm that only READS the value: "+v" would make it opaque, and the max of two opaque values is preceded by a quieting
-    // v_pk_max_f16 x, x of each)
-    if (j < 4) asm volatile("" : : "v"(u.c[j]));
-    else if (j < 8) asm volatile("" : : "v"(u.m[j - 4]));
-    else asm volatile("" : : "v"(u.r[j - 8]));
-}
-
 constexpr int UTD3_LR_PAD = 2 * LR_SLOT + 16 * (256 - LR_COLS * 4);   // where the lanes without an LR piece store (slot offset + lane)
 constexpr int UTD3_LDS = PART_BYTES + LR_BYTES + UTD3_LR_PAD;   // no HR ring: the x4 map never leaves the registers
 
