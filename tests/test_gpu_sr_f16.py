@@ -297,6 +297,41 @@ def test_shared_planes_bit_identical(gpu_vsr_f16, shape, decimate_first):
         assert torch.equal(m(c, shared=shared), m(c))
 
 
+@pytest.mark.parametrize("shape", [(16, 16), (9, 40), (37, 33)])
+@pytest.mark.parametrize("scale", [4, 2])
+def test_precomputed_planes_bit_identical(shape, scale):
+    """`precompute_shared`: the FeedbackBlock maps of the first three planes evaluated AHEAD of the calls that use them (VSR.forward
+    does so on a side stream beside the guidance trunks); both later calls compute their other five planes only and must return
+    exactly the frames of full evaluations -- also when the precompute ran on another stream."""
+    from video_super_resolution_amd import SRProjectionModule
+    from video_super_resolution_amd.weights import fill_module_
+    m = fill_module_(SRProjectionModule(upscale_factor=scale).eval(), seed=0, prefix="model.").cuda()
+    h, w = shape
+    rs = np.random.RandomState(h * 23 + w + scale)
+    a = torch.from_numpy(rs.randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    b = a.clone()
+    b[3:] = torch.from_numpy(rs.randint(0, 256, (5, 3, h, w)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        ref_a, ref_b = m(a, decimate=True), m(b)
+        for side in (False, True):
+            shared = {"n": 3}
+            live = {k: torch.empty((8, h * w, 32), dtype=torch.float16, device="cuda") for k in (3, 6)}
+            first = a[:3].contiguous()
+            if side:
+                st = torch.cuda.Stream()
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    m.precompute_shared(first, shared, live)
+                torch.cuda.current_stream().wait_stream(st)
+            else:
+                m.precompute_shared(first, shared, live)
+            assert shared.get("live") is not None
+            assert torch.equal(m(a, decimate=True, shared=shared), ref_a)
+            assert torch.equal(m(b, shared=shared), ref_b)
+    with pytest.raises(ValueError):
+        m.precompute_shared(a[:2].contiguous(), {"n": 3}, live)
+
+
 def test_shared_planes_scale2():
     from video_super_resolution_amd import SRProjectionModule
     from video_super_resolution_amd.weights import fill_module_

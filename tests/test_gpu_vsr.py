@@ -164,6 +164,31 @@ def test_headline_fp16_configuration_end_to_end(golden, gpu_vsr_f16):
         assert psnr > PSNR255_BAR and psnr_sig > PSNR_SIGNAL_BAR and p99 < P99_BAR, (psnr, psnr_sig, p99)
 
 
+def test_lr_frame_planes_beside_the_guidance_trunks(gpu_vsr_f16):
+    """VSR.overlap_shared (default on, fp16 configuration): the FeedbackBlock maps of the three LR-frame planes are evaluated on a
+    side stream while the guidance trunks of pass 1 run; the recurrent frames must equal those of the serial order (the same
+    kernels on the same values: planes are independent up to the fusion MLP), and those of the evaluation without plane sharing."""
+    import copy
+    m = copy.deepcopy(gpu_vsr_f16)
+    assert m.overlap_shared and m.share_planes
+    clip = torch.from_numpy(np.random.RandomState(9).randint(0, 256, (5, 66, 70, 3)).astype(np.float32)).cuda()
+
+    def run(overlap, share=True):
+        m.overlap_shared, m.share_planes = overlap, share
+        est, outs = None, []
+        for t in range(3):
+            est, _ = m(clip[t:t + 3], None, None, est, train=False)
+            outs.append(est.clone())
+        torch.cuda.synchronize()
+        return outs
+    try:
+        ref, got, plain = run(False), run(True), run(False, share=False)
+    finally:
+        m.overlap_shared, m.share_planes = True, True
+    for a, b, c in zip(got, ref, plain):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_streaming_mode_matches_per_window_evaluation(gpu_vsr_f16):
     """VSR.temporal_cache (opt-in): depth predictions / flow pictures of the two frames consecutive windows share are kept
     across calls.  Same networks on the same frames, but the trunks then run on batches of 1-2 instead of 2-4 frames and the

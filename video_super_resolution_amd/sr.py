@@ -120,6 +120,9 @@ class SRProjectionModule(nn.Module):
         # "fp32": every product and sum in float32 (the parity configuration, ~60x slower).
         self.precision = "fp16"
         self.tail_build = 3   # 3: k_tail3 (csrc/sr_tail3.hip); 1: k_tail (LDS ring; kept as the cross-check)
+        # CUs the fused-stage launches of `precompute_shared` are segmented for: they run beside the guidance trunks and take a CU each
+        # (tools/overlap_ab.py at 540x960: 24.3 ms per frame serial, 24.1 / 23.8-24.0 / 24.0 / 24.1 with 256 / 96 / 128 / 192)
+        self.precompute_cus = 96
         self._pack: Optional[dict] = None
         self._pack_key = None
         self._const: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -308,6 +311,31 @@ class SRProjectionModule(nn.Module):
             S = self.upscale_factor
             return out[..., ::S, ::S] if decimate else out
         return self._forward_kernels(x, taps, decimate, shared)
+
+    @L.on_device
+    @torch.no_grad()
+    def precompute_shared(self, x_first: torch.Tensor, shared: dict, live: dict) -> None:
+        """The FeedbackBlock maps of the FIRST `shared["n"]` planes of a later `forward(x, shared=shared)` call, computed ahead of
+        it: `x_first` [n,3,h,w] are those planes, `live` = {3: buf, 6: buf} the caller's [planes,h*w,32] half buffers the maps go
+        into (rows 0..n-1; the later calls write their own planes beside them).  The planes are independent up to the fusion
+        MLP, so VSR.forward runs this on a side stream next to the guidance trunks, which the LR frames do not depend on
+        (video_super_resolution.py:26-40): same kernels on the same values as the call that evaluated all planes at once
+        (tests/test_gpu_sr_f16.py::test_shared_planes_bit_identical, ::test_precomputed_planes_bit_identical)."""
+        if self.precision != "fp16" or self.block.num_groups != 6:
+            raise ValueError("precompute_shared: the fp16 configuration with six groups only")
+        n, _, h, w = x_first.shape
+        total = live[3].shape[0]
+        if n != int(shared.get("n", 0)) or not 0 < n < total:
+            raise ValueError(f"precompute_shared: {n} planes given, shared['n'] = {shared.get('n')}, {total} in all")
+        x = x_first.detach().float().contiguous()
+        P = self._packed()
+        cmap = self._const_map(P, h, w, x.device)
+        # (segmented for `precompute_cus` CUs, not the whole chip: the launches share it with the trunks they run beside)
+        self._utd_cus = int(getattr(self, "precompute_cus", 256))
+        try:
+            self._forward_f16(x, P, cmap, None, False, shared, precompute=live)
+        finally:
+            self._utd_cus = 256
 
     def _forward_autograd(self, x: torch.Tensor) -> torch.Tensor:
         """CROSS-CHECK ONLY (tests): the same graph on stock differentiable operators -- `forward` never calls it; the train
@@ -510,12 +538,12 @@ class SRProjectionModule(nn.Module):
         # (timer names carry the plane count when it is not the full 8: the roofline leg prices a launch by its planes)
         tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else ("sr_utd_f16" if N == 8 else f"sr_utd_f16_p{N}"))
         L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
-                                        self._rows_per_segment(N, h, w), int(deconv_only), int(self._pack["slopes_le_one"]),
+                                        self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256)), int(deconv_only), int(self._pack["slopes_le_one"]),
                                         L.stream()), "sr_utd_f16")
         L.TIMER.stop(tok)
         return out
 
-    def _forward_f16(self, x, P, cmap, taps, decimate=False, shared=None):
+    def _forward_f16(self, x, P, cmap, taps, decimate=False, shared=None, precompute=None):
         """`shared` (a dict owned by the caller, {"n": k}): the network treats its planes independently up to the fusion
         MLP, so when two calls have their first k planes in common -- the three LR frames in both SR passes of
         VSR.forward, video_super_resolution.py:40,62 -- the FeedbackBlock maps of those planes are computed by the first
@@ -528,8 +556,13 @@ class SRProjectionModule(nn.Module):
         G = self.block.num_groups
         hp = h * w
         n0 = 0
-        share_ok = shared is not None and taps is None and G == 6 and 0 < int(shared.get("n", 0)) < N_all
-        skey = (self._pack_key, h, w, N_all, self.upscale_factor)
+        if precompute is not None:   # `x` = the first planes only; their maps go to rows 0.. of the caller's buffers (precompute_shared)
+            N_tot = precompute[3].shape[0]
+            share_ok = False
+            skey = (self._pack_key, h, w, N_tot, self.upscale_factor)
+        else:
+            share_ok = shared is not None and taps is None and G == 6 and 0 < int(shared.get("n", 0)) < N_all
+            skey = (self._pack_key, h, w, N_all, self.upscale_factor)
         if share_ok and shared.get("live") is not None and shared.get("key") == skey:
             n0 = int(shared["n"])
         x_all, x = x, (x[n0:] if n0 else x)
@@ -577,12 +610,17 @@ class SRProjectionModule(nn.Module):
                     a = self._chain([ut(j, live[j])], N, hp, keep=[True])[0]
                 # (the last step of a call that shares planes writes beside the kept maps of the first call)
                 dst = shared["live"][j + 3][n0:].view(N, h, w, _NF) if (n0 and step == self.num_steps - 1) else None
+                if precompute is not None and step == self.num_steps - 1:
+                    dst = precompute[j + 3][:N].view(N, h, w, _NF)
                 live[j + 3] = (self._utd(a, P["utd"][j], N, h, w, out=dst) if self.upscale_factor == 4 else
                                P["stage"][j](a.view(N, h, w, _NF), self._chain, out=dst)).view(N, hp, _NF)
                 j += 3
             if taps is not None and step == self.num_steps - 1:
                 for k, v in live.items():
                     taps[f"lr{k}"] = nchw(v)
+        if precompute is not None:
+            shared.update(live={k: precompute[k] for k in (3, 6)}, key=skey)
+            return None
         if n0:
             live = {k: shared["live"][k] for k in (3, 6)}
             N, x = N_all, x_all

@@ -66,6 +66,7 @@ class VSR(nn.Module):
         # "fp32": SR stack in exact float32 kernels, trunks on stock float32 convolutions (the parity configuration).
         self.precision = "fp16"
         self.share_planes = True   # evaluate the three LR-frame planes once per forward (both SR passes read them)
+        self.overlap_shared = True  # ... and do so on a side stream beside the guidance trunks of pass 1 (fp16 configuration)
         # Opt-in streaming mode (OFF by default; the headline benchmark leaves it off): consecutive windows of a clip share
         # two of their three LR frames (utils/video_utils.py:25), so the depth prediction of a frame and the flow picture of a
         # frame pair computed for window t are what window t+1 computes again.  With temporal_cache = True they are kept
@@ -133,7 +134,7 @@ class VSR(nn.Module):
     def _side_streams(self, dev):
         key = (dev.type, dev.index)
         if getattr(self, "_streams_key", None) != key:
-            self._streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
             self._streams_key = key
         return self._streams
 
@@ -148,7 +149,7 @@ class VSR(nn.Module):
         h, w = trip[0].shape[:2]
         fast = self._fast()
         main = torch.cuda.current_stream(trip[0].device)
-        s_depth, s_vos = self._side_streams(trip[0].device) if fast else (main, main)
+        s_depth, s_vos = self._side_streams(trip[0].device)[:2] if fast else (main, main)
         if fast:
             s_depth.wait_stream(main)
             s_vos.wait_stream(main)
@@ -238,14 +239,31 @@ class VSR(nn.Module):
                 from . import _lib as L
                 L.check(L.load().vsr_resize_estimate_f32(L.dptr(prev), prev.shape[1], prev.shape[2], L.dptr(est), L.dptr(est_hw3), h, w,
                                                          L.stream()), "resize_estimate")
+            self.model.precision = self.precision
+            # planes 0-2 of both SR calls are the LR frames themselves (:33, :57: `data` NHWC -> NCHW): their FeedbackBlock maps
+            # depend on nothing the guidance trunks produce, so they are evaluated NOW, on a side stream, next to those trunks
+            # (whose low-resolution layers leave most CUs idle); both SR calls then run head + FeedbackBlock on planes 3-7 only
+            shared = {"n": 3} if self.share_planes else None
+            s_sr = None
+            if shared is not None and self.overlap_shared and self._fast() and self.model.block.num_groups == 6:
+                main = torch.cuda.current_stream(d.device)
+                x_first = d.permute(0, 3, 1, 2).contiguous()
+                live = {k: torch.empty((8, h * w, 32), dtype=torch.float16, device=d.device) for k in (3, 6)}
+                s_sr = self._side_streams(d.device)[2]
+                s_sr.wait_stream(main)
+                with torch.cuda.stream(s_sr):
+                    self.model.precompute_shared(x_first, shared, live)
+                x_first.record_stream(s_sr)
+                for t in live.values():
+                    t.record_stream(s_sr)
             # (the estimate's depth is only used in pass 2 but is already known: batched with the three frames)
             pics, z, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,), cacheable=True)
-            self.model.precision = self.precision
+            if s_sr is not None:
+                torch.cuda.current_stream(d.device).wait_stream(s_sr)
             # pass 1's frame is only ever read through the nearest x1/4 resize of :44, i.e. at its pixels (4i,4j): the SR
             # stack evaluates its tail and fusion MLP at exactly those (identical values, 1/16 of the tail work)
             # planes 0-2 (the LR frames) are the same in both SR calls (:40, :62): their FeedbackBlock maps are computed here
             # and kept for pass 2 (sr.py:_forward_f16 `shared`; identical values, 3/8 of pass 2's trunk not recomputed)
-            shared = {"n": 3} if self.share_planes else None
             mid = self.model(self._assemble(d, pics, z, est), decimate=True, shared=shared)[0]  # [3,h,w] = F.interpolate(out1,(h,w))[0]
 
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
