@@ -326,28 +326,8 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
     }
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0);
-    if constexpr (DEC) {
-        // ---- decimated pass: groups G(r0-1) .. G(r1-1), then two more steps that only finish rows
-        for (int i = r0 - 1; i <= r1 + 1; ++i) {
-            const bool produce = i <= r1 - 1;
-            const RawRow nxt = fetch_lr(i + 3);
-            h8 Bf[4][2], ob[4][2];
-            if (produce) load_lr_frags(lr_slot(i), lr_slot(i + 1), Bf);
-            __syncthreads();
-            // rows whose last contribution was stored two steps ago (visible since the previous barrier; their planes are
-            // not rewritten before step i+2)
-            finish_row(4 * i - 7 + wv);
-            if (produce && wv != 0) {   // HR row 4i+2 feeds output rows 4i+1..4i+3 only, none of them kept
-                deconv_row(i, Bf, ob);
-                conv_row(i, ob);
-            }
-            if (produce && wv < 3) {
-                const u4 nv = row_value(nxt, i + 3);
-                if (lr_loader) *reinterpret_cast<u4*>(lrr + lr_slot(i + 3) + lr_st) = nv;   // over row i: read above the barrier
-            }
-        }
-    } else {
-        // ---- full frames: the march as a software pipeline.  Step i = BARRIER [A: deconv of column phases 0,1 of G(i) || PReLU of
+    {
+        // ---- the march as a software pipeline (full frames; the decimated pass has its own steady step, step_dec, below).  Step i = BARRIER [A: deconv of column phases 0,1 of G(i) || PReLU of
         //      phases 2,3 of G(i-1)] [C: the 3x3 over G(i-1) (+ FOLD: the 1x1 of LR row i+3) || its DPP shifts, the finish of output
         //      row 4i-7+wv] [B: deconv of phases 2,3 of G(i) || PReLU of phases 0,1 of G(i), partial stores, LR row i+3, the next
         //      step's LR operands]: every VALU / LDS / memory instruction sits in the gap of an MFMA, one instruction stream written
@@ -388,8 +368,10 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         };
         // the steady state stores its LR piece unconditionally: the lanes without one into a pad behind the rows
         const int lr_st_all = lr_loader ? lr_st : LR_BYTES + 256 + 16 * tid;
-        float* const pf_n = prefc + (size_t)n * 3 * H * W;
-        const __amdgpu_buffer_rsrc_t pf_rsrc = __builtin_amdgcn_make_buffer_rsrc(pf_n, 0, (int)((size_t)3 * H * W * 4), 0x00020000);
+        const int Ho = DEC ? h : H, Wo = DEC ? w : W;   // the planes written: [N,3,h,w] in the decimated pass
+        float* const pf_n = prefc + (size_t)n * 3 * Ho * Wo;
+        const __amdgpu_buffer_rsrc_t pf_rsrc = __builtin_amdgcn_make_buffer_rsrc(pf_n, 0, (int)((size_t)3 * Ho * Wo * 4), 0x00020000);
+        bool p2act = false;   // DEC: phase 2 of the carried group is already activated (ob[2]); accB[0] is then not its accumulator
         const h2 hz = {(_Float16)0.0f, (_Float16)0.0f};
         const bool st_any[2] = {__builtin_amdgcn_ballot_w64(okq[0]) != 0, __builtin_amdgcn_ballot_w64(okq[1]) != 0};
         RawRow nxt = fetch_lr(r0 + 2);
@@ -409,7 +391,8 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
             __syncthreads();
             finish_row(4 * i - 7 + wv);
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c) {
+                if (DEC && c == 0 && p2act) continue;   // (wave-uniform: the decimated steady step leaves phase 2 activated)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     h8 hb = act_pack(accB[c][0][nt], accB[c][1][nt], a_up2, up_max);
@@ -417,6 +400,8 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
                     for (int e = 0; e < 8; ++e) hb[e] = colok[2 + c][nt] ? hb[e] : (_Float16)0.0f;
                     ob[2 + c][nt] = hb;
                 }
+            }
+            p2act = false;
             if (i >= r0 && i <= r1) conv_row(i - 1, ob);
             const int r_hr = 4 * i + 2 + wv;
             if (produce && r_hr >= 0 && r_hr < H) {
@@ -461,7 +446,7 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
             const int c = k >> 4, t = (k >> 2) & 3, mt = (k >> 1) & 1, nt = k & 1;
             acc[c][mt][nt] = mfma16(Aup[2 * half + c][t][mt], t == 3 ? b3[nt] : Bf[t][nt], t == 0 ? bup[mt] : acc[c][mt][nt]);
         };
-        // (two steps per loop trip: the requested LR pieces and tile 3 of the LR operands alternate between two register sets --
+        // (three steps per loop trip: the requested LR pieces and tile 3 of the LR operands rotate through three register sets --
         // carried in one set they cost 8 v_mov_b64 behind a wait for the newest requests at the loop end and an LDS round trip
         // in front of the barrier: ~200 of 2990 cycles per step)
         auto step_steady = [&](int i, auto edgec, const RawRow& cur, RawRow& nx, const h8 (&b3)[2], h8 (&b3n)[2]) __attribute__((always_inline)) {
@@ -471,7 +456,7 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
             constexpr int QS = FOLD ? 12 : 8;      // first slot of the finish sums (after the LDS latency of the plane reads in slots 0..5)
             constexpr int ND = FOLD ? 16 : 12;     // slots its 16 DPP moves are spread over (done before the shifted tiles' MFMAs)
             const unsigned long long t0 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
-            nx = fetch_lr(i + 4);
+            nx = fetch_lr(i + 5);   // (two steps ahead: a step is shorter than a loaded HBM round trip)
             const unsigned long long t1 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
             __syncthreads();
             const unsigned long long t2 = DIAG == 1 ? __builtin_amdgcn_s_memtime() : 0;
@@ -603,6 +588,132 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
                 stamp[0] += t1 - t0; stamp[1] += t2 - t1; stamp[2] += t3 - t2; stamp[3] += t4 - t3; stamp[4] += t5 - t4; stamp[5] += 1;
             }
         };
+        // ---- decimated pass (DEC): only output pixels (4i, 4j) are kept, i.e. output rows R = 0 (mod 4) and column phase 2 of the 3x3:
+        //      HR rows 4i+2+wv with wv = 1,2,3 feed a kept row (wave 0's does not: it only processes the LR rows), the deconv needs
+        //      phases 1,2,3 (48 MFMAs), the 3x3 six, and only wave 3 finishes rows (R = 4i-4).  Step i = BARRIER [A: deconv of phase
+        //      1 of G(i) || PReLU of phase 3 of G(i-1)] [C: FOLD 1x1 of LR row i+3, the 3x3 over G(i-1) || finish of row 4i-4
+        //      (wave 3)] [B: deconv of phases 2,3 || PReLU of phases 1, 2 of G(i) in place, two partial stores, LR row store, LR
+        //      operands].  Carried: ob[1], ob[2] activated, accB[1] = the raw accumulators of phase 3.  (The round-2 march ran
+        //      these one after the other: ~2500 cycles per step for 58 MFMAs.)
+        auto step_dec = [&](int i, auto edgec, auto finc, const RawRow& cur, RawRow& nx, const h8 (&b3)[2], h8 (&b3n)[2]) __attribute__((always_inline)) {
+            constexpr bool EDGE = decltype(edgec)::value, FIN = decltype(finc)::value;
+            constexpr int SU = EDGE ? 16 : 12;
+            constexpr int NC = FOLD ? 10 : 6;
+            nx = fetch_lr(i + 5);
+            __syncthreads();
+            f4 accA[2][2][2], cacc[2], fs[2][3], facc[2];
+            float fr[2][3];
+            ActU u3[2], u12[4], uf;
+            const int Rfin = 4 * i - 7 + wv;   // FIN (wave 3): 4i - 4
+            const unsigned char* const fsrc = pb + ((Rfin & (T3_ROWS - 1)) * 3) * T3_PLANE;
+            VSR_FENCE();
+            // ---- A: 16 MFMAs (deconv of phase 1) || PReLU of phase 3 of G(i-1); FOLD: bias + constant map of LR row i+3
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                dmf3(0, 16 + s, b3, accA);
+#pragma unroll
+                for (int v = (s * 2 * SU) / 16; v < ((s + 1) * 2 * SU) / 16; ++v) {
+                    const int nt = v / SU, st = v % SU;
+                    if (st < 12) act_stage_p(u3[nt], st, accB[1][0][nt], accB[1][1][nt], a_up2, up_max);
+                    else { u3[nt].r[st - 12] = colok[3][nt] ? u3[nt].r[st - 12] : hz; asm volatile("" : : "v"(u3[nt].r[st - 12])); }
+                    if (st == SU - 1) ob[3][nt] = act_result(u3[nt]);
+                }
+                if (FOLD && s >= 12) {
+                    const int mt = (s - 12) >> 1, hf = (s - 12) & 1;
+                    const f4 cm = __builtin_bit_cast(f4, mt ? cur.c1 : cur.c0);
+                    if (hf == 0) { facc[mt][0] = bco[mt][0] + cm[0]; facc[mt][1] = bco[mt][1] + cm[1]; }
+                    else { facc[mt][2] = bco[mt][2] + cm[2]; facc[mt][3] = bco[mt][3] + cm[3]; }
+                }
+                VSR_FENCE();
+            }
+            // ---- C: FOLD MFMAs and the six 3x3 MFMAs (output column phase 2: deconv phases 1,2,3 as they lie)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                int k = q;
+                if (FOLD) k = q < 2 ? -1 - q : (q < 4 ? q - 2 : (q < 6 ? -3 - (q - 4) : q - 4));
+                if (k < 0) {
+                    const int j = -1 - k, mt = j & 1, hf = j >> 1;
+                    facc[mt] = mfma16(Aco[hf][mt], __builtin_bit_cast(h8, hf ? cur.b : cur.a), facc[mt]);
+                } else {
+                    const int dx = k >> 1, nt = k & 1;
+                    cacc[nt] = mfma16(Ac[dx], ob[1 + dx][nt], dx == 0 ? f4{0.0f, 0.0f, 0.0f, 0.0f} : cacc[nt]);
+                }
+                if (FIN && q < 6) {
+                    const int u = lane + 64 * (q / 3);
+                    fs[q / 3][q % 3] = *reinterpret_cast<const f4*>(fsrc + (q % 3) * T3_PLANE + (u ^ ((u >> 3) & 3)) * 16);
+                }
+                if (FOLD && q >= 6) {   // PReLU of the 1x1's row, first stages (the rest rides in B)
+#pragma unroll
+                    for (int st = (q - 6) * 2; st < (q - 6) * 2 + 2; ++st) act_stage_p(uf, st, facc[0], facc[1], a_co2, co_max);
+                }
+                VSR_FENCE();
+            }
+            // ---- B: 32 MFMAs (deconv of phases 2,3) || PReLU of phases 1 and 2 of G(i), finish sums + stores (wave 3), stores
+            const int Rp = 4 * (i - 1) + 2 + wv;
+            int pl3 = ((Rp + 1 - g) & (T3_ROWS - 1)) * 3 + g;
+            asm volatile("" : "+v"(pl3));
+            const int plane = g < 3 ? pl3 : T3_ROWS * 3;
+            unsigned char* const pdst = pb + plane * T3_PLANE + l15 * 64;
+            const int psw = (l15 >> 1) & 3;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                dmf3(1, s, b3, accB);
+                // phase 1 (from accA[1]) in slots 0..15, phase 2 (accB[0], complete after slot 15) in slots 16..31
+#pragma unroll
+                for (int v = ((s & 15) * 2 * SU) / 16; v < (((s & 15) + 1) * 2 * SU) / 16; ++v) {
+                    const int nt = v / SU, st = v % SU, ph = s < 16 ? 1 : 2, u = 2 * (ph - 1) + nt;
+                    const f4& lo = ph == 1 ? accA[1][0][nt] : accB[0][0][nt];
+                    const f4& hi = ph == 1 ? accA[1][1][nt] : accB[0][1][nt];
+                    if (st < 12) act_stage_p(u12[u], st, lo, hi, a_up2, up_max);
+                    else { u12[u].r[st - 12] = colok[ph][nt] ? u12[u].r[st - 12] : hz; asm volatile("" : : "v"(u12[u].r[st - 12])); }
+                    if (st == SU - 1) ob[ph][nt] = act_result(u12[u]);
+                }
+                if (FOLD && s < 8) {   // the rest of the 1x1 row's PReLU (8 max stages / selects), then its store
+                    const int st = 8 + s;
+                    if (st < 12) act_stage_p(uf, st, facc[0], facc[1], a_co2, co_max);
+                    else {
+                        const bool ok = lr_col_ok && i + 3 < h;
+                        uf.r[st - 12] = ok ? uf.r[st - 12] : hz;
+                        asm volatile("" : : "v"(uf.r[st - 12]));
+                    }
+                }
+                if (s == 2 || s == 4) {   // the two partial tiles (column phase 2 of the output)
+                    const int nt = (s - 2) >> 1;
+                    typedef float f3 __attribute__((ext_vector_type(3)));
+                    *reinterpret_cast<f3*>(pdst + nt * 1024 + ((2 ^ psw) << 4)) = f3{cacc[nt][0], cacc[nt][1], cacc[nt][2]};
+                }
+                if (s == 9) *reinterpret_cast<u4*>(lrr + s0 + lr_st_all) = FOLD ? __builtin_bit_cast(u4, act_result(uf)) : cur.a;
+                if (FIN) {
+                    if (s >= 6 && s < 18) {
+                        const int j = s - 6, qq = j / 6, p = 1 + (j % 6) / 3, ch = j % 3;
+                        fr[qq][ch] = (p == 1 ? fs[qq][0][ch] : fr[qq][ch]) + fs[qq][p][ch];
+                        asm volatile("" : "+v"(fr[qq][ch]));
+                    } else if (s == 18 || s == 19) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) { fr[s - 18][ch] += bo[ch]; asm volatile("" : "+v"(fr[s - 18][ch])); }
+                    } else if ((s == 20 || s == 21) && (!EDGE || st_any[s - 20])) {
+                        const int qq = s - 20;
+                        unsigned a0 = (unsigned)(((size_t)(Rfin >> 2) * w + (cq[qq] >> 2)) * 4);
+                        asm volatile("" : "+v"(a0));
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fr[qq][ch]), pf_rsrc, okq[qq] ? a0 + (unsigned)ch * (unsigned)(h * w * 4) : 0xFFFFFFFFu, 0, 0);
+                    }
+                }
+                if (s >= 20 && (s & 3) < 2) lr_tile((s - 20) >> 2, s & 1, s1, s2);
+                if (s == 12 || s == 13) b3n[s - 12] = *reinterpret_cast<const h8*>(lrr + s1 + lr_b[1][s - 12]);
+                VSR_FENCE();
+            }
+            const int t = s0; s0 = s1; s1 = s2; s2 = t;
+        };
+        // wave 0 of the decimated pass: its HR row feeds no kept pixel; it only turns LR row i+3 into its LDS form
+        auto step_dec_w0 = [&](int i, const RawRow& cur, RawRow& nx) __attribute__((always_inline)) {
+            nx = fetch_lr(i + 5);
+            __syncthreads();
+            const u4 nv = row_value(cur, i + 3);
+            *reinterpret_cast<u4*>(lrr + s0 + lr_st_all) = nv;
+            const int t = s0; s0 = s1; s1 = s2; s2 = t;
+        };
         auto march = [&](auto edgec) __attribute__((always_inline)) {
             // (bounds per WAVE and said to be so; every step has one barrier on either path)
             const int i_st = __builtin_amdgcn_readfirstlane(min(r0 + 2, r1 + 2));
@@ -610,18 +721,44 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
             int i = r0 - 1;
             for (; i < i_st; ++i) step_plain(i);
             if (i < i_en) {
-                RawRow rr0 = nxt, rr1 = nxt;
-                h8 b3a[2] = {Bf[3][0], Bf[3][1]}, b3b[2] = {Bf[3][0], Bf[3][1]};
-                for (; i + 1 < i_en; i += 2) {
-                    step_steady(i, edgec, rr0, rr1, b3a, b3b);
-                    step_steady(i + 1, edgec, rr1, rr0, b3b, b3a);
-                }
-                if (i < i_en) {
-                    step_steady(i, edgec, rr0, rr1, b3a, b3b);
-                    ++i;
-                    nxt = rr1; Bf[3][0] = b3b[0]; Bf[3][1] = b3b[1];
+                // three register sets for the requested LR pieces (rows i+3, i+4 in flight, i+5 requested by step i) and for operand
+                // tile 3 (used, loaded for the next step): their roles rotate over three steps of the unrolled loop, no copies
+                RawRow rrP = nxt, rrQ = fetch_lr(i + 4), rrR = nxt;
+                h8 t0[2] = {Bf[3][0], Bf[3][1]}, t1[2] = {Bf[3][0], Bf[3][1]}, t2[2] = {Bf[3][0], Bf[3][1]};
+                auto run = [&](auto stepfn) __attribute__((always_inline)) {
+                    for (; i + 2 < i_en; i += 3) {
+                        stepfn(i, rrP, rrR, t0, t1);
+                        stepfn(i + 1, rrQ, rrP, t1, t2);
+                        stepfn(i + 2, rrR, rrQ, t2, t0);
+                    }
+                    if (i + 1 < i_en) {
+                        stepfn(i, rrP, rrR, t0, t1);
+                        stepfn(i + 1, rrQ, rrP, t1, t2);
+                        i += 2;
+                        nxt = rrR; Bf[3][0] = t2[0]; Bf[3][1] = t2[1];
+                    } else if (i < i_en) {
+                        stepfn(i, rrP, rrR, t0, t1);
+                        ++i;
+                        nxt = rrQ; Bf[3][0] = t1[0]; Bf[3][1] = t1[1];
+                    } else {
+                        nxt = rrP; Bf[3][0] = t0[0]; Bf[3][1] = t0[1];
+                    }
+                };
+                if constexpr (!DEC) {
+                    run([&](int ii, const RawRow& c, RawRow& nx, const h8 (&b3)[2], h8 (&b3n)[2]) __attribute__((always_inline)) { step_steady(ii, edgec, c, nx, b3, b3n); });
                 } else {
-                    nxt = rr0; Bf[3][0] = b3a[0]; Bf[3][1] = b3a[1];
+                    // entering: phase 2 of the carried group activated here, once (the steady step carries it activated)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        h8 hb = act_pack(accB[0][0][nt], accB[0][1][nt], a_up2, up_max);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hb[e] = colok[2][nt] ? hb[e] : (_Float16)0.0f;
+                        ob[2][nt] = hb;
+                    }
+                    if (wv == 0) run([&](int ii, const RawRow& c, RawRow& nx, const h8 (&)[2], h8 (&)[2]) __attribute__((always_inline)) { step_dec_w0(ii, c, nx); });
+                    else if (wv == 3) run([&](int ii, const RawRow& c, RawRow& nx, const h8 (&b3)[2], h8 (&b3n)[2]) __attribute__((always_inline)) { step_dec(ii, edgec, BoolC<true>{}, c, nx, b3, b3n); });
+                    else run([&](int ii, const RawRow& c, RawRow& nx, const h8 (&b3)[2], h8 (&b3n)[2]) __attribute__((always_inline)) { step_dec(ii, edgec, BoolC<false>{}, c, nx, b3, b3n); });
+                    p2act = true;
                 }
             }
             for (; i <= r1 + 1; ++i) step_plain(i);
