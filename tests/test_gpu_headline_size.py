@@ -60,8 +60,18 @@ def test_stage_builds_and_row_segmentations_bit_identical_at_full_size(gpu_vsr_f
         ref = run(0, H)                       # k_utd3, one march per strip (what the forward launches at this size)
         assert torch.isfinite(ref.float()).all()
         assert torch.equal(run(1, H), ref)    # k_utd (LDS ring, two waves per SIMD)
-        for rps in (270, 68, 7):
+        for rps in (270, 68, 7, -256, -200):   # (negative: the flat split, that many workgroups share the rows evenly)
             assert torch.equal(run(0, rps), ref), rps
+        # five planes, what both SR passes launch: the forward's choice (the flat split over 256 workgroups) against one march per strip
+        assert m._rows_per_segment(5, H, W, flat_ok=True) == -256
+        a5 = a[:5].contiguous()
+        outs = []
+        for rps in (H, -256):
+            out = torch.empty((5, H, W, 32), dtype=torch.float16, device="cuda")
+            L.check(lib.vsr_sr_utd_f16(L.dptr(a5, torch.float16), L.dptr(P["utd"][0], torch.uint8), L.dptr(out, torch.float16),
+                                       5, H, W, rps, 0, 1, L.stream()))
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], ref[:5])
     finally:
         lib.vsr_sr_utd_variant(0)
 

@@ -69,7 +69,7 @@ def test_stage_builds_bit_identical(gpu_vsr_f16, shape, rps):
 
 
 def test_stage_row_segments_agree(gpu_vsr_f16):
-    """One march over all rows and several row segments (recomputed halo group) give bit-identical maps."""
+    """One march over all rows, several row segments (recomputed halo group) and the flat split give bit-identical maps."""
     from video_super_resolution_amd import _lib as L
     m = gpu_vsr_f16.model
     P = m._packed()
@@ -77,7 +77,9 @@ def test_stage_row_segments_agree(gpu_vsr_f16):
     a = torch.from_numpy((np.random.RandomState(5).randn(N, h, w, 32) * 10).astype(np.float16)).cuda()
     for fn, blob in ((L.load().vsr_sr_utd2_f16, P["utd2"][0]), (None, P["utd"][0])):
         outs = []
-        for rps in (h, 16, 5, 1):
+        # (negative: the flat split of the one-wave-per-SIMD build -- that many workgroups share the 2 x 2 x 37 strip rows evenly:
+        #  shares inside a strip, spanning strips and planes, of one row, more workgroups than rows)
+        for rps in ((h, 16, 5, 1, -3, -4, -7, -50, -148, -1000) if fn is None else (h, 16, 5, 1)):
             out = torch.empty((N, h, w, 32), dtype=torch.float16, device="cuda")
             if fn is None:
                 L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16),

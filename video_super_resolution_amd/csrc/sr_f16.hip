@@ -1339,10 +1339,12 @@ int vsr_sr_utd_strip_width(void) { return TX; }
 int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int deconv_only,
                    int slopes_le_one, vsr_stream_t stream) {
     VSR_REQUIRE(in && blob && out, "sr_utd: null pointer");
-    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_utd: bad shape");
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg != 0 && rows_per_seg >= -65535 && N <= 65535, "sr_utd: bad shape");
     VSR_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0, "sr_utd: pointers must be 16-byte aligned");
-    const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
+    const bool one_wave_build = !deconv_only && (g_utd_variant == 0 || g_utd_variant == 2 || g_utd_variant == 4);
+    VSR_REQUIRE(rows_per_seg > 0 || one_wave_build, "sr_utd: the flat row split (rows_per_seg < 0) exists in the one-wave-per-SIMD build only");
+    const unsigned strips = vsr::cdiv(w, TX), segs = rows_per_seg > 0 ? vsr::cdiv(h, rows_per_seg) : 1;
     VSR_REQUIRE(segs <= 65535, "sr_utd: too many row segments");
     typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
     static const kern_t kerns[4] = {k_utd<0, false>, k_utd<0, true>, k_utd<1, false>, k_utd<1, true>};

@@ -36,7 +36,7 @@ constexpr int UTD3_LDS = PART_BYTES + LR_BYTES + UTD3_LR_PAD;   // no HR ring: t
 template <bool ALLMAX, int DIAG>
 __global__ void __launch_bounds__(256)
 k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _Float16* __restrict__ out, int h, int w,
-       int rows_per_seg) {
+       int rows_per_seg, int flat_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const part = smem;                 // 2 x 4 fp32 partial tiles
     unsigned char* const lrr = smem + PART_BYTES;     // 3 LR rows
@@ -45,11 +45,20 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // HR row of every group this wave deconvolves and convolves
     const int l15 = lane & 15, g = lane >> 4;
-    const int x0 = blockIdx.x * TX;
-    const int n = blockIdx.z;
-    const int r0 = blockIdx.y * rows_per_seg;
-    const int r1 = min(h, r0 + rows_per_seg);
-    if (r0 >= r1) return;  // uniform per workgroup
+    // Work of this workgroup.  Grid mode (flat_n = 0): strip blockIdx.x, rows blockIdx.y * rows_per_seg .., plane blockIdx.z.
+    // Flat mode (flat_n = planes): the planes' strips laid end to end are one sequence of flat_n * strips * h rows that the gridDim.x
+    // workgroups share evenly; a workgroup's share is at most two marches when it spans the end of a strip.  (5 planes of 31
+    // strips: 155 marches cannot fill 256 CUs evenly in whole row segments -- three segments are 465 workgroups = 1.82 rounds --
+    // but 256 equal shares of 327 rows can.)
+    const int n_planes = flat_n ? flat_n : (int)gridDim.z;
+    const int strips = (w + TX - 1) / TX;
+    int f0 = 0, f_end = 0;
+    if (flat_n) {
+        const int total = flat_n * strips * h, per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+        f0 = (int)blockIdx.x * per;
+        f_end = min(total, f0 + per);
+        if (f0 >= f_end) return;   // uniform per workgroup
+    }
 
     // ---- weights -> registers (once per workgroup): the slices of k_utd's waves (2wv, 2wv+1) and (wv, wv+4)
     h8 Aup[4][4][2];   // [column phase][tap][channel tile]
@@ -96,6 +105,21 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     const float a_up = fpar[96], a_dt = fpar[97], a_dn = fpar[98];
     const h2 a_up2 = {(_Float16)a_up, (_Float16)a_up}, a_dt2 = {(_Float16)a_dt, (_Float16)a_dt};
     const bool up_max = ALLMAX || a_up <= 1.0f, dt_max = ALLMAX || a_dt <= 1.0f;
+    for (;;) {   // one march per trip (grid mode: one trip)
+    int x0, n, r0, r1;
+    if (flat_n) {
+        const int unit = f0 / h;
+        r0 = f0 - unit * h;
+        r1 = min(h, r0 + (f_end - f0));
+        n = unit / strips;
+        x0 = (unit - n * strips) * TX;
+    } else {
+        x0 = (int)blockIdx.x * TX;
+        n = (int)blockIdx.z;
+        r0 = (int)blockIdx.y * rows_per_seg;
+        r1 = min(h, r0 + rows_per_seg);
+        if (r0 >= r1) return;  // uniform per workgroup
+    }
     const bool edge_strip = (x0 == 0) || (4 * (x0 + 32) - 2 >= 4 * w);
     int lr_b[2][2];
 #pragma unroll
@@ -120,7 +144,7 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     // LR row r -> 16-byte piece of this thread.  A buffer load: lanes outside the image (or without a piece) read from
     // an out-of-range offset and get zeros -- no branch, so the value is not a phi and hipcc waits for it where it is
     // used (the LDS store at the end of the step), not at the top of the step
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)n_planes * h * w * NF * 2), 0x00020000);
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     auto fetch_lr = [&](int r) __attribute__((always_inline)) -> u4 {
         unsigned a = (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2);
@@ -213,7 +237,7 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     };
     // reduce of LR row i: the 4 partial tiles summed in a fixed order, bias, PReLU, fp16; lanes without an output pixel
     // store to an out-of-range buffer offset (dropped by the hardware) so that the step stays one basic block
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)n_planes * h * w * NF * 2), 0x00020000);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u2 __attribute__((ext_vector_type(2)));
     // 31 single-instruction stages (scalar fp32 on purpose: packed fp32 VALU is slow beside MFMAs), placed one per
@@ -496,6 +520,11 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     if (r1 - 2 >= r0) reduce_store(r1 - 2, part + part_cur);
     __syncthreads();
     reduce_store(r1 - 1, part + (part_cur ^ PART_BUF));
+    if (!flat_n) break;
+    f0 += r1 - r0;
+    if (f0 >= f_end) break;
+    __syncthreads();   // the next march's prologue rewrites the LR rows and partial tiles this one has just read
+    }
 }
 
 }  // namespace
@@ -507,7 +536,7 @@ int utd3_set_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stam
 // launch of the fused stage on k_utd3 (called by vsr_sr_utd_f16, which has validated the arguments)
 int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                 int diag, hipStream_t stream) {
-    typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
+    typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int, int);
     static const kern_t kerns[4] = {k_utd3<false, 0>, k_utd3<true, 0>, k_utd3<true, 1>, k_utd3<true, 2>};
     static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
     if (!vsr::device_marked(attr_devs)) {
@@ -517,10 +546,17 @@ int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w
         vsr::mark_device(attr_devs);
     }
     if ((size_t)N * h * w * NF * 2 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_utd3: tensors beyond 2 GiB");
-    const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
     const kern_t k = diag ? kerns[1 + diag] : kerns[slopes_le_one ? 1 : 0];
+    if (rows_per_seg < 0) {   // flat mode: -rows_per_seg workgroups share the N * strips * h rows evenly
+        const long long total = (long long)N * vsr::cdiv(w, TX) * h;
+        const unsigned nwg = (unsigned)(total < -rows_per_seg ? total : -rows_per_seg);
+        hipLaunchKernelGGL(k, dim3(nwg, 1, 1), dim3(256), UTD3_LDS, stream, (const _Float16*)in, (const unsigned char*)blob,
+                           (_Float16*)out, h, w, 0, N);
+        return vsr::launched("sr_utd3");
+    }
+    const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
     hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(256), UTD3_LDS, stream, (const _Float16*)in, (const unsigned char*)blob,
-                       (_Float16*)out, h, w, rows_per_seg);
+                       (_Float16*)out, h, w, rows_per_seg, 0);
     return vsr::launched("sr_utd3");
 }
 

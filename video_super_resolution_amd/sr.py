@@ -123,6 +123,7 @@ class SRProjectionModule(nn.Module):
         # CUs the fused-stage launches of `precompute_shared` are segmented for: they run beside the guidance trunks and take a CU each
         # (tools/overlap_ab.py at 540x960: 24.3 ms per frame serial, 24.1 / 23.8-24.0 / 24.0 / 24.1 with 256 / 96 / 128 / 192)
         self.precompute_cus = 96
+        self.utd_flat_split = True   # k_utd3: share the rows evenly among the CUs when whole row segments cannot (see _rows_per_segment)
         self._pack: Optional[dict] = None
         self._pack_key = None
         self._const: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -501,13 +502,15 @@ class SRProjectionModule(nn.Module):
         return outs
 
     @staticmethod
-    def _rows_per_segment(N, h, w, cus=256, strip=None):
+    def _rows_per_segment(N, h, w, cus=256, strip=None, flat_ok=False):
         """Rows one workgroup of the strip-marching kernels walks.  A launch has strips x N x segments workgroups of one
         wave per SIMD (one workgroup per CU at a time); its duration is about ceil(workgroups / CUs) rounds of
         (rows per segment + ~6 rows: the recomputed halo group and the three cold first steps of a segment).  One march per
         (strip, plane) wins when that already fills the chip (8 planes of 960 columns: 248 workgroups); with fewer planes
         (5 x 31 = 155: 61 % of the CUs for the full 540 rows) cutting the rows balances the load (3 segments: 465
-        workgroups, 2 rounds of 186 rows)."""
+        workgroups, 2 rounds of 186 rows).  `flat_ok` (k_utd3 only): a NEGATIVE result -c asks for the flat split -- c workgroups
+        share the N x strips x h rows of the planes' strips laid end to end evenly, a share spanning the end of a strip as two
+        marches -- when that beats the best whole-segment split (5 planes: 256 shares of 327 rows against 1.82 rounds)."""
         strips = -(-w // (strip or L.load().vsr_sr_utd_strip_width()))
         wgs = strips * N
         best, best_cost = 1, None
@@ -516,6 +519,11 @@ class SRProjectionModule(nn.Module):
             cost = -(-(wgs * (-(-h // rows))) // cus) * (rows + 6)
             if best_cost is None or cost < best_cost * 0.97:   # more segments only for a real gain (each adds a halo group)
                 best, best_cost = segs, cost
+        if flat_ok and wgs * h > cus:
+            per = -(-(wgs * h) // cus)
+            flat_cost = per + 6 * (2 if per < h else -(-per // h) + 1)
+            if flat_cost < best_cost * 0.97:
+                return -cus
         return -(-h // best)
 
     def _utd2(self, a, blob_v2, N, h, w):
@@ -538,7 +546,8 @@ class SRProjectionModule(nn.Module):
         # (timer names carry the plane count when it is not the full 8: the roofline leg prices a launch by its planes)
         tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else ("sr_utd_f16" if N == 8 else f"sr_utd_f16_p{N}"))
         L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
-                                        self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256)), int(deconv_only), int(self._pack["slopes_le_one"]),
+                                        self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256), flat_ok=not deconv_only and self.utd_flat_split),
+                                        int(deconv_only), int(self._pack["slopes_le_one"]),
                                         L.stream()), "sr_utd_f16")
         L.TIMER.stop(tok)
         return out
