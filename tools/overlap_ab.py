@@ -10,7 +10,7 @@ h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (540, 960)
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 m = fill_module_(VSR(upscale_factor=S).eval(), 0).cuda() if S != 4 else fill_module_(VSR().eval(), 0).cuda()
 clip = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (14, h, w, 3)).astype(np.float32)).cuda()
-for mode, cus in ((False, 256), (True, 256), (True, 96), (True, 128), (True, 192), (False, 256), (True, 96)):
+for mode, cus in ((False, 256), (True, 96), (True, 128), (True, 160), (True, 192), (True, 256), (False, 256), (True, 96), (True, 128), (True, 160)):
     m.overlap_shared = mode
     m.model.precompute_cus = cus
     est = None

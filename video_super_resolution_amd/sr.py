@@ -120,9 +120,10 @@ class SRProjectionModule(nn.Module):
         # "fp32": every product and sum in float32 (the parity configuration, ~60x slower).
         self.precision = "fp16"
         self.tail_build = 3   # 3: k_tail3 (csrc/sr_tail3.hip); 1: k_tail (LDS ring; kept as the cross-check)
-        # CUs the fused-stage launches of `precompute_shared` are segmented for: they run beside the guidance trunks and take a CU each
-        # (tools/overlap_ab.py at 540x960: 24.3 ms per frame serial, 24.1 / 23.8-24.0 / 24.0 / 24.1 with 256 / 96 / 128 / 192)
-        self.precompute_cus = 96
+        # CUs the fused-stage launches of `precompute_shared` are split for: they run beside the guidance trunks and take a CU each
+        # (tools/overlap_ab.py at 540x960, ms per frame on one box: serial 24.7 / 25.1; beside the trunks with 96 / 128 / 160 / 192 /
+        # 256: 23.80 / 23.77-23.82 / 23.92-23.94 / 24.06 / 24.13)
+        self.precompute_cus = 128
         self.utd_flat_split = True   # k_utd3: share the rows evenly among the CUs when whole row segments cannot (see _rows_per_segment)
         self._pack: Optional[dict] = None
         self._pack_key = None
