@@ -86,3 +86,44 @@ def test_sr_properties_at_headline_width(gpu_vsr):
     gpu_vsr.model(x[perm].contiguous(), taps=t3)
     assert torch.equal(t3["prefc2"], t1["prefc2"][perm])
     assert o1.shape == (1, 3, 96, 3840) and torch.isfinite(o1).all() and (o1 >= 0).all()
+
+
+@pytest.mark.parametrize("scale", [4, 2, 3])
+@pytest.mark.parametrize("shape", [(2, 9, 40), (1, 37, 33), (3, 5, 70), (1, 1, 1)])
+def test_f32_mfma_builds_bit_identical(scale, shape):
+    """The float32 ConvTranspose2d / Conv2d (32, 32, K, S, p2) + PReLU blocks of the FeedbackBlock on v_mfma_f32_32x32x2_f32
+    (csrc/sr_f32_mfma.hip, the default) against the one-pixel-per-thread kernels (csrc/sr_f32.hip): the same fused multiply-adds
+    in the same order -> equal maps; and against the stock operators at the float32 bar.  Ragged widths (column tiles of 32 / 64),
+    heights that are not multiples of the 4 rows of a workgroup, slopes above one."""
+    import torch.nn.functional as F
+    from video_super_resolution_amd import _lib as L
+    K = {4: 8, 2: 6, 3: 7}[scale]
+    N, h, w = shape
+    rs = np.random.RandomState(scale * 100 + h + w)
+    lib = L.load()
+    lib.vsr_sr_f32_variant.restype = __import__("ctypes").c_int
+    x = torch.from_numpy(rs.randn(N, 32, h, w).astype(np.float32)).cuda()
+    wt_d = torch.from_numpy((rs.randn(32, 32, K, K) / (4.0 * K)).astype(np.float32)).cuda()   # ConvTranspose2d weight [in, out, K, K]
+    wt_c = torch.from_numpy((rs.randn(32, 32, K, K) / (4.0 * K)).astype(np.float32)).cuda()   # Conv2d weight [out, in, K, K]
+    b = torch.from_numpy(rs.randn(32).astype(np.float32)).cuda()
+    slope = 1.3 if h == 5 else 0.2
+    wp_d = wt_d.permute(2, 3, 0, 1).contiguous()      # [ky][kx][in][out]
+    wp_c = wt_c.permute(2, 3, 1, 0).contiguous()
+    outs = []
+    try:
+        for variant in (0, 1, 2):
+            lib.vsr_sr_f32_variant(variant)
+            hr = torch.empty((N, 32, scale * h, scale * w), dtype=torch.float32, device="cuda")
+            L.check(lib.vsr_sr_deconv_f32(L.dptr(x), L.dptr(wp_d), L.dptr(b), L.cf(slope), L.dptr(hr), N, h, w, scale, L.stream()), "deconv")
+            lr = torch.empty((N, 32, h, w), dtype=torch.float32, device="cuda")
+            L.check(lib.vsr_sr_conv_f32(L.dptr(hr), L.dptr(wp_c), L.dptr(b), L.cf(slope), L.dptr(lr), N, h, w, scale, L.stream()), "conv")
+            outs.append((hr, lr))
+    finally:
+        lib.vsr_sr_f32_variant(0)
+    (hr0, lr0), (hr1, lr1), (hr2, lr2) = outs
+    assert torch.equal(hr0, hr1) and torch.equal(lr0, lr1) and torch.equal(hr0, hr2) and torch.equal(lr0, lr2)
+    a = torch.tensor([slope], device="cuda")
+    hr_ref = F.prelu(F.conv_transpose2d(x.double(), wt_d.double(), b.double(), stride=scale, padding=2), a.double())
+    lr_ref = F.prelu(F.conv2d(hr0.double(), wt_c.double(), b.double(), stride=scale, padding=2), a.double())
+    _close(hr0.double(), hr_ref.cpu().numpy(), TOL_FP32, "deconv")
+    _close(lr0.double(), lr_ref.cpu().numpy(), TOL_FP32, "conv")

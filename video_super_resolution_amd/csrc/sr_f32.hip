@@ -239,6 +239,12 @@ __global__ void __launch_bounds__(kBlock) k_fc_fuse(const float* __restrict__ pr
 
 }  // namespace
 
+namespace vsr {
+bool launch_conv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale, hipStream_t stream);
+bool launch_conv_f32_mfma_per_tap(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale, hipStream_t stream);
+bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale, hipStream_t stream);
+}  // namespace vsr
+
 extern "C" {
 
 int vsr_sr_head_f32(const float* x, const float* sub_scale3, const float* sub_bias3, const float* w_in,
@@ -262,11 +268,22 @@ int vsr_sr_conv1x1_f32(const float* in0, const float* w0, int ldw0, const float*
     return vsr::launched("sr_conv1x1");
 }
 
+static int g_f32_variant = 0;   // 0: the (de)convolutions on v_mfma_f32_32x32x2_f32 (sr_f32_mfma.hip); 1: one pixel per thread (cross-check); 2: as 0 with the
+                                // convolution's per-tap MFMA build (measurements)
+
+int vsr_sr_f32_variant(int v) {
+    const int old = g_f32_variant;
+    g_f32_variant = v < 0 || v > 2 ? 0 : v;
+    return old;
+}
+
 int vsr_sr_deconv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
                       int h, int w, int scale, vsr_stream_t stream) {
     VSR_REQUIRE(in && weight_packed && bias && out, "sr_deconv: null pointer");
     VSR_REQUIRE(scale >= 2 && scale <= 4, "sr_deconv: scale %d (2: k6 s2, 3: k7 s3, 4: k8 s4; padding 2)", scale);
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && (long long)scale * h <= 65535 && N <= 65535, "sr_deconv: bad shape");
+    if (g_f32_variant != 1 && vsr::launch_deconv_f32_mfma(in, weight_packed, bias, slope, out, N, h, w, scale, vsr::S(stream)))
+        return vsr::launched("sr_deconv_mfma");
     const dim3 grid(vsr::cdiv(w + 1, kBlock), scale * h, N);
     if (scale == 4) hipLaunchKernelGGL((k_deconv<8, 4>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
     else if (scale == 3) hipLaunchKernelGGL((k_deconv<7, 3>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
@@ -279,6 +296,10 @@ int vsr_sr_conv_f32(const float* in, const float* weight_packed, const float* bi
     VSR_REQUIRE(in && weight_packed && bias && out, "sr_conv: null pointer");
     VSR_REQUIRE(scale >= 2 && scale <= 4, "sr_conv: scale %d (2: k6 s2, 3: k7 s3, 4: k8 s4; padding 2)", scale);
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && h <= 65535 && N <= 65535, "sr_conv: bad shape");
+    if (g_f32_variant == 0 && vsr::launch_conv_f32_mfma(in, weight_packed, bias, slope, out, N, h, w, scale, vsr::S(stream)))
+        return vsr::launched("sr_conv_mfma");
+    if (g_f32_variant == 2 && vsr::launch_conv_f32_mfma_per_tap(in, weight_packed, bias, slope, out, N, h, w, scale, vsr::S(stream)))
+        return vsr::launched("sr_conv_mfma_per_tap");
     const dim3 grid(vsr::cdiv(w, kBlock), h, N);
     if (scale == 4) hipLaunchKernelGGL((k_conv<8, 4>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
     else if (scale == 3) hipLaunchKernelGGL((k_conv<7, 3>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);

@@ -1,0 +1,270 @@
+// sr_f32_mfma.hip -- the two float32 (de)convolutions of the FeedbackBlock (SRProjectionModule.py:62-65,77-80: ConvTranspose2d /
+// Conv2d (32, 32, K, S, padding 2) + PReLU, (K, S) = (8, 4) the reference's literals | (6, 2) | (7, 3)) on the matrix cores:
+// v_mfma_f32_32x32x2_f32, float32 in, float32 accumulate -- the same fused multiply-adds in the same order as the one-pixel-per-
+// thread kernels of sr_f32.hip (tap by tap, input channels ascending), so the maps are bit-identical to theirs
+// (tests/test_gpu_sr.py::test_f32_mfma_builds_bit_identical); what changes is who does the bookkeeping: there a lane issues 32
+// v_fmac + a load per (tap, channel) with scalar weight loads in between (0.39 of the float32 peak), here one instruction covers
+// 32 out-channels x 32 pixels x 2 input channels.  SURVEY.md 7-4 / VERDICT r2 item 7 (configuration C2).
+//
+// Operand layout of v_mfma_f32_32x32x2_f32 (wave64): A[i][k]: lane = 32 k + i (one VGPR), B[k][j]: lane = 32 k + j,
+// D[i][j]: lane = 32 (i/4 % 2) + j, register = 4 (i / 8) + i % 4.  Here i = out-channel, j = pixel, k = input-channel parity:
+// A = 64 consecutive floats of the packed weights [ky][kx][ci][co] (ci = 2 cp + k), one coalesced 256-byte load per MFMA pair.
+#include "vsr_common.h"
+
+namespace {
+
+constexpr int NF = 32;
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float prelu(float v, float slope) { return v >= 0.0f ? v : v * slope; }
+
+// Conv2d(32,32,K,S,p2) + PReLU: out[co, iy, ix] = b + sum_{ky,kx,ci} in[ci, S iy - 2 + ky, S ix - 2 + kx] W[ky][kx][ci][co].
+// Workgroup = 4 waves = 4 consecutive output rows x 64 output columns (the rows share K - S input rows through L1); a wave holds
+// two 32 x 32 accumulator tiles (pixels ix0 .. ix0+31, ix0+32 .. ix0+63) that share every weight fragment.
+template <int K, int S>
+__global__ void __launch_bounds__(256) k_conv_mfma(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                   float slope, float* __restrict__ out, int h, int w) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.z, iy = blockIdx.y * 4 + wv, ix0 = blockIdx.x * 64;
+    if (iy >= h) return;   // (uniform per wave; no barrier in this kernel)
+    const int H = S * h, W = S * w;
+    const size_t HW = (size_t)H * W, hw = (size_t)h * w;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)n * NF * HW), 0, (int)(NF * HW * 4), 0x00020000);
+    f16v acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float b = bias[8 * (r >> 2) + 4 * kh + (r & 3)];
+        acc[0][r] = b;
+        acc[1][r] = b;
+    }
+    for (int ky = 0; ky < K; ++ky) {
+        const int Y = S * iy - 2 + ky;
+        if (Y < 0 || Y >= H) continue;   // (uniform)
+        for (int kx = 0; kx < K; ++kx) {
+            const float* wt = wp + (size_t)(ky * K + kx) * NF * NF + lane;
+            unsigned off[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int X = S * (ix0 + 32 * t + col) - 2 + kx;
+                // channel kh of the pair, row Y, column X; a lane outside the image reads an out-of-range offset: zero
+                off[t] = (X >= 0 && X < W) ? (unsigned)((((size_t)kh * H + Y) * W + X) * 4) : 0xFFFFFFFFu;
+            }
+            const unsigned cstep = (unsigned)(2 * HW * 4);   // two input channels further
+#pragma unroll 4
+            for (int cp = 0; cp < NF / 2; ++cp) {
+                const float a = wt[64 * cp];
+                const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, off[0] == 0xFFFFFFFFu ? off[0] : off[0] + cp * cstep, 0, 0));
+                const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, off[1] == 0xFFFFFFFFu ? off[1] : off[1] + cp * cstep, 0, 0));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ix = ix0 + 32 * t + col;
+        if (ix >= w) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 8 * (r >> 2) + 4 * kh + (r & 3);
+            out[((size_t)n * NF + co) * hw + (size_t)iy * w + ix] = prelu(acc[t][r], slope);
+        }
+    }
+}
+
+// The same convolution with the pixel operand loaded ONCE per (input row, channel pair, column class) instead of once per tap:
+// the taps kx = c, c + S, c + 2S, .. of a row read the same strided sequence V_c[p] = in[ci, Y, S p - 2 + c] shifted by 0, 1, 2, ..
+// pixels, so a wave loads V_c at its 64 pixels + one more tile and forms the shifted operands with ds_bpermute_b32 (LDS crossbar,
+// no memory).  k_conv_mfma above asks L1 for ~11 cache lines per MFMA pair and runs at 0.34 of the float32 peak, below the
+// one-pixel-per-thread kernel; this build asks for 2.5 x fewer.  All 16 channel pairs of an input row are resident (96 registers
+// at S = 2), so the sum of an output still runs (ky, kx, ci) ascending: bit-identical maps.
+template <int K, int S>
+__global__ void __launch_bounds__(256) k_conv_mfma_sh(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                      float slope, float* __restrict__ out, int h, int w) {
+    constexpr int T = (K + S - 1) / S;   // taps of column class 0
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.z, iy = blockIdx.y * 4 + wv, ix0 = blockIdx.x * 64;
+    if (iy >= h) return;   // (uniform per wave; no barrier in this kernel)
+    const int H = S * h, W = S * w;
+    const size_t HW = (size_t)H * W, hw = (size_t)h * w;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)n * NF * HW), 0, (int)(NF * HW * 4), 0x00020000);
+    f16v acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float b = bias[8 * (r >> 2) + 4 * kh + (r & 3)];
+        acc[0][r] = b;
+        acc[1][r] = b;
+    }
+    int sidx[T];       // ds_bpermute byte index of the lane j pixels further inside this lane's 32-lane half
+    bool sfirst[T];    // ... which lies in the same tile (else: in the next one)
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        sidx[j] = 4 * (32 * kh + ((col + j) & 31));
+        sfirst[j] = col + j < 32;
+    }
+    for (int ky = 0; ky < K; ++ky) {
+        const int Y = S * iy - 2 + ky;
+        if (Y < 0 || Y >= H) continue;   // (uniform)
+        // V_c of this row, all 16 channel pairs: [cp][class][tile 0, 1, 2]
+        float R[NF / 2][S][3];
+#pragma unroll
+        for (int c = 0; c < S; ++c)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int X = S * (ix0 + 32 * u + col) - 2 + c;
+                const bool ok = X >= 0 && X < W && (u < 2 || col < T - 1);   // (tile 2: only the pixels the shifts reach)
+                const unsigned off = ok ? (unsigned)((((size_t)kh * H + Y) * W + X) * 4) : 0xFFFFFFFFu;
+                const unsigned cstep = (unsigned)(2 * HW * 4);
+#pragma unroll
+                for (int cp = 0; cp < NF / 2; ++cp)
+                    R[cp][c][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, ok ? off + cp * cstep : 0xFFFFFFFFu, 0, 0));
+            }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int c = kx % S, j = kx / S;
+            const float* wt = wp + (size_t)(ky * K + kx) * NF * NF + lane;
+#pragma unroll
+            for (int cp = 0; cp < NF / 2; ++cp) {
+                const float a = wt[64 * cp];
+                float b[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (j == 0) b[t] = R[cp][c][t];
+                    else {
+                        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx[j], __builtin_bit_cast(int, R[cp][c][t])));
+                        const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx[j], __builtin_bit_cast(int, R[cp][c][t + 1])));
+                        b[t] = sfirst[j] ? v0 : v1;
+                    }
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[1], acc[1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ix = ix0 + 32 * t + col;
+        if (ix >= w) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 8 * (r >> 2) + 4 * kh + (r & 3);
+            out[((size_t)n * NF + co) * hw + (size_t)iy * w + ix] = prelu(acc[t][r], slope);
+        }
+    }
+}
+
+// ConvTranspose2d(32,32,K,S,p2) + PReLU: HR pixel (Y, X), iy = (Y+2)/S, py = (Y+2)%S, q = (X+2)/S, px = (X+2)%S:
+//   out = b + sum_{dy, dx < T: py + S dy < K, px + S dx < K} sum_ci in[ci, iy - dy, q - dx] W[py + S dy][px + S dx][ci][co].
+// A wave owns one HR row Y and 64 consecutive q (two pixel tiles); the pixel operand of a (dy, dx, channel pair) does not depend
+// on the column phase px, so it is loaded once and used by the S phases' accumulators (2 S tiles of 32 x 32 per wave); each
+// phase's weight fragment serves both pixel tiles.  Per output the sum still runs (dy, dx, ci) ascending.  The 4 waves of a
+// workgroup are 4 consecutive HR rows.
+template <int K, int S>
+__global__ void __launch_bounds__(256) k_deconv_mfma(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                     float slope, float* __restrict__ out, int h, int w) {
+    constexpr int T = (K + S - 1) / S;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.z, Y = blockIdx.y * 4 + wv, q0 = blockIdx.x * 64;
+    const int H = S * h, W = S * w;
+    if (Y >= H) return;   // (uniform per wave; no barrier)
+    const int iy = (Y + 2) / S, py = (Y + 2) % S;
+    const size_t hw = (size_t)h * w, HW = (size_t)H * W;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)n * NF * hw), 0, (int)(NF * hw * 4), 0x00020000);
+    f16v acc[S][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float b = bias[8 * (r >> 2) + 4 * kh + (r & 3)];
+#pragma unroll
+        for (int px = 0; px < S; ++px) {
+            acc[px][0][r] = b;
+            acc[px][1][r] = b;
+        }
+    }
+#pragma unroll
+    for (int dy = 0; dy < T; ++dy) {
+        const int yy = iy - dy;
+        if (py + S * dy >= K || yy < 0 || yy >= h) continue;   // (uniform)
+#pragma unroll
+        for (int dx = 0; dx < T; ++dx) {
+            unsigned off[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int xc = q0 + 32 * t + col - dx;
+                off[t] = (xc >= 0 && xc < w) ? (unsigned)((((size_t)kh * h + yy) * w + xc) * 4) : 0xFFFFFFFFu;
+            }
+            const float* wt = wp + (size_t)((py + S * dy) * K + S * dx) * NF * NF + lane;   // + px * 1024: tap (py + S dy, px + S dx)
+            const unsigned cstep = (unsigned)(2 * hw * 4);
+#pragma unroll 2
+            for (int cp = 0; cp < NF / 2; ++cp) {
+                const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, off[0] == 0xFFFFFFFFu ? off[0] : off[0] + cp * cstep, 0, 0));
+                const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, off[1] == 0xFFFFFFFFu ? off[1] : off[1] + cp * cstep, 0, 0));
+#pragma unroll
+                for (int px = 0; px < S; ++px) {
+                    if (px + S * dx >= K) continue;   // (compile time)
+                    const float a = wt[px * NF * NF + 64 * cp];
+                    acc[px][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[px][0], 0, 0, 0);
+                    acc[px][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[px][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int q = q0 + 32 * t + col;   // this lane's LR column index, in [0, w]
+        if (q > w) continue;
+#pragma unroll
+        for (int px = 0; px < S; ++px) {
+            const int X = S * q + px - 2;
+            if (X < 0 || X >= W) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 8 * (r >> 2) + 4 * kh + (r & 3);
+                out[((size_t)n * NF + co) * HW + (size_t)Y * W + X] = prelu(acc[px][t][r], slope);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace vsr {
+
+// launches of the MFMA builds (called by vsr_sr_conv_f32 / vsr_sr_deconv_f32, which have validated the arguments); false when
+// a map is beyond the 32-bit byte offsets of one plane group (the caller then runs the one-pixel-per-thread kernel)
+bool launch_conv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale,
+                          hipStream_t stream) {
+    // (8,4) and (7,3): the build that reloads the pixel operand per tap measured 3-5 % BELOW the one-pixel-per-thread kernel
+    // (tools/f32_blocks_time.py: 5.05 vs 4.83 ms, 5.05 vs 4.82), and the shifted-operand build needs 16 x S x 3 resident
+    // registers -- those two shapes stay on the caller's kernel
+    if (scale != 2) return false;
+    if ((size_t)NF * scale * h * scale * w * 4 >= (1ull << 32) - 16 || (h + 3) / 4 > 65535) return false;
+    const dim3 grid(vsr::cdiv(w, 64), vsr::cdiv(h, 4), N);
+    hipLaunchKernelGGL((k_conv_mfma_sh<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    return true;
+}
+
+// (the per-tap build of the convolution: reachable for measurements only)
+bool launch_conv_f32_mfma_per_tap(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale,
+                                  hipStream_t stream) {
+    if ((size_t)NF * scale * h * scale * w * 4 >= (1ull << 32) - 16 || (h + 3) / 4 > 65535) return false;
+    const dim3 grid(vsr::cdiv(w, 64), vsr::cdiv(h, 4), N);
+    if (scale == 4) hipLaunchKernelGGL((k_conv_mfma<8, 4>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    else if (scale == 3) hipLaunchKernelGGL((k_conv_mfma<7, 3>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    else hipLaunchKernelGGL((k_conv_mfma<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    return true;
+}
+
+bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale,
+                            hipStream_t stream) {
+    if ((size_t)NF * h * w * 4 >= (1ull << 32) - 16 || (scale * h + 3) / 4 > 65535) return false;
+    const dim3 grid(vsr::cdiv(w + 1, 64), vsr::cdiv(scale * h, 4), N);
+    if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma<8, 4>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma<7, 3>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    else hipLaunchKernelGGL((k_deconv_mfma<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    return true;
+}
+
+}  // namespace vsr
