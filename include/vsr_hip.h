@@ -157,7 +157,7 @@ int vsr_sr_deconv_f32(const float* in, const float* weight_packed, const float* 
                       int h, int w, int scale, vsr_stream_t stream);
 int vsr_sr_conv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
                     int h, int w, int scale, vsr_stream_t stream);
-/* Build of the two float32 blocks above (process-wide; bit-identical maps): 0 (default) v_mfma_f32_32x32x2_f32 -- 32 out-channels x
+/* Build of the two float32 blocks above and of vsr_sr_conv1x1_f32 (process-wide; bit-identical maps): 0 (default) v_mfma_f32_32x32x2_f32 -- 32 out-channels x
  * 32 pixels x 2 input channels per instruction, the same fused multiply-adds in the same order (csrc/sr_f32_mfma.hip; the stride-4
  * and stride-3 convolutions stay on build 1, which is faster there) --, 1 one pixel per thread (csrc/sr_f32.hip; the cross-check),
  * 2 as 0 with the convolution's per-tap MFMA build at every scale (measurements).  Returns the previous value. */

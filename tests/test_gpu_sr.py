@@ -127,3 +127,40 @@ def test_f32_mfma_builds_bit_identical(scale, shape):
     lr_ref = F.prelu(F.conv2d(hr0.double(), wt_c.double(), b.double(), stride=scale, padding=2), a.double())
     _close(hr0.double(), hr_ref.cpu().numpy(), TOL_FP32, "deconv")
     _close(lr0.double(), lr_ref.cpu().numpy(), TOL_FP32, "conv")
+
+
+@pytest.mark.parametrize("case", [(2, 1000, 1, False), (1, 4097, 2, True), (3, 70, 3, True), (1, 31, 1, True)])
+def test_f32_conv1x1_mfma_bit_identical(case):
+    """vsr_sr_conv1x1_f32 on the matrix cores against its one-pixel-per-thread build: one to three inputs with weight slices of
+    a wider matrix, the constant map, ragged pixel counts."""
+    import ctypes
+    from video_super_resolution_amd import _lib as L
+    N, P, nin, with_map = case
+    rs = np.random.RandomState(P + nin)
+    lib = L.load()
+    ins = [torch.from_numpy(rs.randn(N, 32, P).astype(np.float32)).cuda() for _ in range(nin)]
+    wfull = torch.from_numpy((rs.randn(32, 32 * nin + 7) / 8.0).astype(np.float32)).cuda()      # [32, ld]: input i reads columns 32 i + 3 ..
+    bias = torch.from_numpy(rs.randn(32).astype(np.float32)).cuda()
+    cmap = torch.from_numpy(rs.randn(32, P).astype(np.float32)).cuda() if with_map else None
+    ld = wfull.shape[1]
+    outs = []
+    try:
+        for variant in (0, 1):
+            lib.vsr_sr_f32_variant(variant)
+            out = torch.empty((N, 32, P), dtype=torch.float32, device="cuda")
+            args = []
+            for i in range(3):
+                if i < nin:
+                    args += [L.dptr(ins[i]), ctypes.c_void_p(wfull.data_ptr() + 4 * (32 * i + 3)), ld]
+                else:
+                    args += [L.optr(None), L.optr(None), 0]
+            L.check(lib.vsr_sr_conv1x1_f32(*args, L.dptr(bias), L.optr(cmap), L.cf(0.25), L.dptr(out), N, P, L.stream()), "conv1x1")
+            outs.append(out)
+    finally:
+        lib.vsr_sr_f32_variant(0)
+    assert torch.equal(outs[0], outs[1])
+    ref = bias.double()[None, :, None] + (cmap.double()[None] if with_map else 0.0)
+    for i in range(nin):
+        ref = ref + torch.einsum("oc,ncp->nop", wfull[:, 32 * i + 3:32 * i + 35].double(), ins[i].double())
+    ref = torch.where(ref >= 0, ref, 0.25 * ref)
+    _close(outs[0].double(), ref.cpu().numpy(), TOL_FP32, "conv1x1")

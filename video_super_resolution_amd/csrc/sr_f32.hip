@@ -242,6 +242,8 @@ __global__ void __launch_bounds__(kBlock) k_fc_fuse(const float* __restrict__ pr
 namespace vsr {
 bool launch_conv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale, hipStream_t stream);
 bool launch_conv_f32_mfma_per_tap(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale, hipStream_t stream);
+void launch_conv1x1_f32_mfma(const float* in0, const float* w0, int ld0, const float* in1, const float* w1, int ld1, const float* in2, const float* w2,
+                             int ld2, const float* bias, const float* cmap, float slope, float* out, int N, size_t P, hipStream_t stream);
 bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale, hipStream_t stream);
 }  // namespace vsr
 
@@ -257,19 +259,23 @@ int vsr_sr_head_f32(const float* x, const float* sub_scale3, const float* sub_bi
     return vsr::launched("sr_head");
 }
 
+static int g_f32_variant = 0;   // 0: the (de)convolutions on v_mfma_f32_32x32x2_f32 (sr_f32_mfma.hip); 1: one pixel per thread (cross-check); 2: as 0 with the
+                                // convolution's per-tap MFMA build (measurements)
+
 int vsr_sr_conv1x1_f32(const float* in0, const float* w0, int ldw0, const float* in1, const float* w1, int ldw1,
                        const float* in2, const float* w2, int ldw2, const float* bias, const float* cmap, float slope,
                        float* out, int N, int P, vsr_stream_t stream) {
     VSR_REQUIRE(in0 && w0 && bias && out, "sr_conv1x1: null pointer");
     VSR_REQUIRE((in1 == nullptr) == (w1 == nullptr) && (in2 == nullptr) == (w2 == nullptr), "sr_conv1x1: input/weight mismatch");
     VSR_REQUIRE(N > 0 && P > 0 && N <= 65535, "sr_conv1x1: bad shape");
+    if (g_f32_variant != 1) {
+        vsr::launch_conv1x1_f32_mfma(in0, w0, ldw0, in1, w1, ldw1, in2, w2, ldw2, bias, cmap, slope, out, N, (size_t)P, vsr::S(stream));
+        return vsr::launched("sr_conv1x1_mfma");
+    }
     hipLaunchKernelGGL(k_conv1x1, dim3(vsr::cdiv(P, kBlock), N), dim3(kBlock), 0, vsr::S(stream), in0, w0, ldw0, in1,
                        w1, ldw1, in2, w2, ldw2, bias, cmap, slope, out, (size_t)P);
     return vsr::launched("sr_conv1x1");
 }
-
-static int g_f32_variant = 0;   // 0: the (de)convolutions on v_mfma_f32_32x32x2_f32 (sr_f32_mfma.hip); 1: one pixel per thread (cross-check); 2: as 0 with the
-                                // convolution's per-tap MFMA build (measurements)
 
 int vsr_sr_f32_variant(int v) {
     const int old = g_f32_variant;

@@ -228,6 +228,64 @@ __global__ void __launch_bounds__(256) k_deconv_mfma(const float* __restrict__ i
     }
 }
 
+// 1x1 convolution over up to three 32-channel float32 inputs (+ constant map) + PReLU (the FeedbackBlock's compress / uptran /
+// downtran glue in the float32 configuration; sr_f32.hip:k_conv1x1 is its one-pixel-per-thread form: 32 x 32 v_fmac per pixel and
+// input, VALU-bound at 1.1 ms per input on a x2 map of 16.6 M pixels, next to 0.85 ms of HBM time).  Here a wave owns 64 pixels
+// (two 32 x 32 accumulator tiles); per input its 16 weight fragments are loaded once, the pixel operand is one coalesced
+// 128-byte row per channel and tile.  acc = (bias + map), then input by input, channels ascending: the same fused multiply-adds.
+__global__ void __launch_bounds__(256) k_conv1x1_mfma(const float* __restrict__ in0, const float* __restrict__ w0, int ld0,
+                                                      const float* __restrict__ in1, const float* __restrict__ w1, int ld1,
+                                                      const float* __restrict__ in2, const float* __restrict__ w2, int ld2,
+                                                      const float* __restrict__ bias, const float* __restrict__ cmap, float slope,
+                                                      float* __restrict__ out, size_t P) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.y;
+    const size_t p0 = ((size_t)blockIdx.x * 4 + wv) * 64;
+    if (p0 >= P) return;   // (uniform per wave; no barrier)
+    size_t p[2];
+    bool ok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        p[t] = p0 + 32 * t + col;
+        ok[t] = p[t] < P;
+    }
+    f16v acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 8 * (r >> 2) + 4 * kh + (r & 3);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][r] = bias[co] + ((cmap && ok[t]) ? cmap[(size_t)co * P + p[t]] : 0.0f);
+    }
+    const float* ins[3] = {in0, in1, in2};
+    const float* ws[3] = {w0, w1, w2};
+    const int lds_[3] = {ld0, ld1, ld2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (!ins[i]) continue;   // (uniform)
+        float a[NF / 2];
+#pragma unroll
+        for (int cp = 0; cp < NF / 2; ++cp) a[cp] = ws[i][(size_t)col * lds_[i] + 2 * cp + kh];
+        const float* ip = ins[i] + (size_t)n * NF * P + (size_t)kh * P;
+#pragma unroll 4
+        for (int cp = 0; cp < NF / 2; ++cp) {
+            const float b0 = ok[0] ? ip[(size_t)(2 * cp) * P + p[0]] : 0.0f;
+            const float b1 = ok[1] ? ip[(size_t)(2 * cp) * P + p[1]] : 0.0f;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp], b1, acc[1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (!ok[t]) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 8 * (r >> 2) + 4 * kh + (r & 3);
+            out[((size_t)n * NF + co) * P + p[t]] = prelu(acc[t][r], slope);
+        }
+    }
+}
+
 }  // namespace
 
 namespace vsr {
@@ -255,6 +313,13 @@ bool launch_conv_f32_mfma_per_tap(const float* in, const float* wp, const float*
     else if (scale == 3) hipLaunchKernelGGL((k_conv_mfma<7, 3>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
     else hipLaunchKernelGGL((k_conv_mfma<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
     return true;
+}
+
+void launch_conv1x1_f32_mfma(const float* in0, const float* w0, int ld0, const float* in1, const float* w1, int ld1, const float* in2,
+                             const float* w2, int ld2, const float* bias, const float* cmap, float slope, float* out, int N, size_t P,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_conv1x1_mfma, dim3(vsr::cdiv(P, 256), N), dim3(256), 0, stream, in0, w0, ld0, in1, w1, ld1, in2, w2, ld2, bias, cmap,
+                       slope, out, P);
 }
 
 bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale,
