@@ -9,9 +9,11 @@
 // row 4 dy + co (9 of 16 rows useful), one MFMA per (output column phase, dx, pixel tile) = 24 per step, B operands
 // straight from the deconv's operand tiles (a one-lane DPP shift where dx crosses a position boundary).  Only the
 // fp32 partial sums cross waves: 16 bytes per (output row, dy, HR pixel) in a 16-row LDS window; the wave that owns
-// output row R sums its three partials two steps later, adds bias and the bilinear skip and stores.
-//   step i = [deconv phases 0,1 of G(i); finish output rows 4i-7 .. 4i-4] BARRIER [deconv phases 2,3, PReLU, the 24
-//   conv MFMAs, partial stores, LR row i+3]
+// output row R sums its three partials two steps later, adds bias and stores.
+// The march is a software pipeline (round 3): step i = BARRIER [deconv of column phases 0,1 of G(i) || PReLU of phases 2,3 of
+// G(i-1)] [3x3 over G(i-1), FOLD 1x1 of LR row i+3 || DPP shifts, finish of output row 4i-7+wv] [deconv of phases 2,3 of G(i) ||
+// PReLU of phases 0,1, partial stores, LR row store, next LR operands]; the decimated pass has its own steady step (step_dec);
+// rows outside the steady state run the same stages one after the other (step_plain).
 #include "sr_f16_common.h"
 
 namespace {
@@ -150,59 +152,6 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
         return u4{ok ? o[0] : 0u, ok ? o[1] : 0u, ok ? o[2] : 0u, ok ? o[3] : 0u};
     };
     auto lr_slot = [&](int r) __attribute__((always_inline)) { return ((r + 1) % 3) * LR_SLOT; };
-    auto load_lr_frags = [&](int s_i, int s_i1, h8 (&Bf)[4][2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int dy = t >> 1, dx = t & 1;
-            const unsigned char* base = lrr + (dy ? s_i : s_i1);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) Bf[t][nt] = *reinterpret_cast<const h8*>(base + lr_b[dx][nt]);
-        }
-    };
-
-    // ---- P1: deconv + PReLU of HR row 4i+2+wv -> operand tiles ob[column phase][pixel tile] (zeros outside the image)
-    auto deconv_row = [&](int i, const h8 (&Bf)[4][2], h8 (&ob)[4][2]) __attribute__((always_inline)) {
-        const int r_hr = 4 * i + 2 + wv;
-        if (r_hr < 0 || r_hr >= H) {
-            h8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
-#pragma unroll
-            for (int px = 0; px < 4; ++px)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) ob[px][nt] = z;
-            return;
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f4 acc[2][2][2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (DEC && half == 0 && c == 0) continue;   // column phase 0 is not read when only pixels (4i,4j) are kept
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[c][mt][nt] = mfma16(Aup[2 * half + c][t][mt], Bf[t][nt], t == 0 ? bup[mt] : acc[c][mt][nt]);
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int px = 2 * half + c;
-                    if (DEC && px == 0) { ob[0][nt] = Bf[0][nt]; continue; }   // (never read; any defined value)
-                    h8 hb = act_pack(acc[c][0][nt], acc[c][1][nt], a_up2, up_max);
-                    const int c_hr = 4 * (x0 + 16 * nt + l15) + px - 2;
-                    const bool col_ok = (c_hr >= 0) && (c_hr < W);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) hb[e] = col_ok ? hb[e] : (_Float16)0.0f;
-                    ob[px][nt] = hb;
-                }
-        }
-    };
-
     int cq[2];
     bool okq[2];
 #pragma unroll
