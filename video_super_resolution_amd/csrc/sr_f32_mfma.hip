@@ -228,6 +228,95 @@ __global__ void __launch_bounds__(256) k_deconv_mfma(const float* __restrict__ i
     }
 }
 
+// The transposed convolution with the pixel operand loaded once per (input row, channel pair): the T column taps dx of a row read
+// the same pixels shifted by dx (ds_bpermute_b32, as k_conv_mfma_sh); a wave owns NT pixel tiles (each weight fragment serves
+// S x NT MFMAs).  All 16 channel pairs of the row are resident (16 (NT + 1) registers),
+// the sum of an output still runs (dy, dx, ci) ascending: bit-identical maps.
+template <int K, int S, int NT>
+__global__ void __launch_bounds__(256) k_deconv_mfma_sh(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                        float slope, float* __restrict__ out, int h, int w) {
+    constexpr int T = (K + S - 1) / S;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.z, Y = blockIdx.y * 4 + wv, q0 = blockIdx.x * (32 * NT);
+    const int H = S * h, W = S * w;
+    if (Y >= H) return;   // (uniform per wave; no barrier)
+    const int iy = (Y + 2) / S, py = (Y + 2) % S;
+    const size_t hw = (size_t)h * w, HW = (size_t)H * W;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)n * NF * hw), 0, (int)(NF * hw * 4), 0x00020000);
+    f16v acc[S][NT];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float b = bias[8 * (r >> 2) + 4 * kh + (r & 3)];
+#pragma unroll
+        for (int px = 0; px < S; ++px)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[px][t][r] = b;
+    }
+    int sidx[T];       // ds_bpermute byte index of the lane dx pixels to the left inside this lane's 32-lane half
+    bool ssame[T];     // ... which lies in the same tile (else: in the tile to the left)
+#pragma unroll
+    for (int dx = 0; dx < T; ++dx) {
+        sidx[dx] = 4 * (32 * kh + ((col - dx) & 31));
+        ssame[dx] = col >= dx;
+    }
+#pragma unroll
+    for (int dy = 0; dy < T; ++dy) {
+        const int yy = iy - dy;
+        if (py + S * dy >= K || yy < 0 || yy >= h) continue;   // (uniform)
+        float R[NF / 2][NT + 1];   // [cp][tile -1 (its last T-1 pixels), 0 .. NT-1]
+#pragma unroll
+        for (int u = 0; u <= NT; ++u) {
+            const int xc = q0 + 32 * (u - 1) + col;
+            const bool ok = xc >= 0 && xc < w && (u > 0 || col >= 32 - (T - 1));
+            const unsigned off = ok ? (unsigned)((((size_t)kh * h + yy) * w + xc) * 4) : 0xFFFFFFFFu;
+            const unsigned cstep = (unsigned)(2 * hw * 4);
+#pragma unroll
+            for (int cp = 0; cp < NF / 2; ++cp)
+                R[cp][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, ok ? off + cp * cstep : 0xFFFFFFFFu, 0, 0));
+        }
+#pragma unroll
+        for (int dx = 0; dx < T; ++dx) {
+            const float* wt = wp + (size_t)((py + S * dy) * K + S * dx) * NF * NF + lane;   // + px * 1024: tap (py + S dy, px + S dx)
+#pragma unroll
+            for (int cp = 0; cp < NF / 2; ++cp) {
+                float b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (dx == 0) b[t] = R[cp][t + 1];
+                    else {
+                        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx[dx], __builtin_bit_cast(int, R[cp][t + 1])));
+                        const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx[dx], __builtin_bit_cast(int, R[cp][t])));
+                        b[t] = ssame[dx] ? v0 : v1;
+                    }
+                }
+#pragma unroll
+                for (int px = 0; px < S; ++px) {
+                    if (px + S * dx >= K) continue;   // (compile time)
+                    const float a = wt[px * NF * NF + 64 * cp];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[px][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[px][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = q0 + 32 * t + col;   // this lane's LR column index, in [0, w]
+        if (q > w) continue;
+#pragma unroll
+        for (int px = 0; px < S; ++px) {
+            const int X = S * q + px - 2;
+            if (X < 0 || X >= W) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 8 * (r >> 2) + 4 * kh + (r & 3);
+                out[((size_t)n * NF + co) * HW + (size_t)Y * W + X] = prelu(acc[px][t][r], slope);
+            }
+        }
+    }
+}
+
 // 1x1 convolution over up to three 32-channel float32 inputs (+ constant map) + PReLU (the FeedbackBlock's compress / uptran /
 // downtran glue in the float32 configuration; sr_f32.hip:k_conv1x1 is its one-pixel-per-thread form: 32 x 32 v_fmac per pixel and
 // input, VALU-bound at 1.1 ms per input on a x2 map of 16.6 M pixels, next to 0.85 ms of HBM time).  Here a wave owns 64 pixels
@@ -323,12 +412,14 @@ void launch_conv1x1_f32_mfma(const float* in0, const float* w0, int ld0, const f
 }
 
 bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale,
-                            hipStream_t stream) {
+                            bool per_tap, hipStream_t stream) {
     if ((size_t)NF * h * w * 4 >= (1ull << 32) - 16 || (scale * h + 3) / 4 > 65535) return false;
     const dim3 grid(vsr::cdiv(w + 1, 64), vsr::cdiv(scale * h, 4), N);
     if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma<8, 4>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
     else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma<7, 3>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
-    else hipLaunchKernelGGL((k_deconv_mfma<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    else if (per_tap) hipLaunchKernelGGL((k_deconv_mfma<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    else   // (two pixel tiles per wave; four measured level: 3.27-3.50 vs 3.39-3.43 ms, at one wave per SIMD instead of two)
+        hipLaunchKernelGGL((k_deconv_mfma_sh<6, 2, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
     return true;
 }
 
