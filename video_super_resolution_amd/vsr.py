@@ -248,7 +248,8 @@ class VSR(nn.Module):
             if shared is not None and self.overlap_shared and self._fast() and self.model.block.num_groups == 6:
                 main = torch.cuda.current_stream(d.device)
                 x_first = d.permute(0, 3, 1, 2).contiguous()
-                live = {k: torch.empty((8, h * w, 32), dtype=torch.float16, device=d.device) for k in (3, 6)}
+                n_planes = self.model.fc[0].in_features   # 8: the planes of one SR call (video_super_resolution.py:40)
+                live = {k: torch.empty((n_planes, h * w, 32), dtype=torch.float16, device=d.device) for k in (3, 6)}
                 s_sr = self._side_streams(d.device)[2]
                 s_sr.wait_stream(main)
                 with torch.cuda.stream(s_sr):
