@@ -415,9 +415,12 @@ bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias,
                             bool per_tap, hipStream_t stream) {
     if ((size_t)NF * h * w * 4 >= (1ull << 32) - 16 || (scale * h + 3) / 4 > 65535) return false;
     const dim3 grid(vsr::cdiv(w + 1, 64), vsr::cdiv(scale * h, 4), N);
-    if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma<8, 4>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
-    else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma<7, 3>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
-    else if (per_tap) hipLaunchKernelGGL((k_deconv_mfma<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    if (per_tap) {
+        if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma<8, 4>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+        else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma<7, 3>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+        else hipLaunchKernelGGL((k_deconv_mfma<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    } else if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma_sh<8, 4, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma_sh<7, 3, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
     else   // (two pixel tiles per wave; four measured level: 3.27-3.50 vs 3.39-3.43 ms, at one wave per SIMD instead of two)
         hipLaunchKernelGGL((k_deconv_mfma_sh<6, 2, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
     return true;
