@@ -370,14 +370,17 @@ def main():
                 achieved = flop / (ms * 1e-3) / 1e12
                 # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
                 # gfx950 correction applied) -- a committed measurement of the same launch geometry, not taken in this run
-                pmcs = {(540, 960, 4): ("r02_k_utd3_pmc.json", "r01_k_utd3_pmc.json"), (1080, 1920, 2): ("r02_k_utd_s2_pmc.json",)}
-                for pmc in pmcs.get((h, w, scale), ()):
+                # (file, planes of the profiled launch): the 5-plane flat-split launch has its own passes (round 3)
+                pmcs = {(540, 960, 4): (("r03_k_utd3_pmc.json", 5), ("r02_k_utd3_pmc.json", 8), ("r01_k_utd3_pmc.json", 8)),
+                        (1080, 1920, 2): (("r02_k_utd_s2_pmc.json", 8),)}
+                cands = sorted(pmcs.get((h, w, scale), ()), key=lambda fp: fp[1] != planes_dom)   # the launch's own geometry first
+                for pmc, pl in cands:
                     path = os.path.join(ROOT, "profiles", pmc)
                     if os.path.exists(path):
                         with open(path) as f:
-                            traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"] * planes_dom / 8.0
-                        traffic_source = f"profiles/{pmc} (rocprofv3 --pmc, separate run of the 8-plane launch geometry" + \
-                            (")" if planes_dom == 8 else f", scaled to {planes_dom} planes: the traffic is per plane)")
+                            traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"] * planes_dom / float(pl)
+                        traffic_source = f"profiles/{pmc} (rocprofv3 --pmc, separate run of the {pl}-plane launch geometry" + \
+                            (")" if planes_dom == pl else f", scaled to {planes_dom} planes: the traffic is per plane)")
                         break
                 roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=FP16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / FP16_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,

@@ -1,11 +1,11 @@
-"""Runs only the fused up->tran->down kernel at the bench size (8 x 540 x 960) -- target for rocprofv3 --pmc."""
+"""Runs only the fused up->tran->down kernel at the bench size (UTD_N planes, default 8, x 540 x 960) -- target for rocprofv3 --pmc."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_super_resolution_amd import SRProjectionModule
 from video_super_resolution_amd.weights import fill_module_
 torch.set_grad_enabled(False)
-N, h, w = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 540, int(sys.argv[2]) if len(sys.argv) > 2 else 960
+N, h, w = int(os.environ.get("UTD_N", "8")), int(sys.argv[1]) if len(sys.argv) > 1 else 540, int(sys.argv[2]) if len(sys.argv) > 2 else 960
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 m = fill_module_(SRProjectionModule().eval(), 0, "model.").cuda()
 P = m._packed()
