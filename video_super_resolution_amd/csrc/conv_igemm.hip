@@ -1695,8 +1695,8 @@ static int g_tile_mode = 1;   // conv_tile.hip (two-operand LDS-DMA tile): 0 nev
 // k_conv1x1_t (contiguous accesses through per-wave LDS slots) for 128-input-channel 1x1 layers: 0 never (default), 1 yes
 // (vsr_conv2d_tuning(7000 + n)).  Measured per layer inside the hourglass (tools/trunk_layers.sh): level with k_conv1x1_stream
 // (4 x 270 x 480 128 -> 128 57 vs 55 us, 128 -> 224 89-93 vs 90-91) and SLOWER on the largest layer (4 x 540 x 960 128 -> 208: 336 vs
-// 371 us) -- inside the network the streaming kernel already moves that layer's 1.39 GB at 4.1 TB/s, i.e. at the device's copy
-// rate; the contiguity of the accesses was not what held it.  Kept as the bit-identical cross-check build.
+// 371 us) -- the contiguity of the accesses was not what holds the streaming kernel (1.39 GB in 336 us = 4.1 TB/s; a hand-written
+// kernel of that traffic shape reaches 5.1-5.6 TB/s, profiles/r03_stream_rates.txt).  Kept as the bit-identical cross-check build.
 static int g_c1t_mode = 0;
 static int g_lw_mode = 1;     // k_conv_patch_lw (weight block in LDS): 0 never, 1 heuristic, 2 wherever a build exists (vsr_conv2d_tuning(6000 + n))
 static int g_tile_bn = 0, g_tile_splits = 0;   // experiments: force the tile width (64 / 128) / the split count (vsr_conv2d_tuning(4000 + bn), (5000 + n)); 0 = heuristic
