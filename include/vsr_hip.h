@@ -195,7 +195,7 @@ int vsr_sr_utd_strip_width(void); /* LR columns one workgroup marches down (31) 
  * PReLU)   (SRProjectionModule.py:64,77-80 for the live chain under zero fill).  The x4 feature map stays in LDS.
  * in [N,h,w,32] fp16 -> out [N,h,w,32] fp16.  deconv_only != 0: only up_i + PReLU, out [N,4h,4w,32] fp16 (the
  * `out` DeconvBlock, :118-120,142).  rows_per_seg > 0: LR rows one workgroup marches (h = one march per strip);
- * rows_per_seg = -c (one-wave-per-SIMD build, fused stage only): c workgroups share the N x strips x h rows of the planes'
+ * rows_per_seg = -c (one-wave-per-SIMD build, fused stage only; the other builds then march whole strips): c workgroups share the N x strips x h rows of the planes'
  * strips laid end to end evenly (a share that spans the end of a strip is two marches) -- same values, for plane counts
  * whose strips cannot fill the CUs in whole row segments.
  * slopes_le_one != 0 promises that every PReLU slope packed in the blob is <= 1 (selects the cheaper activation

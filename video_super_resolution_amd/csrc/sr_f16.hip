@@ -1343,7 +1343,7 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
     VSR_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0, "sr_utd: pointers must be 16-byte aligned");
     const bool one_wave_build = !deconv_only && (g_utd_variant == 0 || g_utd_variant == 2 || g_utd_variant == 4);
-    VSR_REQUIRE(rows_per_seg > 0 || one_wave_build, "sr_utd: the flat row split (rows_per_seg < 0) exists in the one-wave-per-SIMD build only");
+    if (rows_per_seg < 0 && !one_wave_build) rows_per_seg = h;   // the flat split exists in the one-wave-per-SIMD build only: one march per strip (same values)
     const unsigned strips = vsr::cdiv(w, TX), segs = rows_per_seg > 0 ? vsr::cdiv(h, rows_per_seg) : 1;
     VSR_REQUIRE(segs <= 65535, "sr_utd: too many row segments");
     typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
