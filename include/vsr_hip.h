@@ -439,9 +439,9 @@ int vsr_train_corr_dw_f32(const float* small, const float* big, float* dw, float
 /* Bias gradient db[c] = sum_{n,p} g[n,c,p]; ws: N * 16 * C floats. */
 int vsr_train_chan_sum_f32(const float* g, float* db, float* ws, int N, int C, size_t P, vsr_stream_t stream);
 /* nn.PReLU(num_parameters=1) (blocks.py:64-71) forward / backward (gv, and dslope[0] = sum g * min(v, 0)). */
-int vsr_train_prelu_f32(const float* v, float slope, float* y, size_t n, vsr_stream_t stream);
+int vsr_train_prelu_f32(const float* v, const float* slope_dev, float* y, size_t n, vsr_stream_t stream);
 size_t vsr_train_prelu_bwd_ws_floats(size_t n);
-int vsr_train_prelu_bwd_f32(const float* v, const float* g, float slope, float* gv, float* dslope, float* ws, size_t n, vsr_stream_t stream);
+int vsr_train_prelu_bwd_f32(const float* v, const float* g, const float* slope_dev, float* gv, float* dslope, float* ws, size_t n, vsr_stream_t stream);
 /* y = (a + b) * scale[c] + shift[c]: MeanShift (blocks.py:46-55) and the skip add + add_mean (SRProjectionModule.py:142-143). */
 int vsr_train_affine_ch_f32(const float* a, const float* b_or_null, const float* scale, const float* shift_or_null, float* y, int N, int C, size_t P,
                             vsr_stream_t stream);

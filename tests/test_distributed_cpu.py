@@ -87,14 +87,14 @@ def _worker_clips(rank, world, port, n_clips, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_clips", [4, 5, 2])
-def test_bench_clip_control_flow_two_ranks(n_clips):
+@pytest.mark.parametrize("world,n_clips", [(2, 4), (2, 5), (2, 2), (4, 6)])
+def test_bench_clip_control_flow(world, n_clips):
     """`bench.py --clips N` (config C4) with a stub model: round-robin clips, per-clip asynchronous gathers, clip order
-    restored on rank 0, a rank without a clip in the last round."""
+    restored on rank 0, ranks without a clip in the last round (4 ranks, 6 clips: the ragged last round of two clips)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_clips, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_clips, args=(r, world, port, n_clips, q)) for r in range(world)]
     for p in procs:
         p.start()
     shape, vals = q.get(timeout=120)
@@ -111,3 +111,40 @@ def test_clip_gather_single_process_is_a_pass_through():
     from video_super_resolution_amd.distributed import run_sharded_clips
     full, n = run_sharded_clips(lambda cid: torch.full((2, 4), float(cid)), 3, 0, 1)
     assert n == 3 and full.shape == (3, 2, 4) and full[:, 0, 0].tolist() == [0.0, 1.0, 2.0]
+
+
+def _worker_subgroup(rank, world, port, q):
+    """Ranks 1 and 2 of a 3-rank world form a sub-group; the root is GLOBAL rank 2 = group rank 1."""
+    sys.path.insert(0, ROOT)
+    from video_super_resolution_amd.distributed import ClipGather, gather_frames
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grp = dist.new_group([1, 2])   # (every rank of the world calls new_group)
+    if rank in (1, 2):
+        local = torch.full((rank, 2, 3), float(rank))   # rank r holds r frames
+        got = gather_frames(local, dst=2, group=grp)
+        cg = ClipGather(2, dst=2, group=grp)
+        cg.submit(torch.full((2, 3), 10.0 * rank))
+        full = cg.finish()
+        if rank == 2:
+            q.put(([tuple(t.shape) for t in got], [float(t.flatten()[0]) for t in got], full[:, 0, 0].tolist()))
+        else:
+            assert got is None and full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_root_given_as_global_rank_in_a_subgroup():
+    """`dst` is a global rank; inside a sub-group the "am I the root" test must use the group rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_subgroup, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    shapes, firsts, clip_vals = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert shapes == [(1, 2, 3), (2, 2, 3)] and firsts == [1.0, 2.0]
+    assert clip_vals == [10.0, 20.0]

@@ -76,6 +76,11 @@ def test_reference_saved_checkpoint_loads_strict_and_round_trips(tmp_path):
     assert refused
     driver.load_checkpoint(m2, name, map_location="cpu", trusted=True)
     assert torch.equal(m2.model.fc[0].weight, m.model.fc[0].weight)
+    # errors that are NOT the weights-only refusal stay what they are (and never become "pass trusted=True")
+    with pytest.raises(FileNotFoundError):
+        driver.load_checkpoint(m2, str(tmp_path / "no_such_file.pth.tar"), map_location="cpu")
+    with pytest.raises(FileNotFoundError):
+        driver.load_checkpoint(m2, str(tmp_path / "no_such_file.pth.tar"), map_location="cpu", trusted=True)
 
 
 def test_oracle_make_lr_is_the_pixels_4i_4j():

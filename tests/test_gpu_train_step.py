@@ -76,7 +76,9 @@ def test_train_prelu_affine_and_fusion_gradients():
     import torch.nn.functional as F
     from video_super_resolution_amd.sr_train import AffineFn, FusionFn, PReLUFn
     rs = np.random.RandomState(9)
-    v = torch.from_numpy(rs.randn(3, 32, 17, 19).astype(np.float32)).cuda().requires_grad_()
+    v0 = rs.randn(3, 32, 17, 19).astype(np.float32)
+    v0[rs.rand(*v0.shape) < 0.2] = 0.0   # exact zeros (the zero-filled FeedbackBlock produces them): ATen passes slope * g there
+    v = torch.from_numpy(v0).cuda().requires_grad_()
     g = torch.from_numpy(rs.randn(3, 32, 17, 19).astype(np.float32)).cuda()
     for slope in (0.2, 1.7, -0.3):
         a = torch.tensor([slope], device="cuda", requires_grad=True)

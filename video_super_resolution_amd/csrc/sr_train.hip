@@ -176,23 +176,27 @@ __global__ void __launch_bounds__(kB) k_chan_sum(const float* __restrict__ g, fl
     if (threadIdx.x == 0) partial[((size_t)n * nseg + seg) * C + c] = t;
 }
 
-__global__ void __launch_bounds__(kB) k_prelu_fwd(const float* __restrict__ v, float slope, float* __restrict__ y, size_t n) {
+// the slope is read from device memory (the module's parameter itself): no host read-back per activation
+__global__ void __launch_bounds__(kB) k_prelu_fwd(const float* __restrict__ v, const float* __restrict__ slope_p, float* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
-    if (i < n) y[i] = v[i] >= 0.0f ? v[i] : v[i] * slope;
+    const float slope = *slope_p;
+    if (i < n) y[i] = v[i] > 0.0f ? v[i] : v[i] * slope;
 }
 
-// gv = g * (v >= 0 ? 1 : slope);  partial[block] = sum g * min(v, 0)   (d/d slope; nn.PReLU(num_parameters=1), blocks.py:64-71)
-__global__ void __launch_bounds__(kB) k_prelu_bwd(const float* __restrict__ v, const float* __restrict__ g, float slope, float* __restrict__ gv,
-                                                  float* __restrict__ partial, size_t n, int per_thread) {
+// gv = g * (v > 0 ? 1 : slope)  (ATen's convention at v == 0: the slope side; exact zeros occur in the zero-filled FeedbackBlock);
+// partial[block] = sum g * min(v, 0)   (d/d slope; nn.PReLU(num_parameters=1), blocks.py:64-71)
+__global__ void __launch_bounds__(kB) k_prelu_bwd(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ slope_p,
+                                                  float* __restrict__ gv, float* __restrict__ partial, size_t n, int per_thread) {
     __shared__ double sm[kB];
     double s = 0.0;
+    const float slope = *slope_p;
     const size_t base = (size_t)blockIdx.x * kB * per_thread;
     for (int j = 0; j < per_thread; ++j) {
         const size_t i = base + (size_t)j * kB + threadIdx.x;
         if (i < n) {
             const float vv = v[i], gg = g[i];
-            gv[i] = vv >= 0.0f ? gg : gg * slope;
-            s += vv >= 0.0f ? 0.0 : (double)gg * (double)vv;
+            gv[i] = vv > 0.0f ? gg : gg * slope;
+            s += vv > 0.0f ? 0.0 : (double)gg * (double)vv;
         }
     }
     const float t = block_sum(s, sm);
@@ -321,8 +325,8 @@ int vsr_train_chan_sum_f32(const float* g, float* db, float* ws, int N, int C, s
     return vsr::launched("train_chan_sum/sum");
 }
 
-int vsr_train_prelu_f32(const float* v, float slope, float* y, size_t n, vsr_stream_t stream) {
-    VSR_REQUIRE(v && y && n > 0, "train_prelu: bad arguments");
+int vsr_train_prelu_f32(const float* v, const float* slope, float* y, size_t n, vsr_stream_t stream) {
+    VSR_REQUIRE(v && y && slope && n > 0, "train_prelu: bad arguments");
     hipLaunchKernelGGL(k_prelu_fwd, dim3(vsr::cdiv((long long)n, kB)), dim3(kB), 0, vsr::S(stream), v, slope, y, n);
     return vsr::launched("train_prelu");
 }
@@ -330,8 +334,8 @@ int vsr_train_prelu_f32(const float* v, float slope, float* y, size_t n, vsr_str
 size_t vsr_train_prelu_bwd_ws_floats(size_t n) { return (n + (size_t)kB * 16 - 1) / ((size_t)kB * 16); }
 
 /* gv = g * (v >= 0 ? 1 : slope); dslope[0] = sum g * min(v, 0) */
-int vsr_train_prelu_bwd_f32(const float* v, const float* g, float slope, float* gv, float* dslope, float* ws, size_t n, vsr_stream_t stream) {
-    VSR_REQUIRE(v && g && gv && dslope && ws && n > 0, "train_prelu_bwd: bad arguments");
+int vsr_train_prelu_bwd_f32(const float* v, const float* g, const float* slope, float* gv, float* dslope, float* ws, size_t n, vsr_stream_t stream) {
+    VSR_REQUIRE(v && g && slope && gv && dslope && ws && n > 0, "train_prelu_bwd: bad arguments");
     const size_t blocks = vsr_train_prelu_bwd_ws_floats(n);
     VSR_REQUIRE(blocks < (1ull << 31), "train_prelu_bwd: too many elements");
     hipLaunchKernelGGL(k_prelu_bwd, dim3((unsigned)blocks), dim3(kB), 0, vsr::S(stream), v, g, slope, gv, ws, n, 16);

@@ -39,9 +39,11 @@ def gather_frames(local: torch.Tensor, dst: int = 0, group=None, force_collectiv
         pad = torch.zeros((kmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat((local, pad), 0)
     local = local.contiguous()
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    # `dst` is a GLOBAL rank (what dist.gather takes); `rank` is this process's rank inside `group`: compare like with like
+    dst_in_group = dist.get_group_rank(group, dst) if group is not None else dst
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst_in_group else None
     dist.gather(local, bufs, dst=dst, group=group)
-    if rank != dst:
+    if rank != dst_in_group:
         return None
     return [b[:c] for b, c in zip(bufs, counts)]
 
@@ -75,6 +77,8 @@ class ClipGather:
         self.dst_in_group = (dist.get_group_rank(group, dst) if group is not None else dst) if self.dist else 0
         self.rounds = []   # (work handle or None, receive buffers or [local])
         self._shape = None
+        self.wait_ms: List[float] = []   # per round: how long finish() stood waiting for that round's transfer (diagnostic)
+        self.root_bytes = 0              # bytes of receive buffers this rank holds as the root (C4: 32 clips x K frames on rank 0)
 
     def submit(self, frames: Optional[torch.Tensor], like: Optional[torch.Tensor] = None):
         """frames [K, ...] of this rank's clip of the current round (None: no clip this round; `like` gives the shape)."""
@@ -87,16 +91,39 @@ class ClipGather:
             self.rounds.append((None, [frames]))
             return
         bufs = [torch.empty_like(frames) for _ in range(self.world)] if self.rank == self.dst_in_group else None
+        if bufs is not None:
+            self.root_bytes += sum(b.numel() * b.element_size() for b in bufs)
         work = dist.gather(frames, bufs, dst=self.dst, group=self.group, async_op=True)
         self.rounds.append((work, bufs, frames))   # keep `frames` alive until the transfer has completed
 
     def finish(self) -> Optional[torch.Tensor]:
+        import time
         out = []
+        marks = []
         for entry in self.rounds:
             if entry[0] is not None:
-                entry[0].wait()
+                # RCCL: wait() orders the CURRENT STREAM behind the transfer (the host does not block), so the stall is
+                # measured with events on that stream; gloo / CPU tensors: wait() blocks the host, measured on its clock
+                on_gpu = entry[2].is_cuda
+                if on_gpu:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    entry[0].wait()
+                    e1.record()
+                    marks.append((e0, e1))
+                else:
+                    t0 = time.perf_counter()
+                    entry[0].wait()
+                    marks.append(1e3 * (time.perf_counter() - t0))
             if self.rank == self.dst_in_group:
                 out.extend(entry[1])
+        self.wait_ms = []
+        for m in marks:
+            if isinstance(m, tuple):
+                m[1].synchronize()
+                self.wait_ms.append(m[0].elapsed_time(m[1]))
+            else:
+                self.wait_ms.append(m)
         self.rounds = []
         if self.rank != self.dst_in_group:
             return None
@@ -131,4 +158,6 @@ def run_sharded_clips(forward_clip, n_clips: int, rank: int, world: int, dst: in
         else:
             pending_none += 1
     assert pending_none == 0
-    return g.finish(), len(mine)
+    full = g.finish()
+    run_sharded_clips.last = dict(gather_wait_ms=[round(x, 3) for x in g.wait_ms], root_resident_bytes=int(g.root_bytes), rounds=rounds)
+    return full, len(mine)

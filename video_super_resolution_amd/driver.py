@@ -159,9 +159,11 @@ def load_checkpoint(model, path: str, map_location=None, trusted: bool = False) 
     The file is first read with `weights_only=True` (tensors and plain containers only).  The reference's checkpoints hold
     the pickled Adam OBJECT under 'optimizer' (main.py:236), which that mode refuses: such a file is unpickled in full only
     when the caller says it is `trusted` (unpickling runs arbitrary code from the file)."""
+    import pickle
     try:
         ckpt = torch.load(path, map_location=map_location, weights_only=True)
-    except Exception as e:   # pickle.UnpicklingError and friends: an object beyond tensors / containers
+    except pickle.UnpicklingError as e:   # ONLY the weights-only refusal (an object beyond tensors / containers); a missing or
+        #                                   corrupt file, a bad map_location etc. propagate as what they are
         if not trusted:
             raise RuntimeError(f"{path} holds pickled objects beyond tensors (the reference saves its optimizer object, "
                                f"main.py:236); pass trusted=True to unpickle it in full -- only for files you trust") from e

@@ -547,7 +547,7 @@ class SRProjectionModule(nn.Module):
         # (timer names carry the plane count when it is not the full 8: the roofline leg prices a launch by its planes)
         tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else ("sr_utd_f16" if N == 8 else f"sr_utd_f16_p{N}"))
         L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
-                                        self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256), flat_ok=not deconv_only and self.utd_flat_split),
+                                        self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256), flat_ok=not deconv_only and getattr(self, "utd_flat_split", True)),
                                         int(deconv_only), int(self._pack["slopes_le_one"]),
                                         L.stream()), "sr_utd_f16")
         L.TIMER.stop(tok)

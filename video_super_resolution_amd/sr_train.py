@@ -121,20 +121,21 @@ class PReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, a):
         v = v.contiguous()
-        ctx.save_for_backward(v, a)
+        slope = a.detach().to(torch.float32).reshape(1).contiguous()   # read by the kernels from device memory: no host sync
+        ctx.save_for_backward(v, a, slope)
         y = torch.empty_like(v)
-        L.check(L.load().vsr_train_prelu_f32(L.dptr(v), L.cf(float(a.detach())), L.dptr(y), ctypes.c_size_t(v.numel()), L.stream()), "train_prelu")
+        L.check(L.load().vsr_train_prelu_f32(L.dptr(v), L.dptr(slope), L.dptr(y), ctypes.c_size_t(v.numel()), L.stream()), "train_prelu")
         return y
 
     @staticmethod
     def backward(ctx, g):
-        v, a = ctx.saved_tensors
+        v, a, slope = ctx.saved_tensors   # `slope`: the value forward used
         g = g.contiguous()
         lib = L.load()
         gv = torch.empty_like(v)
         da = torch.empty(1, dtype=torch.float32, device=v.device)
         ws = _ws(lib.vsr_train_prelu_bwd_ws_floats(ctypes.c_size_t(v.numel())), v.device)
-        L.check(lib.vsr_train_prelu_bwd_f32(L.dptr(v), L.dptr(g), L.cf(float(a.detach())), L.dptr(gv), L.dptr(da), L.dptr(ws),
+        L.check(lib.vsr_train_prelu_bwd_f32(L.dptr(v), L.dptr(g), L.dptr(slope), L.dptr(gv), L.dptr(da), L.dptr(ws),
                                             ctypes.c_size_t(v.numel()), L.stream()), "train_prelu_bwd")
         return gv, da.reshape(a.shape)
 

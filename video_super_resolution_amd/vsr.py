@@ -20,8 +20,10 @@ What differs, on purpose:
     GetObjectsForOBJLoss with its own names) under no_grad on the device and returns the reference's 0-d CPU tensor, so the
     reference driver's call `model(x, y, high_frame, estimated_image)` + `real_loss.data` (main.py:199-203) works as is.
     Inference (`train=False`) returns `loss=None`;
-  * the train step's single differentiable call (:64 at main.py:205-210) is served by `SRProjectionModule._forward_autograd`
-    (sr.py) when the module is in training mode with autograd enabled; eval mode or `no_grad` always runs the HIP kernels.
+  * the train step's single differentiable call (:64 at main.py:205-210) is served by `sr_train.forward_train` (forward and
+    backward of the SR net on this repository's own float32 kernels, csrc/sr_train.hip) when the module is in training mode
+    with autograd enabled; eval mode or `no_grad` runs the inference kernels.  (`SRProjectionModule._forward_autograd`, the
+    stock-operator restatement, is a cross-check for the tests only.)
 """
 from __future__ import annotations
 
