@@ -121,6 +121,7 @@ def cpu_baseline(scale: int, sizes=(64, 96, 128), budget_s: float = 75.0):
     m = fill_module_(VSR(upscale_factor=scale).eval(), seed=0)
     P = {k: v.detach() for k, v in m.state_dict().items()}
     pts = []
+    first = None
     t_start = time.time()
     for lr in sizes:
         if pts and (time.time() - t_start) + pts[-1][1] * (lr * lr) / pts[-1][0] > budget_s:   # next tile ~ linear in pixels
@@ -128,8 +129,10 @@ def cpu_baseline(scale: int, sizes=(64, 96, 128), budget_s: float = 75.0):
         data = torch.from_numpy(synthetic_clip(0, 3, lr, lr))
         t0 = time.time()
         with torch.no_grad():
-            vsr_oracle.vsr_forward(P, data, None, upscale_factor=scale)
+            out = vsr_oracle.vsr_forward(P, data, None, upscale_factor=scale)
         pts.append((lr * lr, time.time() - t0))
+        if first is None:
+            first = (lr, data, out)    # kept: the GPU forward on the same tile gives the line's accuracy fields
     px = np.array([p[0] for p in pts], dtype=np.float64)
     sec = np.array([p[1] for p in pts], dtype=np.float64)
     if len(pts) >= 2:
@@ -137,7 +140,40 @@ def cpu_baseline(scale: int, sizes=(64, 96, 128), budget_s: float = 75.0):
     else:
         b, a = sec[0] / px[0], 0.0
     return dict(points=[(int(p), round(float(s), 2)) for p, s in pts], slope_s_per_px=float(b), intercept_s=float(a),
-                cores=cores, cores_available=avail, cpu=cpu_model())
+                cores=cores, cores_available=avail, cpu=cpu_model(), first=first)
+
+
+def accuracy_vs_oracle(model, scale, precision, dev, first=None, lr=64):
+    """PSNR (peak 255) and max error relative to the oracle's value range of ONE VSR.forward (no recurrent estimate) on an LR
+    `lr` x `lr` tile of the synthetic clip: this build on the GPU against the oracle (the CPU restatement of the reference's
+    forward, pinned by the reference-generated fixtures) on identical inputs and weights.  `first`: the
+    oracle's (lr, data, output) if cpu_baseline already evaluated that tile."""
+    if first is None:
+        from oracle import vsr_oracle
+        from video_super_resolution_amd import VSR
+        from video_super_resolution_amd.weights import fill_module_
+        torch.set_num_threads(max(1, min(16, host_cores())))
+        torch.set_flush_denormal(True)
+        P = {k: v.detach() for k, v in fill_module_(VSR(upscale_factor=scale).eval(), seed=0).state_dict().items()}
+        data = torch.from_numpy(synthetic_clip(0, 3, lr, lr))
+        with torch.no_grad():
+            first = (lr, data, vsr_oracle.vsr_forward(P, data, None, upscale_factor=scale))
+    lr, data, ref = first
+    hf = torch.zeros((3, scale * lr, scale * lr, 3), dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        got, _ = model(data.to(dev), None, hf, None, train=False)
+    got, ref = got.float().cpu().numpy().astype(np.float64), ref.numpy().astype(np.float64)
+    err = np.abs(got - ref)
+    mse = float(np.mean(err ** 2))
+    rng = np.abs(ref).max()
+    return dict(psnr_vs_oracle_db=round(10 * np.log10(255.0 ** 2 / max(mse, 1e-30)), 2),
+                max_rel_err=float(f"{err.max() / rng:.3e}"), p99_rel_err=float(f"{np.percentile(err, 99) / rng:.3e}"),
+                median_rel_err=float(f"{np.percentile(err, 50) / rng:.3e}"),
+                note="the guidance planes are DISCRETE (uint8 flow pictures, the 0/1 VOS mask): a rounding-level difference in a trunk flips "
+                     "a few plane pixels by a whole step, which is where the maximum comes from; the percentiles describe the frame",
+                tile=f"one VSR.forward (estimated_image None) on LR {lr}x{lr} of the synthetic clip, x{scale}, {precision}: this build "
+                     f"on the GPU vs the oracle on the CPU, same seeded weights; max_rel_err = max |diff| / max |oracle|",
+                oracle_range=[round(float(ref.min()), 3), round(float(ref.max()), 3)])
 
 
 def other_configs(progress, names=("C3B", "C5", "C2"), steps=5, warmup=2, timeout_s=170):
@@ -149,7 +185,7 @@ def other_configs(progress, names=("C3B", "C5", "C2"), steps=5, warmup=2, timeou
     out = {}
     for name in names:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", name, "--steps", str(steps), "--warmup", str(warmup),
-               "--no-extras", "--no-cpu-baseline", "--no-configs"]
+               "--no-extras", "--no-cpu-baseline", "--no-configs", "--accuracy"]
         progress(f"config {name}: {steps} steps in a child process")
         t0 = time.time()
         try:
@@ -159,7 +195,8 @@ def other_configs(progress, names=("C3B", "C5", "C2"), steps=5, warmup=2, timeou
                 out[name] = dict(error=f"rc {p.returncode}: {p.stderr[-300:]}")
                 continue
             d = json.loads(lines[0])
-            out[name] = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
+            out[name] = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline",
+                                           "psnr_vs_oracle_db", "max_rel_err", "accuracy") if k in d}
             out[name]["wall_s"] = round(time.time() - t0, 1)
         except subprocess.TimeoutExpired:
             out[name] = dict(error=f"no line within {timeout_s} s")
@@ -181,6 +218,9 @@ def main():
                     help="config C4: this many independent clips round-robin over the ranks (clip i -> rank i mod N), `steps` "
                          "frames each, one asynchronous gather per finished clip; 0 = one clip per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accuracy", action="store_true",
+                    help="with --no-cpu-baseline: still evaluate the oracle on ONE LR 64x64 tile (a few CPU seconds) for the line's "
+                         "psnr_vs_oracle_db / max_rel_err fields (the default run takes them from the cpu_baseline's first tile)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and issue every collective (barrier, gathers, all_reduce) even with ONE "
                          "rank: lets a one-GPU box execute the N > 1 code path (tests/test_gpu_rccl_single_rank.py)")
@@ -274,26 +314,41 @@ def main():
         _lib.TIMER.enabled = True
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        gather_info = None
         if args.clips > 0:
             gathered, ran = run_sharded_clips(forward_clip, n_clips, rank, world, dst=0, force_collective=args.force_dist)   # [n_clips, K, H, W, 3] on rank 0
             total_frames = n_clips * args.steps
+            gather_info = dict(getattr(run_sharded_clips, "last", {}))
         else:
             finished = forward_clip(my_clips[0])
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
             g = gather_frames(finished, dst=0, force_collective=args.force_dist)
+            ev[1].record()
             gathered = torch.stack(g) if g is not None else None
             ran = 1
             total_frames = world * args.steps
         torch.cuda.synchronize()
+        own_s = time.perf_counter() - t0       # this rank's own clock: its clips + its part of the gather(s), before the barrier
         if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if gather_info is None:
+            gather_info = dict(gather_wait_ms=[round(ev[0].elapsed_time(ev[1]), 3)], rounds=1,
+                               root_resident_bytes=int(sum(t.numel() * t.element_size() for t in g)) if g is not None else 0)
         _lib.TIMER.enabled = False
         _lib.TIMER.only = None
         progress(f"timed region: {elapsed:.3f} s for {args.steps} steps x {ran} clip(s) on this rank")
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    # per-rank decomposition for the first multi-GPU run (the value below stays frames / MAX-over-ranks time): every rank's own
+    # seconds and frames, gathered outside the timed region
+    mine = torch.tensor([own_s, float(ran * args.steps), float(sum(gather_info.get("gather_wait_ms", [])))], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(world)] if use_dist else [mine]
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, mine)
     elapsed = float(el.item())
+    per_rank = [t.tolist() for t in per_rank]
 
     # ---- two extra loops, reported beside the headline value and never part of it (single GPU only)
     extras = {}
@@ -435,14 +490,27 @@ def main():
             cb = cpu_baseline(scale)
             sec_full = cb["intercept_s"] + cb["slope_s_per_px"] * h * w
             pts = ", ".join(f"{int(p ** 0.5)}x{int(p ** 0.5)}: {s} s" for p, s in cb["points"])
+            acc = accuracy_vs_oracle(model, scale, precision, dev, first=cb["first"])
+            line["psnr_vs_oracle_db"], line["max_rel_err"], line["accuracy"] = acc["psnr_vs_oracle_db"], acc["max_rel_err"], acc
             line["cpu_baseline"] = dict(value=round(1.0 / sec_full, 8), unit="frames/s", cores=cb["cores"], kind="port",
                                         cores_available=cb["cores_available"], cpu=cb["cpu"], points=cb["points"],
                                         sample=f"1 frame of VSR.forward (the oracle, x{scale}) at LR {pts}; least-squares line "
                                                f"{cb['intercept_s']:.2f} s + {cb['slope_s_per_px'] * 1e3:.4f} ms/px evaluated at "
                                                f"LR {h}x{w} = {sec_full:.0f} s per frame (extrapolated)")
+        elif world == 1 and args.accuracy:
+            acc = accuracy_vs_oracle(model, scale, precision, dev)
+            line["psnr_vs_oracle_db"], line["max_rel_err"], line["accuracy"] = acc["psnr_vs_oracle_db"], acc["max_rel_err"], acc
         if (world == 1 and args.config == "C3A" and not args.no_configs and not args.force_dist and args.clips == 0 and
                 args.lr_h is None and args.lr_w is None and args.scale is None and args.precision is None):
             line["configs"] = other_configs(progress)
+        line["ranks"] = dict(frames_per_s=[round(f / t, 3) for t, f, _ in per_rank], own_seconds=[round(t, 4) for t, _, _ in per_rank],
+                             gather_wait_ms=[round(gw, 3) for _, _, gw in per_rank],
+                             note="per rank: frames it produced / its own wall time up to the end of its gather(s) (before the closing "
+                                  "barrier); gather_wait_ms = time its stream stood behind the gather transfers")
+        line["gather"] = dict(rounds=gather_info.get("rounds"), root_resident_bytes=gather_info.get("root_resident_bytes"),
+                              root_wait_ms_per_round=gather_info.get("gather_wait_ms"),
+                              note="rank 0: receive buffers it holds for the gathered frames (C4: 32 clips x K frames x 49.8 MB fp16) and "
+                                   "how long each round's transfer kept its stream waiting")
         if use_dist:
             line["process_group"] = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), forced_single_rank=bool(args.force_dist))
         print(json.dumps(line))

@@ -385,6 +385,16 @@ int vsr_up2_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int
 int vsr_flownetc_corr_nhwc_f16(const void* feat_a, const void* feat_b, void* out, int out_ld, int out_coff, int B, int H, int W, int C,
                                vsr_stream_t stream);
 
+/* FlowNet's flow head in ONE launch (csrc/conv_flow_head.hip): predict_flow = Conv2d(cin, 2, 3, 1, 1) (reference
+ * networks/submodules.py:32-33) on in[N,H,W,in_ld] slice [in_coff,+cin) -> flow[N,H,W,f_ld] channels f_coff, f_coff+1 (fp16, no
+ * activation), and -- when up_w is given -- the next decoder level's flow upsampling ConvTranspose2d(2, 2, 4, 2, 1) of that flow
+ * (FlowNetS.py:34-37,61-76 `upsampled_flow*_to_*`; bias per sub-network) -> up[N,2H,2W,u_ld] channels u_coff, u_coff+1.
+ * w_packed: [cin/32][32][32] fp16, row n = (ky*3+kx)*2 + co holds w[co][32 chunk + k][ky][kx] (rows 18..31 zero); bias2 [2] or
+ * null; up_w: 64 floats [ci][co][ky][kx] (fp16-representable values: the operand precision of the MFMA path), up_b [2] or null. */
+int vsr_flow_head_f16(const void* in, int in_ld, int in_coff, int cin, const void* w_packed, const float* bias2, void* flow, int f_ld,
+                      int f_coff, const float* up_w, const float* up_b, void* up, int u_ld, int u_coff, int N, int H, int W,
+                      vsr_stream_t stream);
+
 /* ConvTranspose2d(k=4, s=2, p=1) (+bias +activation) as its four 2x2-tap phase convolutions in ONE launch (grid.z walks
  * phase and split-K slice).  w_packed4[py*2+px]: the phase's taps packed like vsr_conv2d_nhwc_f16 weights (kernel rows
  * (3,1) for py = 0, (2,0) for py = 1; same along x).  in [N,H,W,in_ld] -> out [N,2H,2W,out_ld], slice [out_coff,+cout). */

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [[], ["--config", "C3B"], ["--clips", "2"]])
+@pytest.mark.parametrize("extra", [["--accuracy"], ["--config", "C3B"], ["--clips", "2"]])
 def test_bench_line_contract(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--lr-h", "64", "--lr-w", "96",
            "--no-cpu-baseline", "--no-extras"] + extra
@@ -33,3 +33,10 @@ def test_bench_line_contract(extra):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "whole_frame"):
         assert k in r, k
     assert r["bound"] in ("mfma", "hbm") and 0 < r["frac"] < 1
+    # the multi-GPU decomposition fields exist at one rank too (per-rank frames/s, gather waits, the root's resident bytes)
+    assert len(d["ranks"]["frames_per_s"]) == 1 and d["ranks"]["frames_per_s"][0] >= d["value"] * 0.99
+    assert d["gather"]["rounds"] >= 1 and d["gather"]["root_resident_bytes"] > 0
+    if "--accuracy" in extra:   # PSNR / max relative error of this build against the oracle, in the line itself
+        # (the maximum sits on the few pixels where a DISCRETE guidance plane flipped by a whole step: tests/test_gpu_vsr.py)
+        assert d["psnr_vs_oracle_db"] > 58.0 and 0 <= d["max_rel_err"] < 0.5 and d["accuracy"]["p99_rel_err"] < 1e-2, d["accuracy"]
+        assert "oracle" in d["accuracy"]["tile"]

@@ -427,3 +427,92 @@ def test_gather_kernel_five_set_ring(case):
     got = new[..., :cout].permute(0, 3, 1, 2).float()
     assert (got - ref).abs().max().item() <= 3e-3 * ref.abs().max().item()
     assert torch.equal(new, old)
+
+
+@pytest.mark.parametrize("mode", [9002, 9003])
+@pytest.mark.parametrize("case", [  # (N, Cin, H, W, Cout, k, act)
+    (2, 64, 37, 61, 16, 3, igemm.ACT_RELU),     # the hourglass's thin 3x3 (two chunks), ragged tiles
+    (3, 64, 33, 50, 1, 3, igemm.ACT_NONE),      # its final conv (one live out-channel)
+    (1, 224, 40, 70, 2, 3, igemm.ACT_NONE),     # predict_flow over 7 chunks
+    (2, 32, 19, 33, 32, 3, igemm.ACT_RELU),     # one chunk: the pipeline runs across tiles only
+    (1, 96, 50, 97, 70, 3, igemm.ACT_LEAKY),    # odd out-channel count (cout_pad 128: 64 / 32 per workgroup by mode)
+    (2, 256, 35, 64, 256, 3, igemm.ACT_RELU),   # VGG-stage shape: 8 chunks x 4 out-channel blocks
+    (1, 32, 23, 45, 32, 5, igemm.ACT_RELU), (2, 64, 41, 33, 16, 5, igemm.ACT_RELU),
+    (4, 32, 300, 210, 64, 3, igemm.ACT_RELU),   # more work items than resident workgroups: every workgroup walks several tiles
+])
+def test_patch_kernel_persistent_prefetching(case, mode):
+    """k_conv_patch_pf (conv_patch_pf.hip: persistent over (tile, out-channel block) items, the next stage's patch and weight block
+    prefetched into registers before the tap walk) against the stock operator and against k_conv_patch_r8: the same loop nest per
+    accumulator, so the same bits -- with 64 (mode 9002) / at most 32 (9003) out-channels per workgroup."""
+    from video_super_resolution_amd import _lib as L
+    N, cin, H, W, cout, k, act = case
+    rs = np.random.RandomState(cin + 17 * cout + k + H)
+    x = torch.from_numpy(rs.randn(N, cin, H, W).astype(np.float32)).cuda().half()
+    w = torch.from_numpy((rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).cuda().half().float()
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda()
+    ref = F.conv2d(x.float(), w, b, stride=1, padding=k // 2)
+    ref = F.relu(ref) if act == igemm.ACT_RELU else (F.leaky_relu(ref, 0.1) if act == igemm.ACT_LEAKY else ref)
+    conv = igemm.HConv(w, b, stride=1, pad=k // 2, act=act)
+    lib = L.load()
+    xs = igemm.to_nhwc_half(x)
+    try:
+        lib.vsr_conv2d_tuning(2)        # every legal layer through the patch builds
+        lib.vsr_conv2d_tuning(2000)     # (not the tile kernel)
+        lib.vsr_conv2d_tuning(mode)
+        out = conv(xs).clone()
+        assert lib.vsr_last_route().decode().startswith("patch_pf<"), lib.vsr_last_route().decode()
+        lib.vsr_conv2d_tuning(9000)
+        lib.vsr_conv2d_tuning(6000)
+        out_r8 = conv(xs).clone()
+        assert lib.vsr_last_route().decode().startswith("patch_r8<"), lib.vsr_last_route().decode()
+    finally:
+        lib.vsr_conv2d_tuning(0)
+        lib.vsr_conv2d_tuning(2001)
+        lib.vsr_conv2d_tuning(6001)
+        lib.vsr_conv2d_tuning(9001)
+    got = igemm.to_nchw_float(out, cout)
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    if out.shape[3] > cout:
+        assert float(out[..., cout:].abs().max()) == 0.0
+    assert torch.equal(out, out_r8)
+
+
+@pytest.mark.parametrize("case", [  # (N, cin, H, W, in_ld extra, with upsampling, upsampling bias)
+    (2, 1024, 8, 15, 0, True, True), (2, 1026, 16, 30, 30, True, False), (1, 770, 32, 60, 30, True, True), (2, 386, 64, 120, 30, True, False),
+    (2, 194, 128, 240, 30, False, False), (1, 128, 37, 45, 0, True, True), (1, 32, 21, 50, 0, True, True), (3, 16, 9, 7, 16, False, False),
+    (1, 512, 5, 3, 0, True, False)])
+def test_flow_head_matches_torch(case):
+    """igemm.HFlowHead (csrc/conv_flow_head.hip: predict_flow as a 1x1 convolution onto 18 tap-channels + the shifted sum, the flow
+    upsampling ConvTranspose2d(2, 2, 4, 2, 1) fused behind it) against the stock operators on the same fp16-rounded operands: every
+    FlowNet head geometry (8 x 15 ... 128 x 240; the concat buffers' odd channel counts; with / without the upsampling and its bias),
+    ragged tiles, one- and many-chunk contractions.  The flow is compared at the fp16 bar; the upsampled flow against the stock
+    transposed convolution OF THE KERNEL'S OWN fp16 flow (what the unfused path computes)."""
+    N, cin, H, W, extra, with_up, up_bias = case
+    rs = np.random.RandomState(cin + H)
+    ld = igemm.pad32(cin) + extra
+    x = torch.zeros((N, H, W, ld), dtype=torch.float16, device="cuda")
+    x[..., :cin] = torch.from_numpy(rs.randn(N, H, W, cin).astype(np.float32)).cuda().half()
+    if extra:
+        x[..., igemm.pad32(cin):] = 7.0    # channels beyond the slice must not be read
+    wp = torch.from_numpy((rs.randn(2, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)).cuda().half().float()
+    bp = torch.from_numpy(rs.randn(2).astype(np.float32)).cuda()
+    wu = torch.from_numpy((rs.randn(2, 2, 4, 4) * 0.3).astype(np.float32)).cuda().half().float() if with_up else None
+    bu = torch.from_numpy(rs.randn(2).astype(np.float32)).cuda() if (with_up and up_bias) else None
+    head = igemm.HFlowHead(wp, bp, wu, bu)
+    up_out, coff = None, 0
+    if with_up:
+        coff = 6
+        up_out = torch.full((N, 2 * H, 2 * W, 32), 3.0, dtype=torch.float16, device="cuda")
+    flow = head(x, up_out=up_out, up_coff=coff)
+    ref = F.conv2d(x[..., :cin].permute(0, 3, 1, 2).float(), wp, bp, padding=1)
+    got = flow[..., :2].permute(0, 3, 1, 2).float()
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert float(flow[..., 2:].abs().max()) == 0.0
+    if with_up:
+        ref_up = F.conv_transpose2d(got, wu, bu, stride=2, padding=1)
+        got_up = up_out[..., coff:coff + 2].permute(0, 3, 1, 2).float()
+        assert (got_up - ref_up).abs().max().item() <= 2e-3 * max(ref_up.abs().max().item(), 1e-3)
+        assert float((up_out[..., :coff] - 3.0).abs().max()) == 0.0 and float((up_out[..., coff + 2:] - 3.0).abs().max()) == 0.0
+    first = flow.clone()
+    again = head(x, up_out=up_out, up_coff=coff)
+    assert torch.equal(again, first)     # deterministic (the four waves' partial sums are added in wave order)

@@ -53,6 +53,13 @@ assert cg.dist and cg.world == 1
 cg.submit(frames); cg.submit(None, like=frames)        # a rank without a clip in the last round submits zeros
 fin = cg.finish()
 assert fin.shape[0] == 2 and torch.equal(fin[0], frames) and float(fin[1].abs().max()) == 0.0
+# (2b) the root given as a GLOBAL rank inside an explicit (sub-)group: group rank == global rank here, the code path is the same
+grp = dist.new_group([0])
+got = gather_frames(frames, dst=0, group=grp, force_collective=True)
+assert isinstance(got, list) and len(got) == 1 and torch.equal(got[0], frames)
+cg = ClipGather(1, dst=0, group=grp, force_collective=True)
+cg.submit(frames)
+assert torch.equal(cg.finish()[0], frames) and len(cg.wait_ms) == 1 and cg.root_bytes == frames.numel() * frames.element_size()
 # (3) bench.py's max-over-ranks of the elapsed time
 el = torch.tensor([1.25], dtype=torch.float64, device=dev)
 dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -83,3 +90,5 @@ def test_bench_under_the_distributed_launcher_with_one_rank(extra):
     d = json.loads(lines[0])
     assert d["process_group"] == {"backend": "nccl", "world_size": 1, "forced_single_rank": True}
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert len(d["ranks"]["frames_per_s"]) == 1 and len(d["gather"]["root_wait_ms_per_round"]) == d["gather"]["rounds"]
+    assert d["gather"]["root_resident_bytes"] >= 2 * 256 * 384 * 3 * 2     # K = 2 fp16 frames of 256 x 384 x 3 per clip

@@ -56,6 +56,35 @@ def test_flownet2_exec(gpu_vsr):
     assert (got - ref).abs().mean().item() < 5e-3 * ref.abs().max().item()
 
 
+def test_flownet2_fused_heads_against_the_per_head_launches(gpu_vsr):
+    """The fused flow heads (igemm.HFlowHead: predict_flow + the next level's flow upsampling in one launch, default) against the
+    first build (generic convolution + transposed convolution per head): the same fp16 operands and fp32 sums in another order,
+    so the sub-networks' flows agree to fp16 rounding; every head of every sub-network is routed to the fused kernel."""
+    from video_super_resolution_amd import _lib as L
+    from video_super_resolution_amd import trunk_exec
+    net = gpu_vsr.FlowModule.net
+    x = torch.from_numpy(np.random.RandomState(5).randint(0, 256, (2, 3, 2, 128, 192)).astype(np.float32)).cuda()
+    ex = FlowNet2Exec(net)
+    outs = {}
+    old = trunk_exec._Refine.fused_heads
+    try:
+        for fused in (True, False):
+            trunk_exec._Refine.fused_heads = fused
+            L.ROUTES.calls, L.ROUTES.enabled = [], True
+            with torch.no_grad():
+                outs[fused] = ex(x).clone()
+            L.ROUTES.enabled = False
+            heads = [lab for lab, _ in L.ROUTES.calls if lab.startswith("flow_head")]
+            assert len(heads) == (4 * 5 + 3 if fused else 0), heads       # C, S1, S2, SD: 5 levels each; fusion: 3
+    finally:
+        trunk_exec._Refine.fused_heads = old
+        L.ROUTES.enabled = False
+    a, b = outs[True], outs[False]
+    rng = b.abs().max().item()
+    print(f"[fused heads vs per-head launches] max {(a - b).abs().max().item() / rng:.3e} mean {(a - b).abs().mean().item() / rng:.3e} of range")
+    assert (a - b).abs().max().item() < 2e-2 * rng and (a - b).abs().mean().item() < 2e-3 * rng
+
+
 def test_osvos_exec(gpu_vsr):
     net = gpu_vsr.VOSModule.net
     x = torch.from_numpy(np.random.RandomState(3).randint(0, 256, (2, 3, 70, 94)).astype(np.float32)).cuda() - 110.0

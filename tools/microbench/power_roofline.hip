@@ -1,0 +1,80 @@
+// power_roofline.hip -- what this chip SUSTAINS on the fused SR stage's instruction shape, measured instead of inferred (VERDICT r3,
+// item 2).  Two loops with NO global-memory traffic, one 4-wave workgroup per CU (one wave per SIMD, like k_utd3), operands random:
+//   mode 0  bare v_mfma_f32_16x16x32_f16: 144 MFMAs per trip round-robin over 16 independent accumulators
+//   mode 1  the same 144 MFMAs with k_utd3's per-row mix between them: 304 VALU (194 packed fp16, 48 DPP moves, 31 fp32, 31 converts)
+//           and 17 LDS operations (12 ds_read_b128, 5 ds_write_b64) -- profiles/r03_k_utd3_pmc.json: 144 MFMA / 304 VALU / 17 LDS per wave-row
+// Each workgroup stamps s_memtime / s_memrealtime around its loop (in-kernel clock = d memtime / d memrealtime x 100 MHz,
+// MI355X_MICROARCH.md "DVFS give-back" (6)); the stamps go to a buffer nothing else reads.  tools/power_roofline.py drives it for
+// >= 2 s per mode back to back with k_utd3 on the same device and writes profiles/r04_power_roofline.{txt,json}.
+#include <hip/hip_runtime.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k_power(const unsigned* __restrict__ seed, int trips, long long* __restrict__ stamps, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 160 KB requested: ONE workgroup per CU
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // random operands: 4 A fragments, 4 B fragments (fp16 in [-2, 2)), random VALU inputs
+    h8 A[4], B[4];
+    unsigned vx[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u4 ra = *reinterpret_cast<const u4*>(seed + ((i * 256 + tid) * 4));
+        const u4 rb = *reinterpret_cast<const u4*>(seed + ((1024 + i * 256 + tid) * 4));
+        A[i] = __builtin_bit_cast(h8, ra);
+        B[i] = __builtin_bit_cast(h8, rb);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vx[i] = seed[8192 + i * 256 + tid];
+    f4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    // this wave's LDS slice: written once with random data, then read / rewritten in the loop
+    const unsigned laddr = (unsigned)(wv * 16384 + lane * 16);
+    for (int k = 0; k < 16; ++k) *reinterpret_cast<u4*>(lds + wv * 16384 + k * 1024 + lane * 16) = *reinterpret_cast<const u4*>(seed + ((k * 64 + lane) * 4));
+    __syncthreads();
+    int n = trips;
+    const unsigned x0 = vx[0], x1 = vx[1];
+#define PR_OPERANDS                                                                                                                          \
+    [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]), [c5] "+v"(acc[5]), [c6] "+v"(acc[6]),      \
+        [c7] "+v"(acc[7]), [c8] "+v"(acc[8]), [c9] "+v"(acc[9]), [c10] "+v"(acc[10]), [c11] "+v"(acc[11]), [c12] "+v"(acc[12]),               \
+        [c13] "+v"(acc[13]), [c14] "+v"(acc[14]), [c15] "+v"(acc[15]), [n] "+s"(n)                                                             \
+        : [a0] "v"(A[0]), [a1] "v"(A[1]), [a2] "v"(A[2]), [a3] "v"(A[3]), [b0] "v"(B[0]), [b1] "v"(B[1]), [b2] "v"(B[2]), [b3] "v"(B[3]),     \
+          [la] "v"(laddr), [x0] "v"(x0), [x1] "v"(x1)
+#define PR_CLOBBERS                                                                                                                          \
+    "memory", "scc", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", \
+        "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231",      \
+        "v232", "v233", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243"
+    const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (MODE == 0) {
+        asm volatile(
+#include "power_roofline_body0.inc"
+            : PR_OPERANDS : PR_CLOBBERS);
+    } else {
+        asm volatile(
+#include "power_roofline_body1.inc"
+            : PR_OPERANDS : PR_CLOBBERS);
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) { stamps[blockIdx.x * 2] = t1 - t0; stamps[blockIdx.x * 2 + 1] = r1 - r0; }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678f) sink[tid] = s;   // (never true: keeps the results live)
+}
+
+extern "C" int pr_run(int mode, const void* seed, int trips, void* stamps, void* sink, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_power<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_power<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    if (mode == 0) hipLaunchKernelGGL(k_power<0>, dim3(256), dim3(256), 160 * 1024, st, (const unsigned*)seed, trips, (long long*)stamps, (float*)sink);
+    else hipLaunchKernelGGL(k_power<1>, dim3(256), dim3(256), 160 * 1024, st, (const unsigned*)seed, trips, (long long*)stamps, (float*)sink);
+    return (int)hipGetLastError();
+}

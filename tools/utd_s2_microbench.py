@@ -8,6 +8,7 @@ from video_super_resolution_amd.weights import fill_module_
 torch.set_grad_enabled(False)
 N, h, w = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 1080, int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+if len(sys.argv) > 4: N = int(sys.argv[4])   # planes per launch (5: what both SR passes launch)
 m = fill_module_(SRProjectionModule(upscale_factor=2).eval(), 0, "model.").cuda()
 st = m._packed()["stage"][0]
 a = (torch.randn(N, h, w, 32, device="cuda") * 20).half()

@@ -39,4 +39,9 @@ __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 64 + ((
 // Requires cout_pad % bn == 0; p.splits / p.ws / p.nphase set like for the gather kernel.  Returns VSR_OK or an error.
 int launch_conv_tile(const ConvP& p, int bn, hipStream_t stream);
 
+// conv_patch_pf.hip: the persistent, prefetching LDS-patch kernel for stride-1 3x3 / 5x5 layers, 16 mt out-channels per workgroup.
+// Requires a square kernel, stride 1, cout_pad % (16 mt) == 0, N <= 65535 images (the patch kernels' legality rules).
+bool patch_pf_has(int kh, int mt);
+int launch_conv_patch_pf(const ConvP& p, int mt, hipStream_t stream);
+
 }  // namespace vsrc

@@ -13,6 +13,7 @@
 // tensor with out_ld channels (concatenations are written in place), with an output pixel stride/offset so the four
 // phases of a k4 s2 transposed convolution are four ordinary 2x2-tap launches.
 #include "conv_common.h"
+#include "conv_patch.h"
 
 namespace {
 
@@ -22,6 +23,14 @@ using vsrc::f4;
 using vsrc::BM;
 using vsrc::ConvP;
 using vsrc::sw_off;
+using vsrc::patch_epilogue;
+using vsrc::patch_epilogue_act;
+using vsrc::patch_pixoff;
+using vsrc::stage_patch;
+using vsrc::patch_pieces;
+using vsrc::stage_patch_cached;
+using vsrc::PT_H;
+using vsrc::PT_W;
 
 struct C0 { static constexpr int value = 0; };
 struct C1 { static constexpr int value = 1; };
@@ -29,74 +38,6 @@ struct C2 { static constexpr int value = 2; };
 struct C3 { static constexpr int value = 3; };
 struct C4 { static constexpr int value = 4; };
 
-// Epilogue of the convolution kernels: bias + activation + fp16, then out through LDS so that a pixel's 16 MT channels leave
-// as whole 16-byte pieces from adjacent lanes (a full 128-byte line per pixel at MT = 4).  Straight from the MFMA
-// layout a store instruction writes 8 bytes per lane, 32 bytes per pixel per out-channel tile; measured on the 3x3
-// FlowNet layers those partial-line writes cost a third of the kernel (3x3 32->64 at 2x512x960: 121 -> 88 us).  Wave-local: each
-// wave transposes its own NT x 16 pixels in its own LDS slice (the caller has synchronised after the last patch read).
-// acc(ti, mt) -> f4 of pixel-tile ti; pixoff(ti, li) -> element offset of pixel li of tile ti in the output tensor (its
-// channel 0), or -1 when the pixel does not exist.
-template <int MT, int NT, int ACT, class GetAcc, class PixOf>
-__device__ __forceinline__ void patch_epilogue_act(const ConvP& p, unsigned char* wave_lds, int co0, int lane, GetAcc acc, PixOf pixoff) {
-    constexpr int RB = 32 * MT, LPP = 2 * MT, PPI = 64 / LPP;
-    const int l15 = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int c = co0 + 16 * mt + 4 * g;
-        float bz[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bz[e] = (p.bias && c + e < p.cout) ? p.bias[c + e] : 0.0f;
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti) {
-            const f4 a = acc(ti, mt);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float tt = a[e] + bz[e];
-                if (ACT == 1) tt = fmaxf(tt, 0.0f);
-                else if (ACT == 2) tt = tt >= 0.0f ? tt : tt * p.slope;
-                v[e] = tt;
-            }
-            *reinterpret_cast<h4*>(wave_lds + (ti * 16 + l15) * RB + (((2 * mt + (g >> 1)) ^ (l15 & (LPP - 1))) << 4) + ((g & 1) << 3)) =
-                h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        }
-    }
-    asm volatile("" ::: "memory");   // (same wave, in-order LDS: the reads below see the writes above)
-    const bool vec_ok = ((p.out_coff + co0) & 7) == 0 && (p.out_ld & 7) == 0;
-    const int k = lane % LPP;
-    const int c = co0 + 8 * k;
-#pragma unroll
-    for (int it = 0; it < NT * 16 / PPI; ++it) {
-        const int pl = it * PPI + lane / LPP;
-        const int ti = pl >> 4, li = pl & 15;
-        const long long po = pixoff(ti, li);
-        const h8 v = *reinterpret_cast<const h8*>(wave_lds + pl * RB + ((k ^ (li & (LPP - 1))) << 4));
-        if (po < 0 || c >= p.cout) continue;
-        _Float16* dst = p.out + po + p.out_coff + c;
-        if (vec_ok && c + 8 <= p.cout) {
-            *reinterpret_cast<h8*>(dst) = v;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (c + e < p.cout) dst[e] = v[e];
-        }
-    }
-}
-
-// (the activation is a template constant: tested per value at run time it compiled to two scalar branches per output value --
-//  128 branches per wave in the 3x3 build, whose epilogue and patch addressing together issued 9 vector instructions per MFMA;
-//  PMC on the 32 -> 64 layer at 2 x 512 x 960: 1340 VALU / 586 SALU / 144 MFMA per wave, VALU pipe 51 % busy, MFMA pipe 22 %)
-template <int MT, int NT, class GetAcc, class PixOf>
-__device__ __forceinline__ void patch_epilogue(const ConvP& p, unsigned char* wave_lds, int co0, int lane, GetAcc acc, PixOf pixoff) {
-    if (p.act == 0) patch_epilogue_act<MT, NT, 0>(p, wave_lds, co0, lane, acc, pixoff);
-    else if (p.act == 1) patch_epilogue_act<MT, NT, 1>(p, wave_lds, co0, lane, acc, pixoff);
-    else patch_epilogue_act<MT, NT, 2>(p, wave_lds, co0, lane, acc, pixoff);
-}
-
-__device__ __forceinline__ long long patch_pixoff(const ConvP& p, int n, int oy, int ox) {
-    if (oy >= p.Ho || ox >= p.Wo) return -1;
-    return (long long)((((size_t)n * p.outH + oy * p.oy_mul + p.oy_off) * p.outW + ox * p.ox_mul + p.ox_off) * p.out_ld);
-}
 
 // Epilogue of the gather kernels.  This lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15 (straight
 // from the MFMA layout: the LDS-transposed epilogue of the patch kernels was measured here too and loses 10-25 % on these
@@ -812,96 +753,6 @@ __global__ void __launch_bounds__(256) k_conv1x1_t(const ConvP p) {
 // kh*kw times from L2, which bounds these layers by L2 bandwidth; here a workgroup stages the 2-D input patch of an
 // 8 x 32 output tile in LDS once per 32-channel chunk and walks the taps from LDS.
 // M = 16*MT out-channels, N = pixels (wave w: tile rows 2w, 2w+1), K = taps x channels.
-constexpr int PT_H = 8, PT_W = 32;
-
-// Stages the [PH][PW] x 32-channel input patch of image n, chunk ch into LDS (pixel = 64 B, 16-byte pieces XOR-swizzled
-// by pixel-column bits 1-2).  Six pieces per thread are requested back to back with no branch in between (buffer loads:
-// positions outside the image or past the patch carry an out-of-range offset and read zeros) and only then written to
-// LDS -- a conditional load per piece serialises one memory latency per piece, which was most of the 3x3 layers' time.
-__device__ __forceinline__ void stage_patch(const ConvP& p, unsigned char* patch, int n, int ch, int iy0, int ix0, int PH, int PW, int tid) {
-    constexpr int U = 6;
-    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-    // the buffer resource starts at the patch's first image row: offsets then span PH rows only, whatever the size of the image
-    // (a 2160 x 3840 x 224-channel map is 3.7 GB; with the resource at the image base the 32-bit offsets capped an image at
-    // 2 GiB and such layers fell back to the gather kernel: 127 ms of a 437 ms frame at 4K -> 8K)
-    const int by = iy0 > 0 ? iy0 : 0;
-    const size_t rem_bytes = (size_t)(p.H - by) * p.W * p.in_ld * 2;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<_Float16*>(p.in) + ((size_t)n * p.H + by) * p.W * p.in_ld, 0, (int)(rem_bytes < 0x7FFFFFF0ull ? rem_bytes : 0x7FFFFFF0ull),
-        0x00020000);
-    const int total = PH * PW * 4;
-    const unsigned coff = (unsigned)(p.in_coff + ch * 32) * 2;
-    // piece q = tid + 256 k of the patch = pixel q >> 2 (row py, column px), 16-byte piece q & 3.  One division per call; from slot
-    // to slot the pixel index grows by 64 = dpy rows + dpx columns (a division per piece was half of this function's instructions)
-    const int c4 = tid & 3;
-    int pix = tid >> 2, py = pix / PW, px = pix - py * PW;
-    const int dpy = 64 / PW, dpx = 64 - dpy * PW;
-    const unsigned ld2 = (unsigned)p.in_ld * 2, row2 = (unsigned)p.W * ld2;
-    for (int q0 = 0; q0 < total; q0 += 256 * U) {
-        u4v v[U];
-        int dst[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int iy = iy0 + py, ix = ix0 + px;
-            const bool in = pix * 4 < total;   // (all four pieces of a pixel exist or none: total is a multiple of 4)
-            const bool ok = in && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const unsigned off = ok ? ((unsigned)(iy - by) * row2 + (unsigned)ix * ld2 + coff + c4 * 16) : 0xFFFFFFFFu;
-            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-            dst[u] = in ? pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4) : -1;
-            pix += 64; py += dpy; px += dpx;
-            if (px >= PW) { px -= PW; ++py; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (dst[u] >= 0) *reinterpret_cast<u4v*>(patch + dst[u]) = v[u];
-    }
-}
-
-// The same staging with the pieces' descriptors kept in registers across the 32-channel chunks of a layer: a thread's NP
-// pieces are the same pixels for every chunk -- only the channel offset moves, 64 bytes per chunk -- so the (row, column) walk,
-// the bounds tests and the LDS addresses are computed once per workgroup (`patch_pieces`) and a chunk's staging is one add per
-// piece (`stage_patch_cached`).  A 256 -> 256 3x3 layer spent 330 of its 465 vector instructions per chunk on this walk.
-template <int NP>
-__device__ __forceinline__ void patch_pieces(const ConvP& p, int iy0, int ix0, int PH, int PW, int tid, unsigned (&poff)[NP], int (&pdst)[NP]) {
-    const int by = iy0 > 0 ? iy0 : 0;
-    const int total = PH * PW * 4;
-    const int c4 = tid & 3;
-    int pix = tid >> 2, py = pix / PW, px = pix - py * PW;
-    const int dpy = 64 / PW, dpx = 64 - dpy * PW;
-    const unsigned ld2 = (unsigned)p.in_ld * 2, row2 = (unsigned)p.W * ld2;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int iy = iy0 + py, ix = ix0 + px;
-        const bool in = pix * 4 < total;
-        const bool ok = in && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        poff[k] = ok ? ((unsigned)(iy - by) * row2 + (unsigned)ix * ld2 + (unsigned)p.in_coff * 2 + c4 * 16) : 0xFFFFFFFFu;
-        pdst[k] = in ? pix * 64 + ((c4 ^ ((px >> 1) & 3)) << 4) : -1;
-        pix += 64; py += dpy; px += dpx;
-        if (px >= PW) { px -= PW; ++py; }
-    }
-}
-template <int NP>
-__device__ __forceinline__ void stage_patch_cached(const ConvP& p, unsigned char* patch, int n, int ch, int iy0, const unsigned (&poff)[NP],
-                                                   const int (&pdst)[NP]) {
-    constexpr int U = 6;
-    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-    const int by = iy0 > 0 ? iy0 : 0;
-    const size_t rem_bytes = (size_t)(p.H - by) * p.W * p.in_ld * 2;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<_Float16*>(p.in) + ((size_t)n * p.H + by) * p.W * p.in_ld, 0, (int)(rem_bytes < 0x7FFFFFF0ull ? rem_bytes : 0x7FFFFFF0ull),
-        0x00020000);
-    const unsigned coff = (unsigned)ch * 64u;
-#pragma unroll
-    for (int k0 = 0; k0 < NP; k0 += U) {
-        u4v v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (k0 + u < NP) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, poff[k0 + u] == 0xFFFFFFFFu ? 0xFFFFFFFFu : poff[k0 + u] + coff, 0, 0);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (k0 + u < NP && pdst[k0 + u] >= 0) *reinterpret_cast<u4v*>(patch + pdst[k0 + u]) = v[u];
-    }
-}
 
 
 
@@ -1109,7 +960,9 @@ __global__ void __launch_bounds__(256) k_deconv4s2_patch(const ConvP p) {
 // is read once and feeds the up-to-eight output rows it belongs to (row y, tap row ky = row y+1, tap row ky-1), and a
 // fragment is replaced by the next column's as soon as its last row has used it.  Per column: 8 KH MT MFMAs for KH MT
 // fragment loads and KH+7 LDS reads -- half the L1 traffic and a third to a sixth of the LDS traffic per MFMA.
-constexpr int P8_H = 16, P8_W = 32, P8_R = 8;
+using vsrc::P8_H;
+using vsrc::P8_W;
+using vsrc::P8_R;
 template <int KH, int MT>
 __global__ void __launch_bounds__(256) k_conv_patch_r8(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
@@ -1700,6 +1553,7 @@ static int g_tile_mode = 1;   // conv_tile.hip (two-operand LDS-DMA tile): 0 nev
 static int g_c1t_mode = 0;
 static int g_lw_mode = 1;     // k_conv_patch_lw (weight block in LDS): 0 never, 1 heuristic, 2 wherever a build exists (vsr_conv2d_tuning(6000 + n))
 static int g_tile_bn = 0, g_tile_splits = 0;   // experiments: force the tile width (64 / 128) / the split count (vsr_conv2d_tuning(4000 + bn), (5000 + n)); 0 = heuristic
+static int g_pf_mode = 1;     // k_conv_patch_pf (persistent, prefetching; conv_patch_pf.hip): 0 never, 1 heuristic, 2 wherever a build exists (64 out-channels per workgroup where the count allows), 3 as 2 with at most 32 per workgroup (vsr_conv2d_tuning(9000 + n))
 static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
 
 // byte range a gather kernel's buffer resource and its 32-bit offsets cover (0xFFFFFFFF marks "outside the image")
@@ -1731,6 +1585,20 @@ static int tile_choice(const ConvP& p, long long M, int nk_all, int nph, int* sp
         *splits = (int)((320 + nwg128 - 1) / nwg128);
         return 128;
     }
+    return 0;
+}
+
+// Where k_conv_patch_pf replaces k_conv_patch_r8 / _lw: -> 0 (not) or the out-channel tiles (16 each) per workgroup.
+static int pf_choice(const ConvP& p, int N) {
+    const int natural = p.cout_pad == 16 ? 1 : (p.cout_pad & 63) == 0 ? 4 : (p.cout_pad & 31) == 0 ? 2 : 0;
+    if (!natural) return 0;
+    if (g_pf_mode >= 2) {
+        int mt = natural;
+        if (g_pf_mode == 3 && mt == 4) mt = 2;
+        while (mt > 1 && !vsrc::patch_pf_has(p.kh, mt)) mt >>= 1;
+        return vsrc::patch_pf_has(p.kh, mt) ? mt : 0;
+    }
+    // heuristic (mode 1): filled in from per-layer measurements inside the trunks (tools/trunk_layers.sh)
     return 0;
 }
 
@@ -1767,6 +1635,7 @@ extern "C" {
 
 int vsr_conv2d_tuning(int patch_mode) {
     const int old = g_patch_mode;
+    if (patch_mode >= 9000) { g_pf_mode = patch_mode - 9000; return old; }
     if (patch_mode >= 8000) { g_gather_deep = patch_mode - 8000; return old; }
     if (patch_mode >= 7000) { g_c1t_mode = patch_mode - 7000; return old; }
     if (patch_mode >= 6000) { g_lw_mode = patch_mode - 6000; return old; }
@@ -2047,6 +1916,16 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         const int r8_mt = (cout_pad & 31) == 0 ? 2 : (cout_pad == 16 ? 1 : 0);
         if (!no_r8 && r8_mt && r8_lds <= 80 * 1024 && Ho >= 12 && (kh == 3 || kh == 5 || kh == 7 || kh == 11)) {
             hipStream_t st = vsr::S(stream);
+            // the persistent, prefetching build (conv_patch_pf.hip): see pf_choice
+            if (g_pf_mode >= 1 && kh == kw && g_patch_mode != 5) {
+                const int pf_mt = pf_choice(p, N);
+                if (pf_mt) {
+                    vsr::route("patch_pf<%d,%d>", kh, pf_mt);
+                    const int rc = vsrc::launch_conv_patch_pf(p, pf_mt, st);
+                    if (rc) return rc;
+                    return vsr::launched("conv2d_nhwc_f16/patch_pf");
+                }
+            }
             // 3x3 layers on many pixels: the build with the weight block in LDS (k_conv_patch_lw), 64 out-channels per workgroup
             // (32 for a 32-channel layer with >= 64 inputs).  Measured per layer inside the trunks (tools/trunk_layers.sh,
             // profiles/r03_patch_lw_layers.txt): 540 x 960 64 -> 64 130 -> 97 us, 270 x 480 128 -> 128 110 -> 79, 64 -> 128 68 -> 54,

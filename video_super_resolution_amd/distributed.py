@@ -88,6 +88,7 @@ class ClipGather:
             frames = torch.zeros_like(like)
         frames = frames.contiguous()
         if not self.dist:
+            self.root_bytes += frames.numel() * frames.element_size()
             self.rounds.append((None, [frames]))
             return
         bufs = [torch.empty_like(frames) for _ in range(self.world)] if self.rank == self.dst_in_group else None

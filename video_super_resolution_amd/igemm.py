@@ -235,6 +235,50 @@ class HDeconv4s2:
         return out
 
 
+class HFlowHead:
+    """FlowNet's flow head in one launch (csrc/conv_flow_head.hip): predict_flow (Conv2d(cin, 2, 3, 1, 1), no activation) and,
+    when `up` is given, the next level's flow upsampling ConvTranspose2d(2, 2, 4, 2, 1) of the predicted flow, written into a
+    channel slice of that level's concat buffer.  pred_weight [2,cin,3,3]; up_weight [2,2,4,4] (ConvTranspose2d layout [in,out,k,k])."""
+
+    def __init__(self, pred_weight, pred_bias, up_weight=None, up_bias=None, cin_pad=None):
+        w = pred_weight.detach().float()
+        cout, cin, kh, kw = w.shape
+        if (cout, kh, kw) != (2, 3, 3):
+            raise ValueError("HFlowHead: predict_flow is Conv2d(cin, 2, 3, 1, 1)")
+        dev = w.device
+        self.cin_pad = cin_pad or pad32(cin)
+        wp = torch.zeros((self.cin_pad // 32, 32, 32), dtype=torch.float32, device=dev)       # [chunk][n = tap*2+co][k]
+        wfull = torch.zeros((2, self.cin_pad, 3, 3), dtype=torch.float32, device=dev)
+        wfull[:, :cin] = w
+        # n = (ky*3+kx)*2 + co  <-  wfull[co][chunk*32+k][ky][kx]
+        wp[:, :18] = wfull.view(2, self.cin_pad // 32, 32, 9).permute(1, 3, 0, 2).reshape(self.cin_pad // 32, 18, 32)
+        self.w = wp.to(torch.float16).contiguous()
+        self.b = pred_bias.detach().float().contiguous() if pred_bias is not None else None
+        self.up_w = self.up_b = None
+        if up_weight is not None:
+            if tuple(up_weight.shape) != (2, 2, 4, 4):
+                raise ValueError("HFlowHead: the flow upsampling is ConvTranspose2d(2, 2, 4, 2, 1)")
+            self.up_w = up_weight.detach().to(torch.float16).float().contiguous()   # (the MFMA path multiplies fp16 operands)
+            self.up_b = up_bias.detach().float().contiguous() if up_bias is not None else None
+
+    def __call__(self, x, up_out=None, up_coff=0, in_coff=0):
+        """x [N,H,W,ld] -> flow [N,H,W,32] (channels 0, 1 live); with `up_out` [N,2H,2W,ld'] the upsampled flow lands in its
+        channels [up_coff, up_coff + 2)."""
+        N, H, W, in_ld = x.shape
+        flow = cached_zeros(self, "flow", (N, H, W, 32), x.device)
+        if (self.up_w is None) != (up_out is None):
+            raise ValueError("HFlowHead: `up_out` goes with an upsampling weight")
+        tok = L.TIMER.start(f"flow_head N{N} {H}x{W} c{self.cin_pad}") if L.TIMER.enabled else None
+        L.check(L.load().vsr_flow_head_f16(
+            L.dptr(x, torch.float16), in_ld, in_coff, self.cin_pad, L.dptr(self.w, torch.float16), L.optr(self.b), L.dptr(flow, torch.float16), 32, 0,
+            L.optr(self.up_w), L.optr(self.up_b), L.optr(up_out, torch.float16), up_out.shape[3] if up_out is not None else 0, up_coff,
+            N, H, W, L.stream()), "flow_head")
+        L.TIMER.stop(tok)
+        if L.ROUTES.enabled:
+            L.ROUTES.note(f"flow_head N{N} {H}x{W} c{self.cin_pad}{' +up' if up_out is not None else ''}")
+        return flow
+
+
 def pool2x2(x, coff, c, mode):
     """2x2 stride-2 max (mode 0) / average (mode 1) pool of channel slice [coff, coff+c) -> dense [N,H/2,W/2,c];
     mode 2: max with ceil_mode -> [N,ceil(H/2),ceil(W/2),c]."""

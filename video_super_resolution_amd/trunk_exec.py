@@ -21,8 +21,8 @@ import torch.nn.functional as F
 from . import _lib as L
 from . import ops
 from .depth import HOURGLASS
-from .igemm import (ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvPairS2, HConvStem, HDeconv4s2, cached_zeros, pad32, pool2x2, resize_add,
-                    to_nhwc_half)
+from .igemm import (ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvPairS2, HConvStem, HDeconv4s2, HFlowHead, cached_zeros, pad32, pool2x2,
+                    resize_add, to_nhwc_half)
 
 
 def _fold(conv: nn.Conv2d, bn):
@@ -213,24 +213,36 @@ def _cv(seq, stride=1, act=ACT_LEAKY, cin_pad=None):
 
 
 class _Refine:
-    """Coarse-to-fine decoder shared by FlowNetC/S (predict on the concat) and SD (inter_conv before predict)."""
+    """Coarse-to-fine decoder shared by FlowNetC/S (predict on the concat) and SD (inter_conv before predict).
+
+    `fused_heads` (default): predict_flow of a level and the flow upsampling into the next level's concat buffer are ONE launch
+    (igemm.HFlowHead, csrc/conv_flow_head.hip); False: the generic convolution / transposed convolution per head (the first
+    build, kept as the cross-check of tests/test_gpu_trunk_exec.py)."""
+    fused_heads = os.environ.get("VSR_FLOW_HEADS", "1") != "0"
 
     def __init__(self, net, with_inter: bool):
         self.with_inter = with_inter
         self.pred6 = _cv(net.predict_flow6, act=ACT_NONE)
         self.levels = []
+        prev_pred = net.predict_flow6
         for lvl, cin_cat in ((5, 1026), (4, 770), (3, 386), (2, 194)):
             dec = getattr(net, f"deconv{lvl}")[0]
             up = getattr(net, f"upsampled_flow{lvl + 1}_to_{lvl}")
             item = dict(deconv=HDeconv4s2(dec.weight, dec.bias, act=ACT_LEAKY),
                         upflow=HDeconv4s2(up.weight, up.bias, act=ACT_NONE),
                         cat=pad32(cin_cat), dec_c=dec.weight.shape[1])
+            pred = getattr(net, f"predict_flow{lvl}")
             if with_inter:
                 item["inter"] = _cv(getattr(net, f"inter_conv{lvl}"), act=ACT_NONE, cin_pad=pad32(cin_cat))
-                item["pred"] = _cv(getattr(net, f"predict_flow{lvl}"), act=ACT_NONE)
+                item["pred"] = _cv(pred, act=ACT_NONE)
             else:
-                item["pred"] = _cv(getattr(net, f"predict_flow{lvl}"), act=ACT_NONE, cin_pad=pad32(cin_cat))
+                item["pred"] = _cv(pred, act=ACT_NONE, cin_pad=pad32(cin_cat))
+            # the head that PRODUCES this level's upsampled flow: the previous level's predict_flow + this level's upsampling
+            item["head_in"] = HFlowHead(prev_pred.weight, prev_pred.bias, up.weight, up.bias,
+                                        cin_pad=None if (with_inter or lvl == 5) else self.levels[-1]["cat"])
+            prev_pred = pred
             self.levels.append(item)
+        self.head_last = HFlowHead(prev_pred.weight, prev_pred.bias, cin_pad=None if with_inter else self.levels[-1]["cat"])
 
     def alloc_cat(self, idx, N, H, W, dev):
         """Concat buffer of decoder level idx (0 -> level 5 ...) at its resolution; the encoder writes slice 0."""
@@ -239,15 +251,24 @@ class _Refine:
     def __call__(self, c6, cats, enc_c):
         """c6: coarsest features; cats[i]: concat buffer of level 5-i already holding the encoder features in
         [0, enc_c[i]).  Returns flow2 [N,H/4,W/4,32] (2 live channels)."""
-        flow = self.pred6(c6)
-        src = c6
+        if not self.fused_heads:
+            flow = self.pred6(c6)
+            src = c6
+            for i, lv in enumerate(self.levels):
+                cat = cats[i]
+                lv["deconv"](src, out=cat, out_coff=enc_c[i])
+                lv["upflow"](flow, out=cat, out_coff=enc_c[i] + lv["dec_c"])
+                flow = lv["pred"](lv["inter"](cat)) if self.with_inter else lv["pred"](cat)
+                src = cat
+            return flow
+        src = head_src = c6
         for i, lv in enumerate(self.levels):
             cat = cats[i]
             lv["deconv"](src, out=cat, out_coff=enc_c[i])
-            lv["upflow"](flow, out=cat, out_coff=enc_c[i] + lv["dec_c"])
-            flow = lv["pred"](lv["inter"](cat)) if self.with_inter else lv["pred"](cat)
+            lv["head_in"](head_src, up_out=cat, up_coff=enc_c[i] + lv["dec_c"])    # flow of the level above + its upsampling into `cat`
             src = cat
-        return flow
+            head_src = lv["inter"](cat) if self.with_inter else cat
+        return self.head_last(head_src)
 
 
 class _FlowNetSExec:
@@ -352,6 +373,10 @@ class _FusionExec:
         self.up10 = HDeconv4s2(net.upsampled_flow1_to_0.weight, net.upsampled_flow1_to_0.bias)
         self.inter0 = _cv(net.inter_conv0, act=ACT_NONE, cin_pad=pad32(82))
         self.pred0 = _cv(net.predict_flow0, act=ACT_NONE)
+        # predict_flow + the flow upsampling of the next level as one launch (igemm.HFlowHead), like _Refine
+        self.head2 = HFlowHead(net.predict_flow2.weight, net.predict_flow2.bias, net.upsampled_flow2_to_1.weight, net.upsampled_flow2_to_1.bias)
+        self.head1 = HFlowHead(net.predict_flow1.weight, net.predict_flow1.bias, net.upsampled_flow1_to_0.weight, net.upsampled_flow1_to_0.bias)
+        self.head0 = HFlowHead(net.predict_flow0.weight, net.predict_flow0.bias)
 
     def __call__(self, x11):
         N, H, W, _ = x11.shape
@@ -361,6 +386,12 @@ class _FusionExec:
         self.conv0(x11, out=cat0, out_coff=0)                                             # 64
         self.conv1_1(self.conv1(cat0), out=cat1, out_coff=0)                              # 128
         c2 = self.conv2_1(self.conv2(cat1))
+        if _Refine.fused_heads:
+            self.head2(c2, up_out=cat1, up_coff=160)                                      # flow2 + its upsampling (2)
+            self.deconv1(c2, out=cat1, out_coff=128)                                      # 32
+            self.head1(self.inter1(cat1), up_out=cat0, up_coff=80)                        # flow1 + its upsampling (2)
+            self.deconv0(cat1, out=cat0, out_coff=64)                                     # 16
+            return self.head0(self.inter0(cat0))
         flow2 = self.pred2(c2)
         self.deconv1(c2, out=cat1, out_coff=128)                                          # 32
         self.up21(flow2, out=cat1, out_coff=160)                                          # 2
