@@ -105,7 +105,7 @@ int vsr_flownet_up_warp_concat16_f16(const float* x6, const void* flow2_nhwc, in
 /* Build of the warp inside vsr_flownet_up_warp_concat16_f16: 1 (default) the thread-per-pixel gather build (lanes along x, the 2x2
  * neighbourhood served by L1 / L2); 0 an LDS-staged source tile with a halo of 8 pixels, the right column of each lane's 2x2
  * neighbourhood handed over from the next lane by DPP where the flow is smooth, global fallback beyond the halo (BASELINE.json's
- * north_star wording; measured 1.0 - 1.9 x slower).  Bit-identical (resample2d_kernel.cu:16-72's arithmetic). */
+ * north_star wording; measured 1.0 - 1.9 x slower, LAB_NOTES.md 5.4).  Bit-identical (resample2d_kernel.cu:16-72's arithmetic). */
 int vsr_flownet_warp_variant(int variant);
 int vsr_flownet_fusion_input_f16(const float* x6, const void* flow_sd2, int ld_sd, const void* flow_s22, int ld_s2, float div_flow,
                                  void* out32, int B, int H, int W, vsr_stream_t stream);
@@ -384,6 +384,14 @@ int vsr_up2_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int
  * out[b][y][x][out_coff + tj*21 + ti] fp16 (441 channels of an [B,H,W,out_ld] concat buffer), 1/C normalisation. */
 int vsr_flownetc_corr_nhwc_f16(const void* feat_a, const void* feat_b, void* out, int out_ld, int out_coff, int B, int H, int W, int C,
                                vsr_stream_t stream);
+
+/* The front of the depth hourglass in ONE launch (csrc/conv_hg_front.hip; reference pytorch_DIW_scratch.py:34-41 + the first
+ * ChannelConcat of the outermost level): Conv2d(3,128,7,1,3)+BN+ReLU on in4 [N,H,W,4] fp16 (w1_packed / b1 as for
+ * vsr_conv2d_stem_f16), whose 128-channel map is consumed in place by (a) MaxPool2d(2,2) -> pooled [N,H/2,W/2,128] and (b) a
+ * 1x1 convolution + ReLU with c2 out-channels (w2_packed [4][c2_pad][32] fp16 = vsr_conv2d_nhwc_f16's packing of a 128-input 1x1,
+ * b2 [c2_pad]) -> out2 [N,H,W,ld2] channels [0,c2).  stem_out (optional): the 128-channel map itself [N,H,W,s_ld]. */
+int vsr_hg_front_f16(const void* in4, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, int c2, int c2_pad,
+                     void* stem_out_or_null, int s_ld, void* pooled_or_null, void* out2, int ld2, int N, int H, int W, vsr_stream_t stream);
 
 /* FlowNet's flow head in ONE launch (csrc/conv_flow_head.hip): predict_flow = Conv2d(cin, 2, 3, 1, 1) (reference
  * networks/submodules.py:32-33) on in[N,H,W,in_ld] slice [in_coff,+cin) -> flow[N,H,W,f_ld] channels f_coff, f_coff+1 (fp16, no

@@ -383,7 +383,7 @@ def test_conv1x1_transposing_build(case):
             conv(xs, out=dst, out_coff=coff)
             outs.append((dst, lib.vsr_last_route().decode()))
     finally:
-        lib.vsr_conv2d_tuning(7000)   # (the default: the streaming build)
+        lib.vsr_conv2d_tuning(7000)   # (the default: the streaming build; LAB_NOTES.md 5.3)
     (new, r_new), (old, r_old) = outs
     assert r_new == "conv1x1_t" and r_old.startswith("conv1x1_stream<4>"), (r_new, r_old)
     got = new[..., coff:coff + cout].permute(0, 3, 1, 2).float()
@@ -478,8 +478,8 @@ def test_patch_kernel_persistent_prefetching(case, mode):
 
 
 @pytest.mark.parametrize("case", [  # (N, cin, H, W, in_ld extra, with upsampling, upsampling bias)
-    (2, 1024, 8, 15, 0, True, True), (2, 1026, 16, 30, 30, True, False), (1, 770, 32, 60, 30, True, True), (2, 386, 64, 120, 30, True, False),
-    (2, 194, 128, 240, 30, False, False), (1, 128, 37, 45, 0, True, True), (1, 32, 21, 50, 0, True, True), (3, 16, 9, 7, 16, False, False),
+    (2, 1024, 8, 15, 0, True, True), (2, 1026, 16, 30, 32, True, False), (1, 770, 32, 60, 32, True, True), (2, 386, 64, 120, 32, True, False),
+    (2, 194, 128, 240, 32, False, False), (1, 128, 37, 45, 0, True, True), (1, 32, 21, 50, 0, True, True), (3, 16, 9, 7, 16, False, False),
     (1, 512, 5, 3, 0, True, False)])
 def test_flow_head_matches_torch(case):
     """igemm.HFlowHead (csrc/conv_flow_head.hip: predict_flow as a 1x1 convolution onto 18 tap-channels + the shifted sum, the flow

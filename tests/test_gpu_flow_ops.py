@@ -230,7 +230,7 @@ def test_lds_staged_warp_equals_the_gather_build(shape, bilinear, sigma):
                                                          L.dptr(out16, torch.float16), B, H, W, L.stream()))
             outs.append(out16)
     finally:
-        lib.vsr_flownet_warp_variant(1)   # (the default: the gather build is the faster one)
+        lib.vsr_flownet_warp_variant(1)   # (the default: the gather build is the faster one, LAB_NOTES.md 5.4)
     a, b = outs
     same = (a == b) | (torch.isnan(a) & torch.isnan(b))
     assert bool(same.all()), int((~same).sum())

@@ -43,6 +43,43 @@ def test_hourglass_deferred_upsampling_is_bit_identical(gpu_vsr, hw):
     assert torch.equal(fused, two_pass)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 70, 90), (3, 37, 45), (1, 135, 241)])
+def test_hourglass_fused_front_is_bit_identical(gpu_vsr, shape):
+    """igemm.HHourglassFront (csrc/conv_hg_front.hip: stem + max pool + the skip inception's fused 1x1s in one launch, the
+    128-channel stem map never written) against the three launches it replaces -- same MFMA sequences per output, so the same
+    bits: the whole trunk's prediction, and the front's three tensors one by one (ragged tiles, odd sizes: floor-mode pooling)."""
+    from video_super_resolution_amd import igemm
+    netg = gpu_vsr.DepthModule.model.netG
+    N, h, w = shape
+    fr = torch.from_numpy(np.random.RandomState(h + w).randint(0, 256, (N, h, w, 3)).astype(np.float32)).cuda()
+    ex = HourglassExec(netg)
+    assert ex.front is not None and ex.fused_front
+    with torch.no_grad():
+        fused = ex(fr).clone()
+        ex.fused_front = False
+        try:
+            three = ex(fr).clone()
+        finally:
+            ex.fused_front = True
+    assert torch.equal(fused, three)
+    # the front alone, with the stem's own map written too
+    x4 = torch.zeros((N, h, w, 4), dtype=torch.float16, device="cuda")
+    x4[..., :3] = fr
+    inc = ex.prog[1][1][1][0][1][1][1][0][1]
+    stem = ex.prog[1][0][1]
+    buf = torch.full((N, h, w, inc.width), 5.0, dtype=torch.float16, device="cuda")
+    pooled = torch.empty((N, h // 2, w // 2, 128), dtype=torch.float16, device="cuda")
+    smap = torch.empty((N, h, w, 128), dtype=torch.float16, device="cuda")
+    ex.front(x4, buf, pooled, smap)
+    ref_s = stem(x4)
+    assert torch.equal(smap, ref_s[..., :128])
+    assert torch.equal(pooled, igemm.pool2x2(ref_s, 0, 128, 0))
+    ref_b = torch.full_like(buf, 5.0)
+    inc.first(ref_s, out=ref_b, out_coff=0, in_coff=0)
+    c2 = inc.first.cout
+    assert torch.equal(buf[..., :c2], ref_b[..., :c2]) and float((buf[..., c2:] - 5.0).abs().max()) == 0.0
+
+
 def test_flownet2_exec(gpu_vsr):
     net = gpu_vsr.FlowModule.net
     x = torch.from_numpy(np.random.RandomState(2).randint(0, 256, (2, 3, 2, 64, 128)).astype(np.float32)).cuda()
@@ -98,7 +135,7 @@ def test_osvos_exec(gpu_vsr):
 # ------------------------------------------------------------------------------------------------------------------
 # The same executors against the REFERENCE's golden vectors (tests/golden/g4_wrappers.npz, written by the imported
 # reference through oracle/make_golden.py), not only against this repository's own fp32 masters.  Bars = the measured
-# errors recorded in DESIGN.md section 7 plus a margin; every test prints what it measured.
+# errors recorded in LAB_NOTES.md section 7 plus a margin; every test prints what it measured.
 def test_flownet2_exec_vs_reference_golden(golden, gpu_vsr):
     g = golden("g4_wrappers")
     big = torch.from_numpy(g["flow_frames"]).cuda()              # [2,64,128,3]

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3
-# fp16 end-to-end bars (measured on MI355X in round 2)
+# fp16 end-to-end bars (measured on MI355X in round 2; see LAB_NOTES.md section 7)
 # measured: PSNR(255) 63.1 / 63.8 dB, PSNR(signal span) 50.3 / 50.2 dB, p99 0.61 / 0.58, median 0.07 grey levels
 PSNR255_BAR, PSNR_SIGNAL_BAR, P99_BAR = 58.0, 45.0, 1.2
 
@@ -160,7 +160,7 @@ def test_headline_fp16_configuration_end_to_end(golden, gpu_vsr_f16):
         p50, p99 = np.percentile(err, 50), np.percentile(err, 99)
         print(f"[fp16 e2e frame {i}] PSNR(255) {psnr:.2f} dB, PSNR(signal span {span:.1f}) {psnr_sig:.2f} dB, "
               f"median {p50:.4f}, p99 {p99:.4f}, max {err.max():.3f} grey levels")
-        # bars = measured minus a margin for box-to-box differences in the discrete planes
+        # bars = measured (LAB_NOTES.md section 7) minus a margin for box-to-box differences in the discrete planes
         assert psnr > PSNR255_BAR and psnr_sig > PSNR_SIGNAL_BAR and p99 < P99_BAR, (psnr, psnr_sig, p99)
 
 

@@ -16,6 +16,10 @@ def flop(label):
     if m:
         n, h, w, ci, co = map(int, m.groups())
         return 2.0 * n * h * w * ci * co * 16
+    m = re.match(r"hg_front N(\d+) (\d+)x(\d+) c4->128->(\d+)", label)
+    if m:
+        n, h, w, c2 = map(int, m.groups())
+        return 2.0 * n * h * w * (3 * 128 * 49 + 128 * c2)
     m = re.match(r"flow_head N(\d+) (\d+)x(\d+) c(\d+)", label)
     if m:
         n, h, w, ci = map(int, m.groups())

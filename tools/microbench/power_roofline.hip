@@ -53,9 +53,17 @@ __global__ void __launch_bounds__(256, 1) k_power(const unsigned* __restrict__ s
         asm volatile(
 #include "power_roofline_body0.inc"
             : PR_OPERANDS : PR_CLOBBERS);
-    } else {
+    } else if (MODE == 1) {
         asm volatile(
 #include "power_roofline_body1.inc"
+            : PR_OPERANDS : PR_CLOBBERS);
+    } else if (MODE == 2) {
+        asm volatile(
+#include "power_roofline_body2.inc"
+            : PR_OPERANDS : PR_CLOBBERS);
+    } else {
+        asm volatile(
+#include "power_roofline_body3.inc"
             : PR_OPERANDS : PR_CLOBBERS);
     }
     const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -72,9 +80,13 @@ extern "C" int pr_run(int mode, const void* seed, int trips, void* stamps, void*
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_power<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_power<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_power<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_power<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
     if (mode == 0) hipLaunchKernelGGL(k_power<0>, dim3(256), dim3(256), 160 * 1024, st, (const unsigned*)seed, trips, (long long*)stamps, (float*)sink);
-    else hipLaunchKernelGGL(k_power<1>, dim3(256), dim3(256), 160 * 1024, st, (const unsigned*)seed, trips, (long long*)stamps, (float*)sink);
+    else if (mode == 1) hipLaunchKernelGGL(k_power<1>, dim3(256), dim3(256), 160 * 1024, st, (const unsigned*)seed, trips, (long long*)stamps, (float*)sink);
+    else if (mode == 2) hipLaunchKernelGGL(k_power<2>, dim3(256), dim3(256), 160 * 1024, st, (const unsigned*)seed, trips, (long long*)stamps, (float*)sink);
+    else hipLaunchKernelGGL(k_power<3>, dim3(256), dim3(256), 160 * 1024, st, (const unsigned*)seed, trips, (long long*)stamps, (float*)sink);
     return (int)hipGetLastError();
 }

@@ -5,7 +5,7 @@ usage: trunk_layers.py kernel_trace.csv routes.txt -> "label<TAB>route<TAB>us" l
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 labs = [l.rstrip("\n").split("\t") for l in open(sys.argv[2])]
-def isconv(n): return any(k in n for k in ("k_conv_", "k_deconv4s2_patch", "k_stem7_rows", "k_conv1x1", "k_flow_head"))
+def isconv(n): return any(k in n for k in ("k_conv_", "k_deconv4s2_patch", "k_stem7_rows", "k_conv1x1", "k_flow_head", "k_hg_front"))
 conv = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows if isconv(r["Kernel_Name"]) or "k_splitk_finish" in r["Kernel_Name"]]
 # walk backwards: the last len(labs) layers
 out, i = [], len(conv) - 1

@@ -1040,7 +1040,7 @@ __global__ void __launch_bounds__(256) k_conv_patch_r8(const ConvP p) {
 // k_conv_patch_r8 with the chunk's WEIGHT BLOCK staged in LDS once per workgroup.  In k_conv_patch_r8 every wave fetches every
 // weight fragment of its column from L2 (1 KiB per fragment): a 3x3 layer at 32 out-channels per workgroup moves 72 KB of
 // fragments per 32-channel chunk beside a 39-KB patch -- at three workgroups per CU that is ~100 GB/s per CU of L2 -> CU traffic,
-// above what the chip delivers (55-70 GB/s per CU measured on the LDS-DMA tile kernel), so the 3x3 layers with many
+// above what the chip delivers (55-70 GB/s per CU measured on the LDS-DMA tile kernel, LAB_NOTES.md 5.3), so the 3x3 layers with many
 // channels sat at 600-990 TFLOP/s while the 11x11 ones (the same patch feeds 13x the MFMAs) reach 1100-1400.  Here the block
 // [kh*kw][16 MT][32] of a chunk goes to LDS once (18 KB at 32 out-channels, 36 KB at 64, by LDS-DMA: the packed slab of a
 // (tap, chunk) is contiguous), the four waves read their column's fragments from there, and with no weight traffic per wave a

@@ -4,7 +4,7 @@
 // arithmetic order as k_utd (sr_f16.hip): bit-identical output.
 //
 // Why this kernel (all measured on k_utd / earlier builds of this file with s_memtime stamps and ablations,
-// tools/utd_stamps.py):
+// tools/utd_stamps.py, LAB_NOTES.md 5.1):
 //  * k_utd's two waves per SIMD run the same phase at the same time; the older wave wins the MFMA issue, then idles
 //    ~1400 of ~4400 cycles per LR row at the barrier, and the VALU-heavy epilogue never sits beside MFMAs.  Here one
 //    wave owns HR row `wv` of every group with all four column phases and both out-channel halves: one instruction

@@ -235,6 +235,33 @@ class HDeconv4s2:
         return out
 
 
+class HHourglassFront:
+    """The front of the depth hourglass as one launch (csrc/conv_hg_front.hip): the 7x7 stem (3 -> 128, BatchNorm folded, ReLU)
+    whose map is consumed in place by MaxPool2d(2, 2) and by a 1x1 convolution + ReLU (the fused first launch of the skip arm's
+    inception block).  stem: an HConvStem (7x7, 128 out-channels, stride 1, ReLU); one: an HConv (1x1, 128 in, ReLU)."""
+
+    def __init__(self, stem: "HConvStem", one: "HConv"):
+        if (stem.kh, stem.kw, stem.stride, stem.pad, stem.cout, stem.cout_pad, stem.act) != (7, 7, 1, 3, 128, 128, ACT_RELU):
+            raise ValueError("HHourglassFront: the stem is Conv2d(3, 128, 7, 1, 3) + ReLU")
+        if (one.kh, one.kw, one.stride, one.cin_pad, one.act) != (1, 1, 1, 128, ACT_RELU) or one.cout % 8 or one.cout_pad > 256:
+            raise ValueError("HHourglassFront: the second stage is a 1x1 convolution + ReLU over the stem's 128 channels")
+        self.stem, self.one = stem, one
+
+    def __call__(self, x4, out2, pooled=None, stem_out=None):
+        """x4 [N,H,W,4] -> out2 [N,H,W,ld2] channels [0, c2) (written), pooled [N,H//2,W//2,128], stem_out [N,H,W,>=128] (optional)."""
+        N, H, W, c4 = x4.shape
+        assert c4 == 4 and x4.dtype == torch.float16 and out2.shape[:3] == (N, H, W)
+        tok = L.TIMER.start(f"hg_front N{N} {H}x{W} c4->128->{self.one.cout}") if L.TIMER.enabled else None
+        L.check(L.load().vsr_hg_front_f16(
+            L.dptr(x4, torch.float16), L.dptr(self.stem.w, torch.float16), L.optr(self.stem.b), L.dptr(self.one.w, torch.float16), L.optr(self.one.b),
+            self.one.cout, self.one.cout_pad, L.optr(stem_out, torch.float16), stem_out.shape[3] if stem_out is not None else 0,
+            L.optr(pooled, torch.float16), L.dptr(out2, torch.float16), out2.shape[3], N, H, W, L.stream()), "hg_front")
+        L.TIMER.stop(tok)
+        if L.ROUTES.enabled:
+            L.ROUTES.note(f"hg_front N{N} {H}x{W} c4->128->{self.one.cout}")
+        return out2
+
+
 class HFlowHead:
     """FlowNet's flow head in one launch (csrc/conv_flow_head.hip): predict_flow (Conv2d(cin, 2, 3, 1, 1), no activation) and,
     when `up` is given, the next level's flow upsampling ConvTranspose2d(2, 2, 4, 2, 1) of the predicted flow, written into a

@@ -21,8 +21,8 @@ import torch.nn.functional as F
 from . import _lib as L
 from . import ops
 from .depth import HOURGLASS
-from .igemm import (ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvPairS2, HConvStem, HDeconv4s2, HFlowHead, cached_zeros, pad32, pool2x2,
-                    resize_add, to_nhwc_half)
+from .igemm import (ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvPairS2, HConvStem, HDeconv4s2, HFlowHead, HHourglassFront, cached_zeros, pad32,
+                    pool2x2, resize_add, to_nhwc_half)
 
 
 def _fold(conv: nn.Conv2d, bn):
@@ -95,8 +95,30 @@ class _Inception:
 
 
 class HourglassExec:
+    # One launch for the stem + the max pool of the inner arm + the fused 1x1s of the skip arm's inception block
+    # (igemm.HHourglassFront, csrc/conv_hg_front.hip) where the program has that shape (the reference's does); False: the three
+    # launches of the first build (the cross-check of tests/test_gpu_trunk_exec.py).
+    fused_front = os.environ.get("VSR_HG_FRONT", "1") != "0"
+
     def __init__(self, netg: nn.Sequential):
         self.prog = self._build(HOURGLASS, netg)
+        self.front = self._match_front(self.prog)
+
+    @staticmethod
+    def _match_front(prog):
+        """("S", [stem, ("S", [("M", [("S", ["max", ...]), ("S", [("I", J)])]), "+"]), ...]) with J's fused 1x1 over 128 channels
+        -> HHourglassFront, else None."""
+        try:
+            items = prog[1]
+            stem, lvl = items[0], items[1]
+            fan = lvl[1][0]
+            arm_a, arm_b = fan[1]
+            ok = (stem[0] == "stem" and stem[2] == 128 and lvl[0] == "S" and lvl[1][1] == "+" and len(lvl[1]) == 2 and fan[0] == "M" and
+                  arm_a[0] == "S" and arm_a[1][0] == "max" and arm_b[0] == "S" and len(arm_b[1]) == 1 and arm_b[1][0][0] == "I" and
+                  arm_b[1][0][1].cin == 128)
+            return HHourglassFront(stem[1], arm_b[1][0][1].first) if ok else None
+        except (IndexError, TypeError, ValueError, AttributeError):
+            return None
 
     def _build(self, node, mod):
         if isinstance(node, str):
@@ -201,8 +223,28 @@ class HourglassExec:
         stem_first = self.prog[0] == "S" and isinstance(self.prog[1][0], tuple) and self.prog[1][0][0] == "stem"
         x = cached_zeros(self, "in", (k, h, w, 4 if stem_first else 32), frames_nhwc3.device)
         x[..., :3] = frames_nhwc3
-        out, coff, c = self._run(self.prog, x, 0, 32)
+        if self.front is not None and self.fused_front and h >= 2 and w >= 2:
+            out, coff, c = self._run_fused_front(x)
+        else:
+            out, coff, c = self._run(self.prog, x, 0, 32)
         return out[..., coff:coff + 1].permute(0, 3, 1, 2).float()
+
+    def _run_fused_front(self, x4):
+        """The program with its first three launches (stem, max pool of the inner arm, the skip inception's fused 1x1s) as one."""
+        k, h, w, _ = x4.shape
+        items = self.prog[1]
+        arm_a, arm_b = items[1][1][0][1]
+        inc = arm_b[1][0][1]
+        buf = torch.empty((k, h, w, inc.width), dtype=torch.float16, device=x4.device)
+        if inc.width != inc.M + inc.ctot:
+            buf[..., inc.M + inc.ctot:] = 0
+        pooled = torch.empty((k, h // 2, w // 2, 128), dtype=torch.float16, device=x4.device)
+        self.front(x4, buf, pooled)
+        a = self._run(("S", arm_a[1][1:]), pooled, 0, 128, 1)            # the inner arm behind its "max"
+        for conv, moff, ooff in inc.kconvs:                              # the skip arm: the inception's k x k branches
+            conv(buf, out=buf, out_coff=ooff, in_coff=moff)
+        x, coff, c = self._run(("S", ["+"]), [a, (buf, inc.M, inc.ctot)], 0, 0)
+        return self._run(("S", items[2:]), x, coff, c)
 
 
 # ------------------------------------------------------------------------------------------------ FlowNet2
