@@ -379,11 +379,29 @@ int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa,
 int vsr_up2_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, int up2, const void* b_or_null, int b_ld, int b_coff,
                                 int b_up2, void* out, int N, int H, int W, int C, vsr_stream_t stream);
 
+/* vsr_up2_resize_add_nhwc_f16 with either operand given as 1..4 channel segments of equal width C / nseg (separate tensors or
+ * slices; pointer / row length / first channel per segment): where the 16-channel branches of an inception block, written as dense
+ * maps (full-line stores), meet for the level's sum.  b_nseg = 0: no addend. */
+int vsr_resize_add_segs_nhwc_f16(const void* const* a_ptrs, const int* a_lds, const int* a_coffs, int a_nseg, int Ha, int Wa, int up2,
+                                 const void* const* b_ptrs, const int* b_lds, const int* b_coffs, int b_nseg, int b_up2, void* out, int N, int H,
+                                 int W, int C, vsr_stream_t stream);
+
 /* FlowNetC cost volume + LeakyReLU(0.1) on MFMA (reference networks/FlowNetC.py: Correlation(pad_size=20, kernel_size=1,
  * max_displacement=20, stride1=1, stride2=2), correlation_cuda_kernel.cu:74-147): feat_a, feat_b [B,H,W,C] fp16 ->
  * out[b][y][x][out_coff + tj*21 + ti] fp16 (441 channels of an [B,H,W,out_ld] concat buffer), 1/C normalisation. */
 int vsr_flownetc_corr_nhwc_f16(const void* feat_a, const void* feat_b, void* out, int out_ld, int out_coff, int B, int H, int W, int C,
                                vsr_stream_t stream);
+
+/* Generic float32 NCHW convolution on the matrix cores (csrc/conv_f32_nchw.hip: v_mfma_f32_32x32x2_f32 -- float32 in, float32
+ * accumulate) for the guidance trunks of the float32 configuration (reference networks/submodules.py:4-41, pytorch_DIW_scratch.py,
+ * vgg_osvos.py: every nn.Conv2d; ConvTranspose2d(k4,s2,p1) as four phase launches through the output stride / offset):
+ *   out[n][co][oy*oy_mul+oy_off][ox*ox_mul+ox_off] = bias[co] + sum in[n][c][oy*stride-pad_y+ky][ox*stride-pad_x+kx] * w[co][c][ky][kx]
+ * w_packed: vsr_conv2d_f32_pack's layout [kh*kw][ceil16(C)][ceil32(Co)] float32 (zero padded) of weight [Co,C,kh,kw]
+ * (transposed = 1: of a ConvTranspose2d-style [C,Co,kh,kw]); `packed` must hold kh*kw*ceil16(C)*ceil32(Co) floats. */
+int vsr_conv2d_f32_pack(const float* weight, float* packed, int Co, int C, int kh, int kw, int transposed, vsr_stream_t stream);
+int vsr_conv2d_nchw_f32(const float* in, const float* w_packed, const float* bias, float* out, int N, int C, int H, int W, int Co, int Ho, int Wo,
+                        int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off, int ox_mul, int ox_off,
+                        vsr_stream_t stream);
 
 /* The front of the depth hourglass in ONE launch (csrc/conv_hg_front.hip; reference pytorch_DIW_scratch.py:34-41 + the first
  * ChannelConcat of the outermost level): Conv2d(3,128,7,1,3)+BN+ReLU on in4 [N,H,W,4] fp16 (w1_packed / b1 as for

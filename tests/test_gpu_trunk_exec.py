@@ -43,25 +43,28 @@ def test_hourglass_deferred_upsampling_is_bit_identical(gpu_vsr, hw):
     assert torch.equal(fused, two_pass)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 70, 90), (3, 37, 45), (1, 135, 241)])
-def test_hourglass_fused_front_is_bit_identical(gpu_vsr, shape):
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 70, 90), (3, 37, 45), (1, 135, 241), (1, 270, 480), (2, 271, 249)])
+def test_hourglass_fused_front(gpu_vsr, shape):
     """igemm.HHourglassFront (csrc/conv_hg_front.hip: stem + max pool + the skip inception's fused 1x1s in one launch, the
-    128-channel stem map never written) against the three launches it replaces -- same MFMA sequences per output, so the same
-    bits: the whole trunk's prediction, and the front's three tensors one by one (ragged tiles, odd sizes: floor-mode pooling)."""
+    128-channel stem map never written) against the three launches it replaces: the whole trunk's prediction and the front's
+    three tensors one by one (ragged tiles, odd sizes: floor-mode pooling).  From 65,536 pixels up the three launches are
+    k_stem7_rows / k_conv1x1_stream / k_pool2 -- the same MFMA sequences per output as the fused kernel, so the same BITS;
+    below that the generic gather kernel serves stem and 1x1 (bias added after the sum instead of first): fp16 rounding apart."""
     from video_super_resolution_amd import igemm
     netg = gpu_vsr.DepthModule.model.netG
     N, h, w = shape
+    exact = N * h * w >= 65536
     fr = torch.from_numpy(np.random.RandomState(h + w).randint(0, 256, (N, h, w, 3)).astype(np.float32)).cuda()
     ex = HourglassExec(netg)
     assert ex.front is not None and ex.fused_front
-    with torch.no_grad():
-        fused = ex(fr).clone()
-        ex.fused_front = False
-        try:
-            three = ex(fr).clone()
-        finally:
-            ex.fused_front = True
-    assert torch.equal(fused, three)
+
+    def same(a, b, what, bar=2e-3):
+        if exact:
+            assert torch.equal(a, b), what
+        else:
+            d = (a.float() - b.float()).abs().max().item() / max(b.float().abs().max().item(), 1e-6)
+            assert d <= bar, (what, d)
+
     # the front alone, with the stem's own map written too
     x4 = torch.zeros((N, h, w, 4), dtype=torch.float16, device="cuda")
     x4[..., :3] = fr
@@ -72,12 +75,21 @@ def test_hourglass_fused_front_is_bit_identical(gpu_vsr, shape):
     smap = torch.empty((N, h, w, 128), dtype=torch.float16, device="cuda")
     ex.front(x4, buf, pooled, smap)
     ref_s = stem(x4)
-    assert torch.equal(smap, ref_s[..., :128])
-    assert torch.equal(pooled, igemm.pool2x2(ref_s, 0, 128, 0))
+    same(smap, ref_s[..., :128], "stem map")
+    assert torch.equal(pooled, igemm.pool2x2(smap, 0, 128, 0))          # the max pool of the kernel's own map: exact at every size
     ref_b = torch.full_like(buf, 5.0)
-    inc.first(ref_s, out=ref_b, out_coff=0, in_coff=0)
+    inc.first(smap, out=ref_b, out_coff=0, in_coff=0)
     c2 = inc.first.cout
-    assert torch.equal(buf[..., :c2], ref_b[..., :c2]) and float((buf[..., c2:] - 5.0).abs().max()) == 0.0
+    same(buf[..., :c2], ref_b[..., :c2], "fused 1x1s")
+    assert float((buf[..., c2:] - 5.0).abs().max()) == 0.0
+    with torch.no_grad():
+        fused = ex(fr).clone()
+        ex.fused_front = False
+        try:
+            three = ex(fr).clone()
+        finally:
+            ex.fused_front = True
+    same(fused, three, "trunk prediction", bar=1e-2)
 
 
 def test_flownet2_exec(gpu_vsr):
@@ -112,7 +124,7 @@ def test_flownet2_fused_heads_against_the_per_head_launches(gpu_vsr):
                 outs[fused] = ex(x).clone()
             L.ROUTES.enabled = False
             heads = [lab for lab, _ in L.ROUTES.calls if lab.startswith("flow_head")]
-            assert len(heads) == (4 * 5 + 3 if fused else 0), heads       # C, S1, S2, SD: 5 levels each; fusion: 3
+            assert len(heads) == (4 * 5 + 1 if fused else 0), heads       # C, S1, S2, SD: 5 levels each; fusion: predict_flow2
     finally:
         trunk_exec._Refine.fused_heads = old
         L.ROUTES.enabled = False

@@ -1384,6 +1384,41 @@ __global__ void __launch_bounds__(256) k_resize_add(const _Float16* __restrict__
     *reinterpret_cast<h8v*>(out + ((size_t)row * W + x) * C + 8 * c8) = v;
 }
 
+// The same pass with either operand given as up to four channel SEGMENTS of equal width (separate tensors / slices): the 16-channel
+// branches of an inception block write dense [N,H,W,16] maps instead of 32-byte slices of a 512-byte pixel row (partial-line
+// writes: 3x3 64 -> 16 at 4 x 540 x 960 168 -> 118 us, 64 -> 1 139 -> 99, tools/thin_out_ab.py) and meet again here, where the
+// block's 64-channel result is read for the level's sum.
+struct SegOp {
+    const _Float16* ptr[4];
+    int ld[4], coff[4];
+    int seg_c;     // channels per segment (a multiple of 8); one segment: = C
+};
+__global__ void __launch_bounds__(256) k_resize_add_segs(const SegOp a, int Ha, int Wa, const SegOp b, int has_b, _Float16* __restrict__ out, int N, int H,
+                                                         int W, int C, int up2, int b_up2) {
+    const unsigned c8n = (unsigned)C >> 3;
+    const unsigned q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= (unsigned)W * c8n) return;
+    const unsigned x = q / c8n, c8 = q - x * c8n;
+    const unsigned row = blockIdx.y, n = row / (unsigned)H, y = row - n * (unsigned)H;
+    const int Hs = Ha << up2, Ws = Wa << up2;
+    const int ya = min((int)floorf((float)y * ((float)Hs / (float)H)), Hs - 1) >> up2;
+    const int xa = min((int)floorf((float)x * ((float)Ws / (float)W)), Ws - 1) >> up2;
+    const int ch = 8 * (int)c8;
+    const int sa = ch / a.seg_c, ca = ch - sa * a.seg_c;
+    const _Float16* ap = sa == 0 ? a.ptr[0] : sa == 1 ? a.ptr[1] : sa == 2 ? a.ptr[2] : a.ptr[3];
+    const int ald = sa == 0 ? a.ld[0] : sa == 1 ? a.ld[1] : sa == 2 ? a.ld[2] : a.ld[3];
+    const int aco = sa == 0 ? a.coff[0] : sa == 1 ? a.coff[1] : sa == 2 ? a.coff[2] : a.coff[3];
+    h8v v = *reinterpret_cast<const h8v*>(ap + (((size_t)n * Ha + ya) * Wa + xa) * ald + aco + ca);
+    if (has_b) {
+        const int sb = ch / b.seg_c, cb = ch - sb * b.seg_c;
+        const _Float16* bp = sb == 0 ? b.ptr[0] : sb == 1 ? b.ptr[1] : sb == 2 ? b.ptr[2] : b.ptr[3];
+        const int bld = sb == 0 ? b.ld[0] : sb == 1 ? b.ld[1] : sb == 2 ? b.ld[2] : b.ld[3];
+        const int bco = sb == 0 ? b.coff[0] : sb == 1 ? b.coff[1] : sb == 2 ? b.coff[2] : b.coff[3];
+        v += *reinterpret_cast<const h8v*>(bp + (((size_t)n * (H >> b_up2) + (y >> b_up2)) * (W >> b_up2) + (x >> b_up2)) * bld + bco + cb);
+    }
+    *reinterpret_cast<h8v*>(out + ((size_t)row * W + x) * C + ch) = v;
+}
+
 // ---- OSVOS head (reference networks/vgg_osvos.py: side_prep -> upscale ConvTranspose2d(16,16,k=2s,stride=s) -> centre
 //      crop -> cat -> fuse 1x1 (64 -> 1)).  Nothing non-linear sits between the transposed convolutions and the fuse,
 //      so the fuse row is folded into each branch's kernel on the host (weff[b][ky][kx][ci] = sum_co fuse[16b+co] *
@@ -1598,7 +1633,11 @@ static int pf_choice(const ConvP& p, int N) {
         while (mt > 1 && !vsrc::patch_pf_has(p.kh, mt)) mt >>= 1;
         return vsrc::patch_pf_has(p.kh, mt) ? mt : 0;
     }
-    // heuristic (mode 1): filled in from per-layer measurements inside the trunks (tools/trunk_layers.sh)
+    // heuristic (mode 1), from per-layer measurements inside the trunks (tools/trunk_layers.sh, profiles/r04_patch_pf_layers.txt): the
+    // prefetch pays on the THIN layers with several chunks on many pixels (16 out-channels: the hourglass's full-resolution 64 -> 16
+    // and 64 -> 1, OSVOS's side convolutions: -8 ... -22 %); with 32 / 64 out-channels per workgroup the extra registers cost
+    // an occupancy step and the build loses 0 ... 25 % to k_conv_patch_r8 / _lw (64 per workgroup: it spills)
+    if (natural == 1 && p.kh == 3 && (p.cin >> 5) >= 2 && (long long)N * p.Ho * p.Wo >= 60000) return 1;
     return 0;
 }
 
@@ -1687,6 +1726,33 @@ int vsr_up2_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int
     hipLaunchKernelGGL(k_resize_add, dim3(vsr::cdiv((long long)W * (C >> 3), 256), (unsigned)(N * H)), dim3(256), 0, vsr::S(stream),
                        (const _Float16*)a, a_ld, a_coff, Ha, Wa, (const _Float16*)b_or_null, b_ld, b_coff, (_Float16*)out, N, H, W, C, up2, b_up2);
     return vsr::launched("resize_add");
+}
+
+int vsr_resize_add_segs_nhwc_f16(const void* const* a_ptrs, const int* a_lds, const int* a_coffs, int a_nseg, int Ha, int Wa, int up2,
+                                 const void* const* b_ptrs, const int* b_lds, const int* b_coffs, int b_nseg, int b_up2, void* out, int N, int H,
+                                 int W, int C, vsr_stream_t stream) {
+    VSR_REQUIRE(a_ptrs && a_lds && a_coffs && out && a_nseg >= 1 && a_nseg <= 4 && b_nseg >= 0 && b_nseg <= 4, "resize_add_segs: bad segment lists");
+    VSR_REQUIRE(b_nseg == 0 || (b_ptrs && b_lds && b_coffs), "resize_add_segs: addend segments");
+    VSR_REQUIRE((up2 == 0 || up2 == 1) && (b_up2 == 0 || (b_up2 == 1 && b_nseg > 0 && (H & 1) == 0 && (W & 1) == 0)),
+                "resize_add_segs: up2 flags (an upsampled addend needs an even output size)");
+    VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ha > 0 && Wa > 0 && C > 0 && (C & 7) == 0 && C % a_nseg == 0 && ((C / a_nseg) & 7) == 0 &&
+                    (b_nseg == 0 || (C % b_nseg == 0 && ((C / b_nseg) & 7) == 0)), "resize_add_segs: channels per segment must be a multiple of 8");
+    VSR_REQUIRE((long long)N * H <= 65535 && (long long)W * (C >> 3) < (1ll << 31), "resize_add_segs: more than 65535 image rows");
+    SegOp a, b;
+    for (int i = 0; i < 4; ++i) { a.ptr[i] = b.ptr[i] = nullptr; a.ld[i] = b.ld[i] = 8; a.coff[i] = b.coff[i] = 0; }
+    a.seg_c = C / a_nseg;
+    b.seg_c = b_nseg ? C / b_nseg : C;
+    for (int i = 0; i < a_nseg; ++i) {
+        VSR_REQUIRE(a_ptrs[i] && (a_lds[i] & 7) == 0 && (a_coffs[i] & 7) == 0 && a_coffs[i] + a.seg_c <= a_lds[i], "resize_add_segs: segment %d of a", i);
+        a.ptr[i] = (const _Float16*)a_ptrs[i]; a.ld[i] = a_lds[i]; a.coff[i] = a_coffs[i];
+    }
+    for (int i = 0; i < b_nseg; ++i) {
+        VSR_REQUIRE(b_ptrs[i] && (b_lds[i] & 7) == 0 && (b_coffs[i] & 7) == 0 && b_coffs[i] + b.seg_c <= b_lds[i], "resize_add_segs: segment %d of b", i);
+        b.ptr[i] = (const _Float16*)b_ptrs[i]; b.ld[i] = b_lds[i]; b.coff[i] = b_coffs[i];
+    }
+    hipLaunchKernelGGL(k_resize_add_segs, dim3(vsr::cdiv((long long)W * (C >> 3), 256), (unsigned)(N * H)), dim3(256), 0, vsr::S(stream), a, Ha, Wa, b,
+                       b_nseg > 0 ? 1 : 0, (_Float16*)out, N, H, W, C, up2, b_up2);
+    return vsr::launched("resize_add_segs");
 }
 
 int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, int ld, const void* const* weff, const int* strides,

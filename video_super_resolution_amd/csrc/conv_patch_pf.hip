@@ -202,15 +202,15 @@ int launch_pf(const ConvP& p, int N, hipStream_t stream) {
 namespace vsrc {
 
 // -> true when a build exists for (kh, 16 mt out-channels per workgroup)
-bool patch_pf_has(int kh, int mt) { return (kh == 3 && (mt == 1 || mt == 2 || mt == 4)) || (kh == 5 && (mt == 1 || mt == 2)); }
+// (64 out-channels per workgroup at 3x3 and 32 at 5x5 were built and measured: the accumulators + the prefetch registers spill /
+//  leave one workgroup per CU, 3-4x slower than k_conv_patch_lw -- not kept)
+bool patch_pf_has(int kh, int mt) { return (kh == 3 && (mt == 1 || mt == 2)) || (kh == 5 && mt == 1); }
 
 int launch_conv_patch_pf(const ConvP& p, int mt, hipStream_t stream) {
     const int N = p.N;
     if (p.kh == 3 && mt == 1) return launch_pf<3, 1, 3>(p, N, stream);
     if (p.kh == 3 && mt == 2) return launch_pf<3, 2, 2>(p, N, stream);
-    if (p.kh == 3 && mt == 4) return launch_pf<3, 4, 1>(p, N, stream);
     if (p.kh == 5 && mt == 1) return launch_pf<5, 1, 2>(p, N, stream);
-    if (p.kh == 5 && mt == 2) return launch_pf<5, 2, 1>(p, N, stream);
     return vsr::fail(VSR_E_ARG, "conv2d/patch_pf: no build for %dx%d with %d out-channels per workgroup", p.kh, p.kw, 16 * mt);
 }
 

@@ -11,6 +11,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .trunk_f32 import Conv2dF32
+
 # ("I", cin, o0, (mid,k,out) x3): inception block = concat of a 1x1 branch and three 1x1 -> kxk branches,
 # every conv followed by BatchNorm(affine=False) + ReLU (pytorch_DIW_scratch.py:42-72 is one instance).
 _A = ("I", 128, 32, (32, 3, 32), (32, 5, 32), (32, 7, 32))
@@ -47,7 +49,7 @@ class AddResized(nn.Module):
 
 
 def _cbr(cin, cout, k):
-    return [nn.Conv2d(cin, cout, k, 1, (k - 1) // 2), nn.BatchNorm2d(cout, 1e-05, 0.1, False), nn.ReLU()]
+    return [Conv2dF32(cin, cout, k, 1, (k - 1) // 2), nn.BatchNorm2d(cout, 1e-05, 0.1, False), nn.ReLU()]
 
 
 def _build(node) -> nn.Module:
@@ -63,7 +65,7 @@ def _build(node) -> nn.Module:
         return AddResized()
     tag = node[0]
     if tag == "conv":
-        return nn.Conv2d(node[1], node[2], node[3], 1, node[4])
+        return Conv2dF32(node[1], node[2], node[3], 1, node[4])
     if tag == "bn":
         return nn.BatchNorm2d(node[1]) if node[2] else nn.BatchNorm2d(node[1], 1e-05, 0.1, False)
     if tag == "S":

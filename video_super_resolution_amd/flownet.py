@@ -13,24 +13,25 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .trunk_f32 import Conv2dF32, ConvTranspose2dF32
 
 
 def conv(in_planes, out_planes, kernel_size=3, stride=1):
     """Conv2d(pad=(k-1)//2, bias) + LeakyReLU(0.1); batchNorm is False everywhere on this path (models.py:28)."""
-    return nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size, stride, (kernel_size - 1) // 2, bias=True),
+    return nn.Sequential(Conv2dF32(in_planes, out_planes, kernel_size, stride, (kernel_size - 1) // 2, bias=True),
                          nn.LeakyReLU(0.1, inplace=True))
 
 
 def i_conv(in_planes, out_planes):
-    return nn.Sequential(nn.Conv2d(in_planes, out_planes, 3, 1, 1, bias=True))
+    return nn.Sequential(Conv2dF32(in_planes, out_planes, 3, 1, 1, bias=True))
 
 
 def predict_flow(in_planes):
-    return nn.Conv2d(in_planes, 2, 3, 1, 1, bias=True)
+    return Conv2dF32(in_planes, 2, 3, 1, 1, bias=True)
 
 
 def deconv(in_planes, out_planes):
-    return nn.Sequential(nn.ConvTranspose2d(in_planes, out_planes, 4, 2, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
+    return nn.Sequential(ConvTranspose2dF32(in_planes, out_planes, 4, 2, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
 
 
 class _Decoder(nn.Module):
@@ -47,7 +48,7 @@ class _Decoder(nn.Module):
         self.predict_flow3 = predict_flow(386)
         self.predict_flow2 = predict_flow(194)
         for a, b in ((6, 5), (5, 4), (4, 3), (3, 2)):
-            setattr(self, f"upsampled_flow{a}_to_{b}", nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=flow_up_bias))
+            setattr(self, f"upsampled_flow{a}_to_{b}", ConvTranspose2dF32(2, 2, 4, 2, 1, bias=flow_up_bias))
 
     def _decode(self, c2, c3, c4, c5, c6):
         flow6 = self.predict_flow6(c6)
@@ -147,7 +148,7 @@ class FlowNetSD(nn.Module):
         self.predict_flow3 = predict_flow(128)
         self.predict_flow2 = predict_flow(64)
         for a, b in ((6, 5), (5, 4), (4, 3), (3, 2)):
-            setattr(self, f"upsampled_flow{a}_to_{b}", nn.ConvTranspose2d(2, 2, 4, 2, 1))
+            setattr(self, f"upsampled_flow{a}_to_{b}", ConvTranspose2dF32(2, 2, 4, 2, 1))
 
     def forward(self, x):
         c0 = self.conv0(x)
@@ -183,8 +184,8 @@ class FlowNetFusion(nn.Module):
         self.predict_flow2 = predict_flow(128)
         self.predict_flow1 = predict_flow(32)
         self.predict_flow0 = predict_flow(16)
-        self.upsampled_flow2_to_1 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
-        self.upsampled_flow1_to_0 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        self.upsampled_flow2_to_1 = ConvTranspose2dF32(2, 2, 4, 2, 1)
+        self.upsampled_flow1_to_0 = ConvTranspose2dF32(2, 2, 4, 2, 1)
 
     def forward(self, x):
         c0 = self.conv0(x)

@@ -317,13 +317,44 @@ def pool2x2(x, coff, c, mode):
     return out
 
 
+class SegMap:
+    """A [N,H,W,c] map kept as up to four channel segments of equal width, each a slice (tensor, first channel) of its own tensor:
+    what an inception block with 16-channel branches hands to the level's sum (resize_add) -- its branches write dense
+    [N,H,W,16] maps (full-line stores) instead of 32-byte slices of one wide pixel row."""
+
+    def __init__(self, segs):
+        self.segs = list(segs)              # [(tensor [N,H,W,ld], coff)]
+        self.shape = self.segs[0][0].shape  # (N, H, W, .): the spatial shape is what callers read
+
+    @property
+    def device(self):
+        return self.segs[0][0].device
+
+
+def _seg_args(t, coff, c):
+    """(pointer array, ld array, coff array, nseg, keep-alive) of a plain tensor slice or a SegMap for vsr_resize_add_segs_nhwc_f16."""
+    segs = t.segs if isinstance(t, SegMap) else [(t, coff)]
+    n = len(segs)
+    vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+    for tt, _ in segs:
+        if tt.dtype != torch.float16 or not tt.is_contiguous():
+            raise L.VsrHipError("resize_add: segments must be dense float16 tensors")
+    return vp(*[tt.data_ptr() for tt, _ in segs]), ip(*[tt.shape[3] for tt, _ in segs]), ip(*[co for _, co in segs]), n
+
+
 def resize_add(a, a_coff, c, out_hw, b=None, b_coff=0, up2=False, b_up2=False):
     """nearest-resize slice [a_coff, +c) of `a` to out_hw and (optionally) add slice [b_coff, +c) of `b` -> dense [N,H,W,c].
     up2 / b_up2: `a` / `b` stands for UpsamplingNearest2d(2) of the tensor passed (not materialised; the index arithmetic of the
-    two steps; an upsampled `b` is [N, H/2, W/2, .])."""
+    two steps; an upsampled `b` is [N, H/2, W/2, .]).  `a` / `b` may be SegMaps (channel segments in separate tensors)."""
     N, Ha, Wa, a_ld = a.shape
     H, W = out_hw
     out = torch.empty((N, H, W, c), dtype=torch.float16, device=a.device)
+    if isinstance(a, SegMap) or isinstance(b, SegMap):
+        ap, al, ac, an = _seg_args(a, a_coff, c)
+        bp, bl, bc, bn = _seg_args(b, b_coff, c) if b is not None else (None, None, None, 0)
+        L.check(L.load().vsr_resize_add_segs_nhwc_f16(ap, al, ac, an, Ha, Wa, 1 if up2 else 0, bp, bl, bc, bn, 1 if b_up2 else 0,
+                                                      L.dptr(out, torch.float16), N, H, W, c, L.stream()), "resize_add_segs")
+        return out
     L.check(L.load().vsr_up2_resize_add_nhwc_f16(L.dptr(a, torch.float16), a_ld, a_coff, Ha, Wa, 1 if up2 else 0, L.optr(b, torch.float16),
                                                  b.shape[3] if b is not None else 0, b_coff, 1 if b_up2 else 0, L.dptr(out, torch.float16),
                                                  N, H, W, c, L.stream()), "resize_add")

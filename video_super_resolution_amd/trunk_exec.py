@@ -21,8 +21,8 @@ import torch.nn.functional as F
 from . import _lib as L
 from . import ops
 from .depth import HOURGLASS
-from .igemm import (ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvPairS2, HConvStem, HDeconv4s2, HFlowHead, HHourglassFront, cached_zeros, pad32,
-                    pool2x2, resize_add, to_nhwc_half)
+from .igemm import (ACT_LEAKY, ACT_NONE, ACT_RELU, HConv, HConvPairS2, HConvStem, HDeconv4s2, HFlowHead, HHourglassFront, SegMap, cached_zeros,
+                    pad32, pool2x2, resize_add, to_nhwc_half)
 
 
 def _fold(conv: nn.Conv2d, bn):
@@ -83,15 +83,31 @@ class _Inception:
         self.kconvs = packed
         self.cin = w0.shape[1]
 
+    # 16-channel branches write DENSE [N,H,W,16] maps (a 32-byte slice of a 512-byte pixel row is a partial-line store per
+    # pixel: 3x3 64 -> 16 at 4 x 540 x 960 168 -> 118 us); the block's result is then a SegMap for the level's sum.  False: slices
+    # of the work buffer as for the wider blocks (the first build; cross-check).
+    dense_thin = os.environ.get("VSR_DENSE_THIN", "1") != "0"
+
+    def branches(self, buf):
+        """The three k x k branches on the work buffer `buf` (whose [0, M + o0) the fused 1x1 launch has written) ->
+        (map, first channel, channels) of the block's result."""
+        if self.dense_thin and all(conv.cout == 16 for conv, _, _ in self.kconvs) and self.o0 == 16:
+            N, H, W, _ = buf.shape
+            outs = torch.empty((len(self.kconvs), N, H, W, 16), dtype=torch.float16, device=buf.device)
+            for j, (conv, moff, _) in enumerate(self.kconvs):
+                conv(buf, out=outs[j], out_coff=0, in_coff=moff)
+            return SegMap([(buf, self.M)] + [(outs[j], 0) for j in range(len(self.kconvs))]), 0, self.ctot
+        for conv, moff, ooff in self.kconvs:
+            conv(buf, out=buf, out_coff=ooff, in_coff=moff)
+        return buf, self.M, self.ctot
+
     def __call__(self, x, in_coff):
         N, H, W, _ = x.shape
         buf = torch.empty((N, H, W, self.width), dtype=torch.float16, device=x.device)
         if self.width != self.M + self.ctot:
             buf[..., self.M + self.ctot:] = 0
         self.first(x, out=buf, out_coff=0, in_coff=in_coff)
-        for conv, moff, ooff in self.kconvs:
-            conv(buf, out=buf, out_coff=ooff, in_coff=moff)
-        return buf, self.M, self.ctot
+        return self.branches(buf)
 
 
 class HourglassExec:
@@ -188,7 +204,12 @@ class HourglassExec:
             return resize_add(x, coff, c, (2 * x.shape[1], 2 * x.shape[2])), 0, c
         tag = node[0]
         if tag == "conv":
-            out = node[1](x, in_coff=coff)
+            if node[2] == 1:   # one out-channel (the trunk's last layer): a dense [N,H,W,1] map, not 2 bytes of a 64-byte pixel row
+                N, H, W, _ = x.shape
+                Ho, Wo = node[1].out_hw(H, W)
+                out = node[1](x, in_coff=coff, out=torch.empty((N, Ho, Wo, 1), dtype=torch.float16, device=x.device))
+            else:
+                out = node[1](x, in_coff=coff)
             return out, 0, node[2]
         if tag == "stem":
             return node[1](x), 0, node[2]
@@ -241,9 +262,7 @@ class HourglassExec:
         pooled = torch.empty((k, h // 2, w // 2, 128), dtype=torch.float16, device=x4.device)
         self.front(x4, buf, pooled)
         a = self._run(("S", arm_a[1][1:]), pooled, 0, 128, 1)            # the inner arm behind its "max"
-        for conv, moff, ooff in inc.kconvs:                              # the skip arm: the inception's k x k branches
-            conv(buf, out=buf, out_coff=ooff, in_coff=moff)
-        x, coff, c = self._run(("S", ["+"]), [a, (buf, inc.M, inc.ctot)], 0, 0)
+        x, coff, c = self._run(("S", ["+"]), [a, inc.branches(buf)], 0, 0)   # the skip arm: the inception's k x k branches
         return self._run(("S", items[2:]), x, coff, c)
 
 
@@ -417,8 +436,6 @@ class _FusionExec:
         self.pred0 = _cv(net.predict_flow0, act=ACT_NONE)
         # predict_flow + the flow upsampling of the next level as one launch (igemm.HFlowHead), like _Refine
         self.head2 = HFlowHead(net.predict_flow2.weight, net.predict_flow2.bias, net.upsampled_flow2_to_1.weight, net.upsampled_flow2_to_1.bias)
-        self.head1 = HFlowHead(net.predict_flow1.weight, net.predict_flow1.bias, net.upsampled_flow1_to_0.weight, net.upsampled_flow1_to_0.bias)
-        self.head0 = HFlowHead(net.predict_flow0.weight, net.predict_flow0.bias)
 
     def __call__(self, x11):
         N, H, W, _ = x11.shape
@@ -428,15 +445,16 @@ class _FusionExec:
         self.conv0(x11, out=cat0, out_coff=0)                                             # 64
         self.conv1_1(self.conv1(cat0), out=cat1, out_coff=0)                              # 128
         c2 = self.conv2_1(self.conv2(cat1))
+        # the fused head (predict_flow as a 1x1 onto 18 tap-channels, its four waves sharing the channel chunks) pays from 4 chunks
+        # up: predict_flow2 (128 channels).  The 32-channel heads at 1/2 and full resolution stay on the patch kernel and the
+        # four-phase transposed convolution (measured, tools/trunk_layers.sh: 150 vs 38 us for predict_flow0 at 2 x 512 x 960)
         if _Refine.fused_heads:
             self.head2(c2, up_out=cat1, up_coff=160)                                      # flow2 + its upsampling (2)
             self.deconv1(c2, out=cat1, out_coff=128)                                      # 32
-            self.head1(self.inter1(cat1), up_out=cat0, up_coff=80)                        # flow1 + its upsampling (2)
-            self.deconv0(cat1, out=cat0, out_coff=64)                                     # 16
-            return self.head0(self.inter0(cat0))
-        flow2 = self.pred2(c2)
-        self.deconv1(c2, out=cat1, out_coff=128)                                          # 32
-        self.up21(flow2, out=cat1, out_coff=160)                                          # 2
+        else:
+            flow2 = self.pred2(c2)
+            self.deconv1(c2, out=cat1, out_coff=128)                                      # 32
+            self.up21(flow2, out=cat1, out_coff=160)                                      # 2
         flow1 = self.pred1(self.inter1(cat1))
         self.deconv0(cat1, out=cat0, out_coff=64)                                         # 16
         self.up10(flow1, out=cat0, out_coff=80)                                           # 2
@@ -557,8 +575,9 @@ class OSVOSExec:
         for si, items in enumerate(self.stages):
             for it in items:
                 x = pool2x2(x, 0, x.shape[3], 2) if it == "M" else it(x)   # MaxPool2d(2, 2, ceil_mode=True)
-            if si > 0:
-                sides.append(self.side[si - 1](x))  # [N,h',w',32] (16 live)
+            if si > 0:   # side_prep: 16 channels, as a DENSE [N,h',w',16] map (full-line stores, see _Inception.dense_thin)
+                hs, ws = x.shape[1], x.shape[2]
+                sides.append(self.side[si - 1](x, out=torch.empty((N, hs, ws, 16), dtype=torch.float16, device=x.device)))
         nb = len(sides)
         out = torch.empty((N, 1, hh, ww), dtype=torch.float32, device=x.device)
         vp = ctypes.c_void_p * nb

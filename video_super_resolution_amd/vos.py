@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .trunk_f32 import Conv2dF32
+
 _STAGES = [[64, 64], ["M", 128, 128], ["M", 256, 256, 256], ["M", 512, 512, 512], ["M", 512, 512, 512]]
 _STAGE_IN = [3, 64, 128, 256, 512]
 MEANVAL = (104.00699, 116.66877, 122.67892)
@@ -21,7 +23,7 @@ def _stage(cfg, cin):
         if v == "M":
             layers.append(nn.MaxPool2d(kernel_size=2, stride=2, ceil_mode=True))
         else:
-            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            layers += [Conv2dF32(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
             cin = v
     return nn.Sequential(*layers)
 
@@ -43,7 +45,7 @@ class OSVOS(nn.Module):
         self.upscale = nn.ModuleList()
         self.upscale_ = nn.ModuleList()
         for i in range(1, len(_STAGES)):
-            self.side_prep.append(nn.Conv2d(_STAGES[i][-1], 16, kernel_size=3, padding=1))
+            self.side_prep.append(Conv2dF32(_STAGES[i][-1], 16, kernel_size=3, padding=1))
             self.score_dsn.append(nn.Conv2d(16, 1, kernel_size=1, padding=0))
             self.upscale_.append(nn.ConvTranspose2d(1, 1, kernel_size=2 ** (1 + i), stride=2 ** i, bias=False))
             self.upscale.append(nn.ConvTranspose2d(16, 16, kernel_size=2 ** (1 + i), stride=2 ** i, bias=False))
