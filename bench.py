@@ -440,6 +440,17 @@ def main():
                 roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=FP16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / FP16_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                             launches_timed=launches, avg_ms=round(ms, 4), algorithmic_flop_per_launch=flop, planes_per_launch=planes_dom)
+                # what an fp16 MFMA loop of this kernel's instruction shape SUSTAINS on this chip (power-governed clock): a committed
+                # same-device measurement (tools/power_roofline.py), reported beside the spec peak -- `frac` stays achieved / spec peak
+                pr_path = os.path.join(ROOT, "profiles", "r04_power_roofline.json")
+                if scale == 4 and os.path.exists(pr_path):
+                    with open(pr_path) as f:
+                        pr = json.load(f)
+                    roof["practical_peak"] = dict(
+                        value=pr["mix_loop_tflops"], unit="TFLOP/s", frac_of_practical=round(achieved / pr["mix_loop_tflops"], 4),
+                        bare_mfma_loop_tflops=pr["bare_mfma_tflops"], source="profiles/r04_power_roofline.json (tools/power_roofline.py: 144 "
+                        "v_mfma_f32_16x16x32_f16 + k_utd3's 304 VALU + 17 LDS per trip, no global memory, random operands, one wave per SIMD, "
+                        ">= 2.5 s back to back with k_utd3 on one device; measured on another box than this run)")
                 if part3 is not None:
                     f3 = 3 * h * w * STAGE_FLOP_PER_PX[scale]
                     roof["three_plane_launches"] = dict(launches_timed=part3[0], avg_ms=round(part3[1], 4), algorithmic_flop_per_launch=f3,

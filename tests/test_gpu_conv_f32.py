@@ -26,7 +26,8 @@ TOL = 2e-5
     (3, 64, 6, 5, 1, 3, 1, 1, True),         # one out-channel
     (1, 16, 9, 140, 16, 1, 1, 0, True),      # OSVOS score layer shape
 ])
-def test_conv2d_f32_matches_float64(case):
+def test_conv2d_f32_matches_float64(case, monkeypatch):
+    monkeypatch.setattr(trunk_f32, "ROUTE", False)     # every shape through the own kernel (the router would keep the small ones on the stock operator)
     N, C, H, W, Co, k, stride, pad, bias = case
     rs = np.random.RandomState(C + 7 * Co + k)
     x = torch.from_numpy(rs.randn(N, C, H, W).astype(np.float32))
@@ -56,7 +57,8 @@ def test_conv2d_f32_matches_float64(case):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 7, 9, 32, True), (1, 1026, 4, 5, 256, True), (1, 2, 16, 30, 2, False), (2, 386, 16, 30, 64, True)])
-def test_conv_transpose_k4s2_f32_matches_float64(case):
+def test_conv_transpose_k4s2_f32_matches_float64(case, monkeypatch):
+    monkeypatch.setattr(trunk_f32, "ROUTE", False)
     N, C, H, W, Co, bias = case
     rs = np.random.RandomState(C + Co)
     x = torch.from_numpy(rs.randn(N, C, H, W).astype(np.float32))

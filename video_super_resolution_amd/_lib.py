@@ -55,6 +55,9 @@ def load() -> ctypes.CDLL:
                 getattr(lib, fn).restype = ctypes.c_size_t
         if lib.vsr_abi_version() != 1:
             raise VsrHipError("libvsr_hip.so ABI version mismatch")
+        for t in os.environ.get("VSR_TUNING", "").split(","):   # measurement hook: kernel-selection switches (vsr_conv2d_tuning codes)
+            if t.strip():
+                lib.vsr_conv2d_tuning(int(t))
         _lib = lib
     return _lib
 

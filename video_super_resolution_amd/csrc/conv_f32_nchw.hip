@@ -6,8 +6,9 @@
 // nn.Conv2d of those trunks (any kernel size, stride, padding; `trunk_f32.Conv2dF32`) and, as four 2x2-tap phase launches, their
 // ConvTranspose2d(k4, s2, p1) layers.
 //
-// Implicit GEMM, no im2col: rows = out-channels, columns = 128 consecutive pixels of ONE output row (NCHW: contiguous in
-// memory for every (channel, tap) -> coalesced loads and stores), K walked as (tap, 16 input channels) steps.
+// Implicit GEMM, no im2col: rows = out-channels, columns = 128 consecutive output pixels in (n, oy, ox) order (NCHW: a row's
+// pixels are contiguous in memory for every (channel, tap) -> coalesced loads and stores; a small map puts several rows / images
+// in one block), K walked as (tap, 16 input channels) steps.
 //   workgroup: 32 MT out-channels x 128 pixels, 4 waves; wave w owns pixels [32w, 32w+32) and all MT 32 x 32 accumulator tiles
 //   per step: weights [16][32 MT] and pixels [16][128] staged through LDS (double-buffered: the next step's global loads are in
 //   flight while this step is multiplied), 8 MT MFMAs per wave
@@ -36,18 +37,22 @@ __global__ void __launch_bounds__(256) k_conv_f32(const CF32 p) {
     __shared__ __attribute__((aligned(16))) float Bs[2][KC][BN];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, kh2 = lane >> 5;
-    // blockIdx.x = (n, oy, segment of 128 output columns); blockIdx.y = block of BM out-channels
-    const int seg = blockIdx.x % p.segs, row = blockIdx.x / p.segs;
-    const int oy = row % p.Ho, n = row / p.Ho;
-    const int ox0 = seg * BN, co0 = blockIdx.y * BM;
+    // blockIdx.x = block of 128 consecutive output pixels in (n, oy, ox) order (rows of a wide map: 128 contiguous columns; a
+    // small map: several rows / images per block, so an 8 x 15 map still fills its tiles); blockIdx.y = block of BM out-channels
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const long long m0 = (long long)blockIdx.x * BN;
+    const int co0 = blockIdx.y * BM;
     const int ncc = p.cpad / KC, nsteps = p.kh * p.kw * ncc;
 
-    // staging roles: pixels -- thread t loads column t & 127 of rows (t >> 7) + 2 r; weights -- float4 pieces of the [16][BM] block
+    // staging roles: pixels -- thread t loads pixel t & 127 of rows (t >> 7) + 2 r; weights -- float4 pieces of the [16][BM] block
     const int bpx = tid & 127, bk0 = tid >> 7;
-    const int ox = ox0 + bpx;
+    const long long mb = m0 + bpx;
+    const bool px_ok = mb < M;
+    const int hw = p.Ho * p.Wo;
+    const int n = px_ok ? (int)(mb / hw) : 0, rem = px_ok ? (int)(mb - (long long)n * hw) : 0;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
     const int ixb = ox * p.stride - p.pad_x;             // + kx
     const int iyb = oy * p.stride - p.pad_y;             // + ky
-    const bool px_ok = ox < p.Wo;
     constexpr int APT = (KC * BM / 4 + 255) / 256;       // float4 pieces per thread (MT = 4: 2, 2: 1, 1: 0.5)
     float breg[8];
     f4v areg[APT];
@@ -100,9 +105,11 @@ __global__ void __launch_bounds__(256) k_conv_f32(const CF32 p) {
         __syncthreads();
     }
     // D[i][j]: lane = 32 (i / 4 % 2) + j, register = 4 (i / 8) + i % 4: a register row = 32 consecutive pixels of one out-channel
-    const int opx = ox0 + 32 * wv + col;
-    if (opx >= p.Wo) return;
-    const size_t obase = ((size_t)n * p.Co) * p.outH * p.outW + (size_t)(oy * p.oy_mul + p.oy_off) * p.outW + (size_t)opx * p.ox_mul + p.ox_off;
+    const long long mo = m0 + 32 * wv + col;
+    if (mo >= M) return;
+    const int on = (int)(mo / hw), orem = (int)(mo - (long long)on * hw);
+    const int ooy = orem / p.Wo, oox = orem - ooy * p.Wo;
+    const size_t obase = ((size_t)on * p.Co) * p.outH * p.outW + (size_t)(ooy * p.oy_mul + p.oy_off) * p.outW + (size_t)oox * p.ox_mul + p.ox_off;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -147,9 +154,9 @@ int vsr_conv2d_nchw_f32(const float* in, const float* w_packed, const float* bia
     p.N = N; p.C = C; p.H = H; p.W = W; p.Co = Co; p.Ho = Ho; p.Wo = Wo; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
     p.cpad = (C + 15) / 16 * 16; p.co_pad = (Co + 31) / 32 * 32;
     p.outH = outH; p.outW = outW; p.oy_mul = oy_mul; p.oy_off = oy_off; p.ox_mul = ox_mul; p.ox_off = ox_off;
-    p.segs = (Wo + BN - 1) / BN;
-    const long long gx = (long long)N * Ho * p.segs;
-    VSR_REQUIRE(gx < (1ll << 31), "conv2d_nchw_f32: too many row segments");
+    p.segs = 0;
+    const long long gx = ((long long)N * Ho * Wo + BN - 1) / BN;
+    VSR_REQUIRE(gx < (1ll << 31) && (long long)Ho * Wo < (1ll << 31), "conv2d_nchw_f32: too many pixel blocks");
     hipStream_t st = vsr::S(stream);
     // widest out-channel block the padded count fills
     if ((p.co_pad & 127) == 0) hipLaunchKernelGGL(k_conv_f32<4>, dim3((unsigned)gx, p.co_pad / 128), dim3(256), 0, st, p);

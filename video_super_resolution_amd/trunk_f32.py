@@ -9,12 +9,14 @@ reference: my_packages/FlowProjection/networks/submodules.py:4-41, DepthProjecti
 VOSProjection/vgg_osvos.py:47-62 (their nn.Conv2d / nn.ConvTranspose2d layers)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib as L
 
-ENABLED = True     # False: every layer on the stock operator (A/B switch; tests)
+ENABLED = os.environ.get("VSR_TRUNK_F32", "1") != "0"     # False: every layer on the stock operator (A/B switch; tests)
 
 
 def _ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -55,10 +57,32 @@ def conv2d_packed(x, wp, bias, co, kh, kw, stride, pad_y, pad_x, out=None, out_h
     return out
 
 
+ROUTE = os.environ.get("VSR_TRUNK_F32_ROUTE", "1") != "0"   # True: the layers the stock operator runs faster stay on it (below)
+
+
+def _own_pays(N, C, H, W, Co, k, stride) -> bool:
+    """Where the own kernel beats the stock operator -- per-layer device times of both at the C2 size, tools/conv_f32_ab.py,
+    profiles/r04_conv_f32_ab.txt: NOT on (a) launches of a few dozen workgroups (FlowNet's 1/32 and 1/64-resolution layers: the
+    kernel has no split-K; 8 x 15 x 1024 -> 1024: 0.95 vs 0.19 ms), (b) RGB stems (3 input channels padded to a 16-channel K step),
+    (c) k x k layers with <= 16 out-channels (half of each 32-row MFMA tile is padding)."""
+    if not ROUTE:
+        return True
+    Ho, Wo = (H + 2 * ((k - 1) // 2) - k) // stride + 1, (W + 2 * ((k - 1) // 2) - k) // stride + 1
+    co_pad = (Co + 31) // 32 * 32
+    bm = 128 if co_pad % 128 == 0 else (64 if co_pad % 64 == 0 else 32)
+    wgs = -(-(N * Ho * Wo) // 128) * (co_pad // bm)
+    if wgs < 192 or C <= 4:
+        return False
+    if Co <= 16 and k >= 3:
+        return False
+    return True
+
+
 class Conv2dF32(nn.Conv2d):
     def _conv_forward(self, x, weight, bias):
         if (not _ok(x, weight) or self.groups != 1 or self.dilation != (1, 1) or self.padding_mode != "zeros" or isinstance(self.padding, str) or
-                self.stride[0] != self.stride[1]):
+                self.stride[0] != self.stride[1] or
+                not _own_pays(x.shape[0], x.shape[1], x.shape[2], x.shape[3], weight.shape[0], weight.shape[2], self.stride[0])):
             return super()._conv_forward(x, weight, bias)
         pk = self.__dict__.setdefault("_vsr_pack", _Packed())
         with torch.cuda.device(x.device):

@@ -49,7 +49,7 @@ class OSVOS(nn.Module):
             self.score_dsn.append(nn.Conv2d(16, 1, kernel_size=1, padding=0))
             self.upscale_.append(nn.ConvTranspose2d(1, 1, kernel_size=2 ** (1 + i), stride=2 ** i, bias=False))
             self.upscale.append(nn.ConvTranspose2d(16, 16, kernel_size=2 ** (1 + i), stride=2 ** i, bias=False))
-        self.fuse = nn.Conv2d(64, 1, kernel_size=1, padding=0)
+        self.fuse = Conv2dF32(64, 1, kernel_size=1, padding=0)
 
     def forward(self, x):
         hh, ww = x.shape[-2:]
