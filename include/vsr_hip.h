@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VSR_ABI_VERSION 1
+#define VSR_ABI_VERSION 2
 
 #define VSR_OK 0
 #define VSR_E_ARG (-1)     /* null pointer / non-positive size / unsupported parameter */
@@ -106,7 +106,6 @@ int vsr_flownet_up_warp_concat16_f16(const float* x6, const void* flow2_nhwc, in
  * neighbourhood served by L1 / L2); 0 an LDS-staged source tile with a halo of 8 pixels, the right column of each lane's 2x2
  * neighbourhood handed over from the next lane by DPP where the flow is smooth, global fallback beyond the halo (BASELINE.json's
  * north_star wording; measured 1.0 - 1.9 x slower, LAB_NOTES.md 5.4).  Bit-identical (resample2d_kernel.cu:16-72's arithmetic). */
-int vsr_flownet_warp_variant(int variant);
 int vsr_flownet_fusion_input_f16(const float* x6, const void* flow_sd2, int ld_sd, const void* flow_s22, int ld_s2, float div_flow,
                                  void* out32, int B, int H, int W, vsr_stream_t stream);
 
@@ -138,18 +137,10 @@ int vsr_sr_conv1x1_f32(const float* in0, const float* w0, int ldw0, const float*
                        const float* in2, const float* w2, int ldw2, const float* bias, const float* cmap,
                        float slope, float* out, int N, int P, vsr_stream_t stream);
 
-/* DeconvBlock: ConvTranspose2d(32,32,k8,s4,p2) + PReLU (:22-24,:64; blocks.py:30-43).
- * in [N,32,h,w] -> out [N,32,4h,4w].  weight_packed = the ConvTranspose2d weight [32(in),32(out),8,8]
- * permuted to [ky][kx][in][out] (the host does `.permute(2,3,0,1).contiguous()` once per weight). */
-int vsr_sr_deconv8s4_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
-                         int h, int w, vsr_stream_t stream);
-
-/* ConvBlock: Conv2d(32,32,k8,s4,p2) + PReLU (:25-27,:79).  in [N,32,4h,4w] -> out [N,32,h,w].
- * weight_packed = the Conv2d weight [32(out),32(in),8,8] permuted to [ky][kx][in][out]. */
-int vsr_sr_conv8s4_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
-                       int h, int w, vsr_stream_t stream);
-
-/* The same two blocks for the other rows of SRFBN's (kernel, stride) table: scale 4 = (8,4) the reference's literals
+/* DeconvBlock: ConvTranspose2d(32,32,k8,s4,p2) + PReLU (:22-24,:64; blocks.py:30-43): in [N,32,h,w] -> out [N,32,4h,4w],
+ * weight_packed = the ConvTranspose2d weight [32(in),32(out),8,8] permuted to [ky][kx][in][out] (`.permute(2,3,0,1)` once per
+ * weight); ConvBlock: Conv2d(32,32,k8,s4,p2) + PReLU (:25-27,:79): in [N,32,4h,4w] -> out [N,32,h,w], weight_packed = the Conv2d
+ * weight [32(out),32(in),8,8] permuted to [ky][kx][in][out].  Both with the scale as a parameter: the two blocks for every row of SRFBN's (kernel, stride) table: scale 4 = (8,4) the reference's literals
  * (SRProjectionModule.py:10-12,101-103), 3 = (7,3), 2 = (6,2); padding 2 in all.  This is the "scale-2 extension" of
  * SURVEY.md 7-1 / 8(d) (configs C1/C2/C3-B/C5 are labelled x2); the reference itself crashes for upscale_factor != 4.
  * in [N,32,h,w] <-> [N,32,scale*h,scale*w]; weight_packed [ky][kx][in][out] as above with K x K taps. */
@@ -157,21 +148,14 @@ int vsr_sr_deconv_f32(const float* in, const float* weight_packed, const float* 
                       int h, int w, int scale, vsr_stream_t stream);
 int vsr_sr_conv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
                     int h, int w, int scale, vsr_stream_t stream);
-/* Build of the two float32 blocks above and of vsr_sr_conv1x1_f32 (process-wide; bit-identical maps): 0 (default) v_mfma_f32_32x32x2_f32 -- 32 out-channels x
- * 32 pixels x 2 input channels per instruction, the same fused multiply-adds in the same order (csrc/sr_f32_mfma.hip; the stride-4
- * and stride-3 convolutions stay on build 1, which is faster there) --, 1 one pixel per thread (csrc/sr_f32.hip; the cross-check),
- * 2 as 0 with the convolution's per-tap MFMA build at every scale (measurements).  Returns the previous value. */
-int vsr_sr_f32_variant(int v);
-/* vsr_sr_tail_f32 with the skip's bilinear factor (= upscale_factor, :136) as a parameter. */
+/* conv_out 3x3 (32->3, no activation) + bilinear skip of sub_mean(x) + add_mean (:136,:142-143), the skip's factor (=
+ * upscale_factor, :136) a parameter: hr [N,32,S h,S w] (output of the `out` DeconvBlock), x [N,3,h,w] -> prefc [N,3,S h,S w].
+ * (float32 blocks on the matrix cores: v_mfma_f32_32x32x2_f32, the same fused multiply-adds in the same order as one pixel per
+ * thread, csrc/sr_f32_mfma.hip; the stride-4 / stride-3 convolutions stay on csrc/sr_f32.hip's kernels, which are faster there.) */
 int vsr_sr_tail_scale_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
                           const float* sub_bias3, const float* add_scale3, const float* add_bias3, float* prefc, int N,
                           int h, int w, int scale, vsr_stream_t stream);
 
-/* conv_out 3x3 (32->3, no activation) + bilinear x4 skip of sub_mean(x) + add_mean (:136,:142-143).
- * hr [N,32,4h,4w] (output of the `out` DeconvBlock), x [N,3,h,w] -> prefc [N,3,4h,4w]. */
-int vsr_sr_tail_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
-                    const float* sub_bias3, const float* add_scale3, const float* add_bias3, float* prefc, int N,
-                    int h, int w, vsr_stream_t stream);
 
 /* The fusion MLP over the batch axis (:126-131,:146; tools.py:118-123):
  *   out[c,p] = relu( w2 . relu(W1 v + b1) + b2 ),  v = prefc[0..nplanes-1, c, p]
@@ -187,46 +171,29 @@ int vsr_sr_fc_fuse_f32(const float* prefc, const float* w1, const float* b1, con
 
 /* Packed weights of one fused stage (host builds it once per weight set; video_super_resolution_amd/sr.py
  * pack_utd_blob documents the element order): per wave 16 deconv + 16 conv MFMA A-fragments of 64 lanes x 8 fp16,
- * 2 fragments of the 1x1, then fp32 b_up[32] b_tr[32] b_dn[32] slope_up slope_tr slope_dn.  16-byte aligned. */
-size_t vsr_sr_utd_blob_bytes(void);
-int vsr_sr_utd_strip_width(void); /* LR columns one workgroup marches down (31) */
+ * 2 fragments of the 1x1, then fp32 b_up[32] b_tr[32] b_dn[32] slope_up slope_tr slope_dn.  16-byte aligned.
+ * Sizes the host needs to pack blobs and cut strips: */
+enum {
+    VSR_Q_UTD_BLOB_BYTES = 0,      /* bytes of one fused-stage blob (x4 geometry) */
+    VSR_Q_UTD_STRIP_WIDTH = 1,     /* LR columns one workgroup of the x4 strip-marching kernels walks (31) */
+    VSR_Q_UTD_S2_BLOB_BYTES = 2,   /* ... of the x2 fused stage (csrc/sr_utd_s2.hip) */
+    VSR_Q_UTD_S2_STRIP_WIDTH = 3,  /* ... its strips (30) */
+    VSR_Q_TAIL_S2_BLOB_BYTES = 4   /* bytes of the x2 tail's blob (csrc/sr_tail_s2.hip) */
+};
+size_t vsr_sr_query(int what);
 
 /* Fused   in -> up_i (ConvTranspose2d k8 s4 p2 + PReLU) -> 1x1 slice of downtran + PReLU -> down_j (Conv2d k8 s4 p2 +
- * PReLU)   (SRProjectionModule.py:64,77-80 for the live chain under zero fill).  The x4 feature map stays in LDS.
- * in [N,h,w,32] fp16 -> out [N,h,w,32] fp16.  deconv_only != 0: only up_i + PReLU, out [N,4h,4w,32] fp16 (the
- * `out` DeconvBlock, :118-120,142).  rows_per_seg > 0: LR rows one workgroup marches (h = one march per strip);
- * rows_per_seg = -c (one-wave-per-SIMD build, fused stage only; the other builds then march whole strips): c workgroups share the N x strips x h rows of the planes'
+ * PReLU)   (SRProjectionModule.py:64,77-80 for the live chain under zero fill).  The x4 feature map stays in registers
+ * (k_utd3, csrc/sr_utd3.hip: one wave per SIMD, 144 MFMAs per LR row in one hand-ordered instruction stream).
+ * in [N,h,w,32] fp16 -> out [N,h,w,32] fp16.  deconv_only must be 0 (the deconv-only mode lives in the cross-check library,
+ * vsr_hip_xcheck.h).  rows_per_seg > 0: LR rows one workgroup marches (h = one march per strip);
+ * rows_per_seg = -c: c workgroups share the N x strips x h rows of the planes'
  * strips laid end to end evenly (a share that spans the end of a strip is two marches) -- same values, for plane counts
  * whose strips cannot fill the CUs in whole row segments.
  * slopes_le_one != 0 promises that every PReLU slope packed in the blob is <= 1 (selects the cheaper activation
  * form max(v, a*v); with 0 the kernel handles any slope). */
 int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int deconv_only,
                    int slopes_le_one, vsr_stream_t stream);
-
-/* Build of the fused stage vsr_sr_utd_f16 launches (process-wide; results are bit-identical across builds):
- *   0  k_utd3, one wave per SIMD, 144 MFMAs per LR row in one hand-ordered instruction stream (default)
- *   1  k_utd, two waves per SIMD (the first design; 17 % slower on MI355X)
- *   2 / 3  builds 0 / 1 with s_memtime stamps around their phases (diagnostics: tools/utd_stamps.py)
- *   4  build 0 stamped around the whole march only (cycles and clock without perturbing the step). */
-int vsr_sr_utd_variant(int variant);
-/* Build vsr_sr_chain1x1_f16 launches (process-wide; returns the previous setting): 0 = the streaming builds specialised
- * on the glue's launch shapes where one exists (default), 1 = always the generic kernel (cross-check; same results).
- * Bit 1 of the argument (value 2) sends full frames of vsr_sr_fc_planes_skip_f32 through its one-pixel build as well. */
-int vsr_sr_chain_variant(int generic);
-/* Device buffer the stamped builds write to: [workgroup][wave 8][8] uint64 (phase cycle sums, loop cycles, loop time in
- * 10 ns ticks).  NULL detaches. */
-int vsr_sr_utd_stamp_buffer(void* device_buf);
-/* The same for the stamped build of the fused tail (full frames, folded compress_out, slopes <= 1): [workgroup][wave 8][8] uint64 =
- * cycle sums of {LR requests, barrier, region A, C, B}, steps stamped, loop cycles, loop time in 10 ns ticks; totals_only: the
- * build that stamps the whole march only (the per-region stamps cost cycles of their own). */
-int vsr_sr_tail_stamp_buffer(void* device_buf, int totals_only);
-
-/* The same fused stage with specialised wave roles (4 producer waves: deconv + 1x1 into the LDS ring; 4 consumer
- * waves: stride-4 conv out of it).  Measured 7 % slower than vsr_sr_utd_f16 on MI355X (the producer chain is the long
- * pole); kept, tested, as the starting point for unequal role splits.  blob_v2: fragment order of sr.py:pack_utd_blob(...,
- * layout=2): up [producer 4][phase 4][tap 4][tile 2], conv [consumer 4][lo/hi 2][kx 8][tile 2], then as v1. */
-int vsr_sr_utd2_f16(const void* in, const void* blob_v2, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
-                    vsr_stream_t stream);
 
 /* vsr_sr_conv1x1_f32 for NHWC fp16 tensors [N,P,32]; weights/bias fp32, cmap_nhwc fp32 [P,32] or NULL. */
 int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* in1, const float* w1, int ldw1,
@@ -258,21 +225,12 @@ int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bi
                     float slope_in, int nmid, const float* w_feat, const float* b_feat, float slope_feat, void* out_nhwc,
                     int N, int h, int w, vsr_stream_t stream);
 
-/* Fused tail: hid [N,h,w,32] fp16 -> `out` DeconvBlock -> conv_out 3x3 + bilinear x4 skip of sub_mean(x) + add_mean
- * -> pre-fusion planes prefc [N,3,4h,4w] fp32 (SRProjectionModule.py:118-123,136,142-143); the x4 feature map stays in
- * LDS (ring of 12 HR rows).  blob: a deconv-only vsr_sr_utd blob of the `out` block; conv_out_frags: 9 MFMA
- * A-fragments [tap][lane 64][8] fp16 with channel c in row 4c (sr.py:pack_conv_out_frags); tail_params: fp32
- * b_out[3] sub_scale[3] sub_bias[3] add_scale[3] add_bias[3]; x [N,3,h,w] fp32. */
-int vsr_sr_tail_f16(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,
-                    const float* x, float* prefc, int N, int h, int w, int rows_per_seg, int slopes_le_one,
-                    vsr_stream_t stream);
-
 /* The tail in the structure of the fused stage (k_tail3, csrc/sr_tail3.hip): one wave per SIMD, the x4 map in registers,
  * the 3x3 turned around so that the wave holding an HR row forms that row's contribution to its three output rows (M row
  * 4 dy + co) and only fp32 partial sums cross waves.  Writes the RAW planes raw [N,3,4h,4w] fp32 = conv_out(PReLU(out
  * deconv)) + bias; the bilinear skip and add_mean are applied by vsr_sr_fc_planes_skip_f32, which reads the planes next.
- * conv3_frags: [dx 3][lane 64][8] fp16 (sr.py:pack_conv_out_frags3); tail_params as vsr_sr_tail_f16.  decimate != 0:
- * raw is [N,3,h,w], the pixels (4i,4j).  The pair the forward runs; vsr_sr_tail_f16 + vsr_sr_fc_planes_f32 are the
+ * conv3_frags: [dx 3][lane 64][8] fp16 (sr.py:pack_conv_out_frags3); tail_params: fp32 b_out[3] sub_scale[3] sub_bias[3] add_scale[3] add_bias[3].  decimate != 0:
+ * raw is [N,3,h,w], the pixels (4i,4j).  The pair the forward runs (the LDS-ring tail of the cross-check library, vsr_hip_xcheck.h, is the
  * LDS-ring build with the skip inside the tail (agree up to fp32 summation order). */
 int vsr_sr_tail3_f16(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* raw,
                      int N, int h, int w, int rows_per_seg, int slopes_le_one, int decimate, vsr_stream_t stream);
@@ -284,7 +242,7 @@ int vsr_sr_tail3_f16(const void* hid_nhwc, const void* blob, const void* conv3_f
 int vsr_sr_tail3_fold_f16(const void* lr_a, const void* lr_b, const float* cmap_nhwc, const void* blob_fold, const void* conv3_frags,
                           const float* tail_params, float* raw, int N, int h, int w, int rows_per_seg, int slopes_le_one, int decimate,
                           vsr_stream_t stream);
-/* Fusion MLP over the 8 planes (vsr_sr_fc_planes_f32) reading RAW planes and finishing them on the fly:
+/* Fusion MLP over the 8 planes (vsr_sr_fc_fuse_f32 specialised and unrolled for the reference's 8 planes x 32 hidden units) reading RAW planes and finishing them on the fly:
  * plane = (bilinear x4 of (x * sub_scale + sub_bias) + raw) * add_scale + add_bias; x [8,3,h,w] fp32; out [3,4h,4w] (or
  * [3,h,w] with decimate != 0) fp32. */
 int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tail_params, const float* w1, const float* b1,
@@ -292,22 +250,16 @@ int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tai
                               vsr_stream_t stream);
 
 /* The fused up -> tran -> down stage for the scale-2 extension (k6 s2 p2; csrc/sr_utd_s2.hip): vsr_sr_utd_f16's x2 sibling.
- * in / out [N,h,w,32] fp16 NHWC; blob = vsr_sr_utd_s2_blob_bytes() bytes packed by sr.py:pack_utd_s2_blob
+ * in / out [N,h,w,32] fp16 NHWC; blob = vsr_sr_query(VSR_Q_UTD_S2_BLOB_BYTES) bytes packed by sr.py:pack_utd_s2_blob
  * ([wave 4][tap 9][mt 2] deconv fragments, [wave 4][kernel-row slot 3][shift 3][mt 2] conv fragments, 2 fragments of the 1x1,
- * then b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn as fp32); strips of vsr_sr_utd_s2_strip_width() = 30 LR columns. */
-size_t vsr_sr_utd_s2_blob_bytes(void);
-int vsr_sr_utd_s2_strip_width(void);
+ * then b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn as fp32); strips of vsr_sr_query(VSR_Q_UTD_S2_STRIP_WIDTH) = 30 LR columns. */
 int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                       vsr_stream_t stream);
-/* Measurement hook: 0 the step with its uniform branches (pairs outside the image skipped), 1 the branch-free step (one basic
- * block; bit-identical output).  Returns the previous variant. */
-int vsr_sr_utd_s2_variant(int variant);
 
 /* The tail for the scale-2 extension in one launch (csrc/sr_tail_s2.hip): `out` DeconvBlock (k6 s2 p2 + PReLU) -> conv_out 3x3
  * (32 -> 3, bias) -> raw planes [N,3,2h,2w] fp32 (decimate != 0: the pixels (2i, 2j) only -> [N,3,h,w]); the x2 map stays in
- * LDS.  hid_nhwc [N,h,w,32] fp16; blob = vsr_sr_tail_s2_blob_bytes() bytes packed by sr.py:pack_tail_s2_blob.  Followed by
+ * LDS.  hid_nhwc [N,h,w,32] fp16; blob = vsr_sr_query(VSR_Q_TAIL_S2_BLOB_BYTES) bytes packed by sr.py:pack_tail_s2_blob.  Followed by
  * vsr_sr_fc_planes_skip_scale_f32 (skip + add_mean + fusion MLP). */
-size_t vsr_sr_tail_s2_blob_bytes(void);
 int vsr_sr_tail_s2_f16(const void* hid_nhwc, const void* blob, float* raw, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                        int decimate, vsr_stream_t stream);
 
@@ -320,17 +272,6 @@ int vsr_sr_convout_planes_f16(const void* hr_nhwc, const float* weight, const fl
 int vsr_sr_fc_planes_skip_scale_f32(const float* raw, const float* x, const float* tail_params, const float* w1, const float* b1,
                                     const float* w2, const float* b2, int nplanes, int hidden, float* out, int h, int w, int scale,
                                     int decimate, vsr_stream_t stream);
-
-/* The same tail evaluated only at the output pixels (4i, 4j): prefc_dec [N,3,h,w] fp32.  Pass 1 of VSR.forward hands its
- * frame to a nearest-neighbour x1/4 resize and nothing else (video_super_resolution.py:41-44), so only these pixels of
- * it are ever read. */
-int vsr_sr_tail_dec_f16(const void* hid_nhwc, const void* blob, const void* conv_out_frags, const float* tail_params,
-                        const float* x, float* prefc_dec, int N, int h, int w, int rows_per_seg, int slopes_le_one,
-                        vsr_stream_t stream);
-
-/* The fusion MLP (vsr_sr_fc_fuse_f32) specialised and unrolled for the reference's 8 planes x 32 hidden units. */
-int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,
-                         int nplanes, int hidden, float* out, int P, int out_nhwc, vsr_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------
@@ -349,12 +290,7 @@ int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, c
  * bias: fp32 [cout_pad] or NULL.  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  fp32 accumulation.
  * splitk_ws: optional fp32 scratch (splitk_ws_bytes); when the launch cannot fill the chip and K is long, K is split
  * over grid.z, partial tiles go to the scratch and a second kernel sums them in a fixed order (deterministic). */
-int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
-                        int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
-                        int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
-                        int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
-                        vsr_stream_t stream);
-/* The same with a column stride of its own (stride applies to rows, stride_x to columns; 0 = the same).  Used by the host to
+/* stride applies to rows, stride_x to columns (0 = the same).  A column stride of its own is used by the host to
  * run a stride-2 first convolution on a <=16-channel map as a stride-(2,1) convolution over PIXEL PAIRS: [N,H,W,16] viewed as
  * [N,H,W/2,32], kernel columns folded into (pair tap, parity) -- 43 % less K than the 32-channel padding (igemm.py HConvPairS2). */
 int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
@@ -371,17 +307,12 @@ int vsr_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, in
  * pool: mode 0 max, 1 average (out H/2 x W/2), 2 max with ceil_mode (out ceil(H/2) x ceil(W/2): OSVOS's VGG pools).  resize_add: out = nearest_resize(a -> HxW) (+ b if given). */
 int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int N, int H, int W, int C, int mode,
                          vsr_stream_t stream);
-int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,
-                            void* out, int N, int H, int W, int C, vsr_stream_t stream);
-/* The same with `a` (up2 = 1) or `b` (b_up2 = 1: b is [N,H/2,W/2,b_ld]) standing for UpsamplingNearest2d(2) of the tensor passed
- * (the doubled map is never written): the tail of an hourglass level, `up` followed by coolAddTensors (pytorch_DIW_scratch.py:
- * UpsamplingNearest2d(scale_factor=2), then F.interpolate(a, b.shape) + b), in one pass with the two-step index arithmetic. */
-int vsr_up2_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, int up2, const void* b_or_null, int b_ld, int b_coff,
-                                int b_up2, void* out, int N, int H, int W, int C, vsr_stream_t stream);
-
-/* vsr_up2_resize_add_nhwc_f16 with either operand given as 1..4 channel segments of equal width C / nseg (separate tensors or
- * slices; pointer / row length / first channel per segment): where the 16-channel branches of an inception block, written as dense
- * maps (full-line stores), meet for the level's sum.  b_nseg = 0: no addend. */
+/* The tail of an hourglass level (pytorch_DIW_scratch.py:29-31 coolAddTensors = F.interpolate(a, b.shape) + b, preceded by
+ * UpsamplingNearest2d(2) on either arm): out [N,H,W,C] dense = nearest-resize(a) (+ b).  `a` (up2 = 1) / `b` (b_up2 = 1: b is
+ * [N,H/2,W/2,.]) may stand for UpsamplingNearest2d(2) of the tensor passed -- the doubled map is never written, the two-step index
+ * arithmetic is applied.  Either operand is given as 1..4 channel SEGMENTS of equal width C / nseg (separate tensors or slices:
+ * pointer / row length / first channel per segment): the 16-channel branches of an inception block are written as dense maps
+ * (full-line stores) and meet here.  b_nseg = 0: no addend. */
 int vsr_resize_add_segs_nhwc_f16(const void* const* a_ptrs, const int* a_lds, const int* a_coffs, int a_nseg, int Ha, int Wa, int up2,
                                  const void* const* b_ptrs, const int* b_lds, const int* b_coffs, int b_nseg, int b_up2, void* out, int N, int H,
                                  int W, int C, vsr_stream_t stream);
@@ -406,7 +337,7 @@ int vsr_conv2d_nchw_f32(const float* in, const float* w_packed, const float* bia
 /* The front of the depth hourglass in ONE launch (csrc/conv_hg_front.hip; reference pytorch_DIW_scratch.py:34-41 + the first
  * ChannelConcat of the outermost level): Conv2d(3,128,7,1,3)+BN+ReLU on in4 [N,H,W,4] fp16 (w1_packed / b1 as for
  * vsr_conv2d_stem_f16), whose 128-channel map is consumed in place by (a) MaxPool2d(2,2) -> pooled [N,H/2,W/2,128] and (b) a
- * 1x1 convolution + ReLU with c2 out-channels (w2_packed [4][c2_pad][32] fp16 = vsr_conv2d_nhwc_f16's packing of a 128-input 1x1,
+ * 1x1 convolution + ReLU with c2 out-channels (w2_packed [4][c2_pad][32] fp16 = vsr_conv2d_nhwc_sx_f16's packing of a 128-input 1x1,
  * b2 [c2_pad]) -> out2 [N,H,W,ld2] channels [0,c2).  stem_out (optional): the 128-channel map itself [N,H,W,s_ld]. */
 int vsr_hg_front_f16(const void* in4, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, int c2, int c2_pad,
                      void* stem_out_or_null, int s_ld, void* pooled_or_null, void* out2, int ld2, int N, int H, int W, vsr_stream_t stream);
@@ -422,7 +353,7 @@ int vsr_flow_head_f16(const void* in, int in_ld, int in_coff, int cin, const voi
                       vsr_stream_t stream);
 
 /* ConvTranspose2d(k=4, s=2, p=1) (+bias +activation) as its four 2x2-tap phase convolutions in ONE launch (grid.z walks
- * phase and split-K slice).  w_packed4[py*2+px]: the phase's taps packed like vsr_conv2d_nhwc_f16 weights (kernel rows
+ * phase and split-K slice).  w_packed4[py*2+px]: the phase's taps packed like vsr_conv2d_nhwc_sx_f16 weights (kernel rows
  * (3,1) for py = 0, (2,0) for py = 1; same along x).  in [N,H,W,in_ld] -> out [N,2H,2W,out_ld], slice [out_coff,+cout). */
 int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* const* w_packed4, const float* bias, void* out,
                            int out_ld, int out_coff, int N, int H, int W, int cin, int cout, int cout_pad, int act, float slope,
@@ -430,7 +361,7 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
 
 /* First convolution of a trunk on an image with <= 4 channels: in4 [N,H,W,4] fp16, w_packed [kh][cout_pad][32] fp16 with
  * k = 4 kx + c (zero for kx >= kw, c >= cin): one K chunk per kernel row instead of one per tap (hourglass 7x7 stem:
- * 7 chunks instead of 49 zero-padded ones).  kw <= 8.  Otherwise as vsr_conv2d_nhwc_f16. */
+ * 7 chunks instead of 49 zero-padded ones).  kw <= 8.  Otherwise as vsr_conv2d_nhwc_sx_f16. */
 int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias, void* out, int out_ld, int out_coff, int N,
                         int H, int W, int Ho, int Wo, int cout, int cout_pad, int kh, int kw, int stride, int pad_y, int pad_x,
                         int act, float slope, vsr_stream_t stream);
@@ -440,17 +371,6 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
  * live), weff[b] [2s][2s][16] fp16 = the branch's transposed-conv kernel with the fuse row folded in; out [N,h,w] fp32. */
 int vsr_osvos_fuse_f16(const void* const* side, const int* hs, const int* ws, int ld, const void* const* weff, const int* strides,
                        int nbranch, float bias, float* out, int N, int h, int w, vsr_stream_t stream);
-
-/* Tuning hook for benchmarks and cross-checks (not part of the path).  0 heuristic kernel choice, 1 never the LDS-patch kernels
- * (nor the tile kernel), 2 the patch kernels whenever legal, 3 / 5 / 6 / 7 subsets of the patch builds, 8 the first gather build
- * (pixel operand through LDS), 10 / 11 128-channel gather tiles always / never.  Ranges set one knob each and leave the mode:
- * 1000 + n split-K fill threshold of the gather kernel (default 128); 2000 + m tile kernel (conv_tile.hip) 0 never, 1 where it
- * wins (default), 3 every layer it can run; 4000 + bn / 5000 + n force the tile width (64 / 128) / split count (0 = heuristic);
- * 6000 + m k_conv_patch_lw (weight block in LDS) 0 never, 1 heuristic (default), 2 wherever a build exists; 7000 + m k_conv1x1_t
- * (128-input-channel 1x1 layers through per-wave LDS slots, contiguous accesses) 0 never (default), 1 where legal; 8000 + m the
- * gather kernel's five-set register ring 0 never (default), 1 launches of at most one workgroup per CU, 2 always.
- * Returns the previous mode. */
-int vsr_conv2d_tuning(int patch_mode);
 
 /* ------------------------------------------------------------------------------------------
  * Train step: forward AND backward kernels of the SR net's operators for the reference's one

@@ -19,6 +19,33 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "xcheck: runs against libvsr_hip_xcheck.so (superseded builds, switches, stamped diagnostics)")
+
+
+# What only the cross-check library (include/vsr_hip_xcheck.h) exports.  A test whose body mentions one of these runs with
+# `_lib.load()` returning libvsr_hip_xcheck.so, so that a switch it sets reaches the kernels the package's classes launch; every
+# other test runs against the shipping library libvsr_hip.so (which has none of these symbols: a stray use fails loudly).
+_XCHECK_WORDS = ("vsr_conv2d_tuning", "_variant(", "stamp_buffer", "vsr_sr_utd2_f16", "vsr_sr_tail_f16", "vsr_sr_tail_dec_f16",
+                 "vsr_sr_fc_planes_f32")
+
+
+@pytest.fixture(autouse=True)
+def _cross_check_library(request):
+    import inspect
+    fn = getattr(request.node, "function", None)
+    want = request.node.get_closest_marker("xcheck") is not None
+    if not want and fn is not None:
+        try:
+            src = inspect.getsource(fn)
+        except (OSError, TypeError):
+            src = ""
+        want = any(w in src for w in _XCHECK_WORDS)
+    if not want:
+        yield
+        return
+    from video_super_resolution_amd import _lib
+    with _lib.xcheck():
+        yield
 
 
 @pytest.fixture(scope="session")

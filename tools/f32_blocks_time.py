@@ -1,6 +1,7 @@
 """Device time of the float32 (de)convolution blocks of the FeedbackBlock (vsr_sr_deconv_f32 / vsr_sr_conv_f32) on the matrix cores
 (variant 0, csrc/sr_f32_mfma.hip) against one pixel per thread (variant 1, csrc/sr_f32.hip).  usage: f32_blocks_time.py [N h w scale]"""
 import os, sys, ctypes
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_super_resolution_amd import _lib as L

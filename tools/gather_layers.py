@@ -1,5 +1,6 @@
 """Kernel times of real trunk layer shapes: the gather kernel (LDS-patch kernels switched off) or, with VSR_TUNING=0, whatever the heuristic picks."""
 import os, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_super_resolution_amd import igemm, _lib as L

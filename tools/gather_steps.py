@@ -1,5 +1,6 @@
 """Gather-kernel time against the number of K steps (square kernels k = 1..11 on one shape, split-K off): intercept = fixed cost of a launch, slope = cost of a K step."""
 import os, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_super_resolution_amd import igemm, _lib as L

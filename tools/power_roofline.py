@@ -3,6 +3,7 @@ random data: k_utd3 (5-plane launches as the forward issues them), a bare v_mfma
 304 VALU : 144 MFMA : 17 LDS mix and no global memory (tools/microbench/power_roofline.hip), k_utd3 again.  Wall TFLOP/s and the
 in-kernel clock (s_memtime / s_memrealtime) of each.  usage: power_roofline.py [seconds per arm] -> text on stdout, JSON to argv[2]"""
 import ctypes, json, os, sys, time
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch

@@ -1,6 +1,7 @@
 """Per-layer time of the three guidance trunks at the bench size (HIP events around every convolution launch,
 one stream): where the trunk milliseconds go.  usage: probe_layers.py [flow|depth|vos] [top] [h w]"""
 import os, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 os.environ.setdefault('MIOPEN_FIND_MODE', '2'); os.environ.setdefault('MIOPEN_LOG_LEVEL', '2')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

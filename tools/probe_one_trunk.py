@@ -1,5 +1,6 @@
 """Runs ONE guidance trunk a few times (target for rocprofv3 --kernel-trace --stats): usage probe_one_trunk.py flow|depth|depth1|vos|sr [reps]"""
 import os, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 os.environ.setdefault('MIOPEN_FIND_MODE', '2'); os.environ.setdefault('MIOPEN_LOG_LEVEL', '2')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

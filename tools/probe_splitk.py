@@ -1,5 +1,6 @@
 """Trunk wall times against the split-K fill threshold (workgroups below which K is split)."""
 import os, sys, time
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_super_resolution_amd import VSR, _lib as L

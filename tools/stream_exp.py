@@ -1,5 +1,6 @@
 """Time of the 1x1 streaming kernel on the hourglass's fused inception reductions."""
 import os, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_super_resolution_amd import igemm, _lib as L

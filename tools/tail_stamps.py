@@ -1,6 +1,7 @@
 """Stamped diagnostic build of the fused tail k_tail3 (full frames, folded compress_out): per-wave shader-clock sums per region of
 the pipelined step, and the in-kernel clock.  usage: tail_stamps.py [h w] [totals]"""
 import os, sys, ctypes
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_super_resolution_amd import SRProjectionModule, _lib as L

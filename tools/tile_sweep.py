@@ -3,6 +3,7 @@ trunks (labels from the event timer) is run STANDALONE (random operands of the l
 through the tile kernel (conv_tile.hip) with forced tile widths / split counts, rounds interleaved in one process.
 usage: tile_sweep.py [flow|depth|vos|all] [min_us]   -> table: layer, current route + us, best candidate + us"""
 import os, re, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 os.environ.setdefault('MIOPEN_FIND_MODE', '2'); os.environ.setdefault('MIOPEN_LOG_LEVEL', '2')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """Standalone wall time of each trunk and of the SR call at the bench size (HIP events, one process)."""
 import os, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_super_resolution_amd import VSR

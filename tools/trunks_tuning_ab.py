@@ -2,6 +2,7 @@
 usage trunks_tuning_ab.py [h w] -- 0 heuristic, 2 patch kernel whenever legal, 5 heuristic without k_conv_patch_r8, 10 / 11 128-channel
 gather tiles always / never."""
 import os, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 os.environ.setdefault('MIOPEN_FIND_MODE', '2'); os.environ.setdefault('MIOPEN_LOG_LEVEL', '2')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

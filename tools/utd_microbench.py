@@ -1,5 +1,6 @@
 """Runs only the fused up->tran->down kernel at the bench size (UTD_N planes, default 8, x 540 x 960) -- target for rocprofv3 --pmc."""
 import os, sys, time
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_super_resolution_amd import SRProjectionModule

@@ -1,6 +1,7 @@
 """Runs only the fused x2 stage kernel k_utd_s2 (8 planes of LR h x w, default the C3-B size 1080 x 1920) -- target for
 rocprofv3 --pmc (tools/utd_pmc.sh s2) and a quick timing."""
 import os, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_super_resolution_amd import SRProjectionModule

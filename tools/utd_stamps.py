@@ -1,6 +1,7 @@
 """Stamped diagnostic builds of the fused stage: per-wave shader-clock sums per phase of the march, and the
 in-kernel clock (s_memtime / s_memrealtime).  usage: utd_stamps.py [2|3|4]   (2: k_utd3, 3: k_utd, 4: k_utd3 totals only)"""
 import os, sys, ctypes
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_super_resolution_amd import SRProjectionModule, _lib as L

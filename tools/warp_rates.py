@@ -2,6 +2,7 @@
 (0: LDS-staged tile + DPP neighbour hand-over, 1: thread-per-pixel gathers), rounds interleaved, on a smooth flow (the
 FlowNet case) and on a rough one."""
 import os, sys
+os.environ.setdefault("VSR_USE_XCHECK", "1")   # the switches / superseded builds used here live in libvsr_hip_xcheck.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_super_resolution_amd import _lib as L

@@ -15,8 +15,14 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libvsr_hip.so")
+XLIB_PATH = os.path.join(_PKG, "libvsr_hip_xcheck.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "vsr_hip.h")
+XHEADER_PATH = os.path.join(_ROOT, "include", "vsr_hip_xcheck.h")
 _lib = None
+_xlib = None
+# the cross-check library instead of the shipping one for every call (set by `xcheck()`; the environment switch serves the
+# measurement tools, whose VSR_TUNING codes only that library understands)
+_use_x = os.environ.get("VSR_USE_XCHECK", "0") == "1" or bool(os.environ.get("VSR_TUNING", "").strip())
 
 
 class VsrHipError(RuntimeError):
@@ -24,42 +30,77 @@ class VsrHipError(RuntimeError):
 
 
 def build(verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into the in-tree libvsr_hip.so (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", os.path.join(_PKG, "csrc")]
+    """Compile every HIP source for gfx950 into the in-tree libvsr_hip.so and libvsr_hip_xcheck.so (hipcc cross-compiles without
+    a GPU)."""
+    cmd = ["make", "-j4", "-C", os.path.join(_PKG, "csrc")]
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)
     return LIB_PATH
 
 
-def declared_symbols() -> list:
-    """Entry points include/vsr_hip.h declares (used by the export test and by `load`)."""
-    with open(HEADER_PATH) as f:
+def declared_symbols(xcheck: bool = False) -> list:
+    """Entry points include/vsr_hip.h declares (xcheck: the ones include/vsr_hip_xcheck.h adds)."""
+    with open(XHEADER_PATH if xcheck else HEADER_PATH) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
     return sorted(set(re.findall(r"\b(vsr_[a-z0-9_]+)\s*\(", text)))
 
 
-def load() -> ctypes.CDLL:
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise VsrHipError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(there is no CPU fallback for the device path)")
-        lib = ctypes.CDLL(LIB_PATH)
-        lib.vsr_last_error.restype = ctypes.c_char_p
-        lib.vsr_last_route.restype = ctypes.c_char_p
-        for fn in ("vsr_sr_utd_blob_bytes", "vsr_sr_utd_s2_blob_bytes", "vsr_sr_tail_s2_blob_bytes", "vsr_train_corr_dw_ws_floats",
-                   "vsr_train_prelu_bwd_ws_floats"):
-            if hasattr(lib, fn):
-                getattr(lib, fn).restype = ctypes.c_size_t
-        if lib.vsr_abi_version() != 1:
-            raise VsrHipError("libvsr_hip.so ABI version mismatch")
+def _open(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise VsrHipError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the device path)")
+    lib = ctypes.CDLL(path)
+    lib.vsr_last_error.restype = ctypes.c_char_p
+    lib.vsr_last_route.restype = ctypes.c_char_p
+    for fn in ("vsr_sr_query", "vsr_train_corr_dw_ws_floats", "vsr_train_prelu_bwd_ws_floats"):
+        getattr(lib, fn).restype = ctypes.c_size_t
+    if lib.vsr_abi_version() != 2:
+        raise VsrHipError(f"{os.path.basename(path)}: ABI version mismatch")
+    return lib
+
+
+def load_xcheck() -> ctypes.CDLL:
+    """libvsr_hip_xcheck.so (include/vsr_hip_xcheck.h): the shipping entry points + the superseded builds, switches and stamped
+    diagnostics.  For tests and tools; the package calls it only from code paths that exist for the tests."""
+    global _xlib
+    if _xlib is None:
+        lib = _open(XLIB_PATH)
         for t in os.environ.get("VSR_TUNING", "").split(","):   # measurement hook: kernel-selection switches (vsr_conv2d_tuning codes)
             if t.strip():
                 lib.vsr_conv2d_tuning(int(t))
-        _lib = lib
+        _xlib = lib
+    return _xlib
+
+
+def load() -> ctypes.CDLL:
+    """The library every product call goes through: libvsr_hip.so, unless a test / tool asked for the cross-check library."""
+    global _lib
+    if _use_x:
+        return load_xcheck()
+    if _lib is None:
+        _lib = _open(LIB_PATH)
     return _lib
+
+
+class xcheck:
+    """`with _lib.xcheck():` -- every `load()` inside returns the cross-check library (so a switch set through it reaches the
+    kernels the package's classes launch)."""
+
+    def __enter__(self):
+        global _use_x
+        self._old, _use_x = _use_x, True
+        return load_xcheck()
+
+    def __exit__(self, *exc):
+        global _use_x
+        _use_x = self._old
+        return False
+
+
+# vsr_sr_query codes (include/vsr_hip.h)
+Q_UTD_BLOB_BYTES, Q_UTD_STRIP_WIDTH, Q_UTD_S2_BLOB_BYTES, Q_UTD_S2_STRIP_WIDTH, Q_TAIL_S2_BLOB_BYTES = range(5)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -35,8 +35,8 @@ using vsrc::PT_W;
 struct C0 { static constexpr int value = 0; };
 struct C1 { static constexpr int value = 1; };
 struct C2 { static constexpr int value = 2; };
-struct C3 { static constexpr int value = 3; };
-struct C4 { static constexpr int value = 4; };
+struct C3 { [[maybe_unused]] static constexpr int value = 3; };   // (sets 3 and 4: the five-set ring of the cross-check library)
+struct C4 { [[maybe_unused]] static constexpr int value = 4; };
 
 
 // Epilogue of the gather kernels.  This lane holds channels co0 + 16 mt + 4 g + {0..3} of pixels 32 wv + 16 nt + l15 (straight
@@ -101,6 +101,7 @@ __device__ __forceinline__ void gather_store(const ConvP& p, const f4 (&acc)[BN 
 // STEM: the input has 4 channels per pixel ([N,H,W,4] fp16, 3 live) and one K chunk is a whole kernel ROW: k = 4 kx + c
 // for kx < 8 (packed weights [ky][cout_pad][32], zero where kx >= kw or c >= cin).  A 7x7 stem on an RGB image is 7 K
 // chunks instead of 49 chunks that are 29/32 zero padding.
+#if VSR_X   // the first gather build (pixel operand through LDS): cross-check library only
 template <int BN, bool STEM = false>
 __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     constexpr int MT = BN / 16;                 // out-channel tiles per wave
@@ -271,6 +272,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(const ConvP p) {
     else if (p.act == 1) gather_store<BN, 1>(p, acc, M, m0, co0, tid, zsplit, ph, oy_off, ox_off);
     else gather_store<BN, 2>(p, acc, M, m0, co0, tid, zsplit, ph, oy_off, ox_off);
 }
+#endif  // VSR_X
 
 
 // k_conv_igemm with the PIXEL operand kept out of LDS.  A wave's MFMA B fragments are its own 32 pixels (lane: pixel
@@ -625,6 +627,7 @@ __global__ void __launch_bounds__(512) k_conv1x1_stream(const ConvP p) {
 __device__ __forceinline__ void c1t_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned off) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, off, 0, 0, 0);
 }
+#if VSR_X   // the transposing 1x1 build (measured: does not pay): cross-check library only
 constexpr int C1T_SLOT = 32 * 256;   // one wave's [32 px][256 B] image
 __global__ void __launch_bounds__(256) k_conv1x1_t(const ConvP p) {
     constexpr int NCH = 4;
@@ -746,6 +749,7 @@ __global__ void __launch_bounds__(256) k_conv1x1_t(const ConvP p) {
     store_group(slots + (cur ^ 1) * C1T_SLOT, prev_mbase, ngroup - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the zero-fill DMA past the last block has landed before the wave ends)
 }
+#endif  // VSR_X
 
 // ---------------------------------------------------------------------------------------------------------------
 // Stride-1 convolutions with a spatial kernel (the hourglass's 3x3..11x11 inception branches and final conv, FlowNet's
@@ -1362,32 +1366,14 @@ __global__ void __launch_bounds__(256) k_nchw_to_nhwc_h(const float* __restrict_
 }
 
 // out[n,y,x,:] = a[n, y*Ha/H, x*Wa/W, slice a] (nearest, as F.interpolate(size)) + b[n,y,x, slice b]; b == null: resize only.
-__global__ void __launch_bounds__(256) k_resize_add(const _Float16* __restrict__ a, int a_ld, int a_coff, int Ha, int Wa,
-                                                    const _Float16* __restrict__ b, int b_ld, int b_coff,
-                                                    _Float16* __restrict__ out, int N, int H, int W, int C, int up2, int b_up2) {
-    // blockIdx.y = image row (n * H + y), blockIdx.x walks (x, 8-channel piece) of that row: 32-bit index math only
-    // (a flat 64-bit index with three divisions per thread made this copy VALU-bound at a third of the device's copy rate)
-    const unsigned c8n = (unsigned)C >> 3;
-    const unsigned q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= (unsigned)W * c8n) return;
-    const unsigned x = q / c8n, c8 = q - x * c8n;
-    const unsigned row = blockIdx.y, n = row / (unsigned)H, y = row - n * (unsigned)H;
-    // ATen nearest: src = min(floor(dst * (in / out)), in - 1) with a float scale
-    // up2: `a` stands for UpsamplingNearest2d(2)(a), never materialised -- the resize indexes the doubled map (same float scale
-    // as the two-step evaluation) and halves the index
-    const int Hs = Ha << up2, Ws = Wa << up2;
-    const int ya = min((int)floorf((float)y * ((float)Hs / (float)H)), Hs - 1) >> up2;
-    const int xa = min((int)floorf((float)x * ((float)Ws / (float)W)), Ws - 1) >> up2;
-    h8v v = *reinterpret_cast<const h8v*>(a + (((size_t)n * Ha + ya) * Wa + xa) * a_ld + a_coff + 8 * c8);
-    // b_up2: `b` stands for UpsamplingNearest2d(2)(b) of exactly the output's size (H = 2 Hb, W = 2 Wb): pixel (y >> 1, x >> 1)
-    if (b) v += *reinterpret_cast<const h8v*>(b + (((size_t)n * (H >> b_up2) + (y >> b_up2)) * (W >> b_up2) + (x >> b_up2)) * b_ld + b_coff + 8 * c8);
-    *reinterpret_cast<h8v*>(out + ((size_t)row * W + x) * C + 8 * c8) = v;
-}
 
 // The same pass with either operand given as up to four channel SEGMENTS of equal width (separate tensors / slices): the 16-channel
 // branches of an inception block write dense [N,H,W,16] maps instead of 32-byte slices of a 512-byte pixel row (partial-line
 // writes: 3x3 64 -> 16 at 4 x 540 x 960 168 -> 118 us, 64 -> 1 139 -> 99, tools/thin_out_ab.py) and meet again here, where the
 // block's 64-channel result is read for the level's sum.
+// (ATen nearest: src = min(floor(dst * (in / out)), in - 1) with a float scale; up2: `a` stands for UpsamplingNearest2d(2)(a), never
+//  materialised -- the resize indexes the doubled map and halves the index; b_up2: `b` likewise, of exactly the output's size.
+//  blockIdx.y = image row, blockIdx.x walks (x, 8-channel piece) of that row: 32-bit index math only.)
 struct SegOp {
     const _Float16* ptr[4];
     int ld[4], coff[4];
@@ -1549,7 +1535,7 @@ __global__ void __launch_bounds__(256) k_corr_mfma(const _Float16* __restrict__ 
 // default --, 1 that rule, 2 always; vsr_conv2d_tuning(8000 + n)).  Measured (tools/trunks_time.py, one box): FlowNet2 3.06 / 3.09 /
 // 3.16 ms, hourglass x4 4.76 / 4.66 / 4.70, OSVOS 1.186 / 1.177 / 1.230 for n = 0 / 1 / 2 -- inside the run-to-run spread: the
 // low-resolution layers are not waiting on the depth of the prefetch.  Bit-identical to the three-set build (tests).
-static int g_gather_deep = 0;
+VSR_TUNABLE g_gather_deep = 0;
 // k_conv_igemm_d's dynamic LDS: the double-buffered weight ring + the K-walk table of one workgroup's range of steps
 template <int BN, bool STEM>
 static int launch_gather(const ConvP& p, dim3 grid, hipStream_t stream) {
@@ -1561,11 +1547,14 @@ static int launch_gather(const ConvP& p, dim3 grid, hipStream_t stream) {
     const size_t lds = (size_t)BN * 256 + (size_t)2 * (ks_per + (deep ? 9 : 5)) * 16;
     if (lds > 64 * 1024) return vsr::fail(VSR_E_ARG, "conv2d: %d K steps per workgroup exceed the kernel's walk table (split K further)", ks_per);
     if ((unsigned long long)npair * p.cout_pad * 64 >= (1ull << 30)) return vsr::fail(VSR_E_ARG, "conv2d: packed weights beyond 1 GiB");
-    if (deep) hipLaunchKernelGGL((k_conv_igemm_d<BN, STEM, 5>), grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((k_conv_igemm_d<BN, STEM, 3>), grid, dim3(256), lds, stream, p);
+#if VSR_X
+    if (deep) { hipLaunchKernelGGL((k_conv_igemm_d<BN, STEM, 5>), grid, dim3(256), lds, stream, p); return VSR_OK; }
+#endif
+    hipLaunchKernelGGL((k_conv_igemm_d<BN, STEM, 3>), grid, dim3(256), lds, stream, p);
     return VSR_OK;
 }
 
+#if VSR_X
 template <int BN, bool STEM>
 static int launch_gather_lds(const ConvP& p, dim3 grid, hipStream_t stream) {
     const int nchunk = STEM ? 1 : p.cin >> 5, npair = STEM ? p.kh : p.kh * p.kw * nchunk;
@@ -1576,20 +1565,21 @@ static int launch_gather_lds(const ConvP& p, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL((k_conv_igemm<BN, STEM>), grid, dim3(256), lds, stream, p);
     return VSR_OK;
 }
+#endif  // VSR_X
 
-static int g_splitk_fill = 128;   // split K when a launch has fewer workgroups than this, into ~2x as many (tools/probe_splitk.py; 256 until the
+VSR_TUNABLE g_splitk_fill = 128;   // split K when a launch has fewer workgroups than this, into ~2x as many (tools/probe_splitk.py; 256 until the
                                    // round-2 rebuild made a K step cheap: FlowNet2 3.7 -> 3.45 ms, hourglass 5.03 -> 4.88, OSVOS 1.25 -> 1.29)
-static int g_tile_mode = 1;   // conv_tile.hip (two-operand LDS-DMA tile): 0 never, 1 (default) where tile_choice says it wins over the gather kernel, 3 every layer it can run, the patch kernels' too (tests) (vsr_conv2d_tuning(2000 + n))
+VSR_TUNABLE g_tile_mode = 1;   // conv_tile.hip (two-operand LDS-DMA tile): 0 never, 1 (default) where tile_choice says it wins over the gather kernel, 3 every layer it can run, the patch kernels' too (tests) (vsr_conv2d_tuning(2000 + n))
 // k_conv1x1_t (contiguous accesses through per-wave LDS slots) for 128-input-channel 1x1 layers: 0 never (default), 1 yes
 // (vsr_conv2d_tuning(7000 + n)).  Measured per layer inside the hourglass (tools/trunk_layers.sh): level with k_conv1x1_stream
 // (4 x 270 x 480 128 -> 128 57 vs 55 us, 128 -> 224 89-93 vs 90-91) and SLOWER on the largest layer (4 x 540 x 960 128 -> 208: 336 vs
 // 371 us) -- the contiguity of the accesses was not what holds the streaming kernel (1.39 GB in 336 us = 4.1 TB/s; a hand-written
 // kernel of that traffic shape reaches 5.1-5.6 TB/s, profiles/r03_stream_rates.txt).  Kept as the bit-identical cross-check build.
-static int g_c1t_mode = 0;
-static int g_lw_mode = 1;     // k_conv_patch_lw (weight block in LDS): 0 never, 1 heuristic, 2 wherever a build exists (vsr_conv2d_tuning(6000 + n))
-static int g_tile_bn = 0, g_tile_splits = 0;   // experiments: force the tile width (64 / 128) / the split count (vsr_conv2d_tuning(4000 + bn), (5000 + n)); 0 = heuristic
-static int g_pf_mode = 1;     // k_conv_patch_pf (persistent, prefetching; conv_patch_pf.hip): 0 never, 1 heuristic, 2 wherever a build exists (64 out-channels per workgroup where the count allows), 3 as 2 with at most 32 per workgroup (vsr_conv2d_tuning(9000 + n))
-static int g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
+[[maybe_unused]] VSR_TUNABLE g_c1t_mode = 0;
+VSR_TUNABLE g_lw_mode = 1;     // k_conv_patch_lw (weight block in LDS): 0 never, 1 heuristic, 2 wherever a build exists (vsr_conv2d_tuning(6000 + n))
+VSR_TUNABLE g_tile_bn = 0, g_tile_splits = 0;   // experiments: force the tile width (64 / 128) / the split count (vsr_conv2d_tuning(4000 + bn), (5000 + n)); 0 = heuristic
+VSR_TUNABLE g_pf_mode = 1;     // k_conv_patch_pf (persistent, prefetching; conv_patch_pf.hip): 0 never, 1 heuristic, 2 wherever a build exists (64 out-channels per workgroup where the count allows), 3 as 2 with at most 32 per workgroup (vsr_conv2d_tuning(9000 + n))
+VSR_TUNABLE g_patch_mode = 0;  // 0: heuristic, 1: never use the LDS-patch kernel, 2: whenever legal, 3: heuristic without the row-reuse builds, 5: heuristic without k_conv_patch_r8, 6 / 7: as 2 without r8 / without r8 and rows, 8: gather layers through the first build k_conv_igemm, 10 / 11: 128-channel gather tiles always / never (tuning hook)
 
 // byte range a gather kernel's buffer resource and its 32-bit offsets cover (0xFFFFFFFF marks "outside the image")
 static constexpr unsigned long long kGatherLimit = 0xFFFFFFFFull;
@@ -1672,6 +1662,7 @@ static int run_tile(ConvP& p, long long M, int nk_all, int nph, void* splitk_ws,
 
 extern "C" {
 
+#if VSR_X
 int vsr_conv2d_tuning(int patch_mode) {
     const int old = g_patch_mode;
     if (patch_mode >= 9000) { g_pf_mode = patch_mode - 9000; return old; }
@@ -1688,6 +1679,7 @@ int vsr_conv2d_tuning(int patch_mode) {
     g_patch_mode = patch_mode;
     return old;
 }
+#endif  // VSR_X
 
 int vsr_pool2x2_nhwc_f16(const void* in, int in_ld, int in_coff, void* out, int N, int H, int W, int C, int mode,
                          vsr_stream_t stream) {
@@ -1707,25 +1699,6 @@ int vsr_nchw_f32_to_nhwc_f16(const float* in, void* out, int N, int C, int H, in
     const long long total = (long long)N * H * W * (cp >> 2);
     hipLaunchKernelGGL(k_nchw_to_nhwc_h, dim3(vsr::cdiv(total, 256)), dim3(256), 0, vsr::S(stream), in, (_Float16*)out, N, C, H * W, cp);
     return vsr::launched("nchw_f32_to_nhwc_f16");
-}
-
-int vsr_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, const void* b_or_null, int b_ld, int b_coff,
-                            void* out, int N, int H, int W, int C, vsr_stream_t stream) {
-    return vsr_up2_resize_add_nhwc_f16(a, a_ld, a_coff, Ha, Wa, 0, b_or_null, b_ld, b_coff, 0, out, N, H, W, C, stream);
-}
-
-int vsr_up2_resize_add_nhwc_f16(const void* a, int a_ld, int a_coff, int Ha, int Wa, int up2, const void* b_or_null, int b_ld, int b_coff,
-                                int b_up2, void* out, int N, int H, int W, int C, vsr_stream_t stream) {
-    VSR_REQUIRE(a && out, "resize_add: null pointer");
-    VSR_REQUIRE((up2 == 0 || up2 == 1) && (b_up2 == 0 || (b_up2 == 1 && b_or_null && (H & 1) == 0 && (W & 1) == 0)),
-                "resize_add: up2 flags (an upsampled addend needs an even output size)");
-    VSR_REQUIRE(N > 0 && H > 0 && W > 0 && Ha > 0 && Wa > 0 && C > 0 && (C & 7) == 0 && (a_ld & 7) == 0 && (a_coff & 7) == 0 &&
-                    a_coff + C <= a_ld, "resize_add: bad arguments");
-    VSR_REQUIRE(!b_or_null || ((b_ld & 7) == 0 && (b_coff & 7) == 0 && b_coff + C <= b_ld), "resize_add: bad addend slice");
-    VSR_REQUIRE((long long)N * H <= 65535 && (long long)W * (C >> 3) < (1ll << 31), "resize_add: more than 65535 image rows");
-    hipLaunchKernelGGL(k_resize_add, dim3(vsr::cdiv((long long)W * (C >> 3), 256), (unsigned)(N * H)), dim3(256), 0, vsr::S(stream),
-                       (const _Float16*)a, a_ld, a_coff, Ha, Wa, (const _Float16*)b_or_null, b_ld, b_coff, (_Float16*)out, N, H, W, C, up2, b_up2);
-    return vsr::launched("resize_add");
 }
 
 int vsr_resize_add_segs_nhwc_f16(const void* const* a_ptrs, const int* a_lds, const int* a_coffs, int a_nseg, int Ha, int Wa, int up2,
@@ -1854,11 +1827,14 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
     p.splits = splits;
     const dim3 grid(gx, gy, 4 * splits);
     vsr::route(splits > 1 ? "deconv4s2 gather<%d>+splitk%d" : "deconv4s2 gather<%d>", bn, splits);
+#if VSR_X
     if (g_patch_mode == 8) {   // the first gather build (pixel operand through LDS): cross-check / A-B
         const int rc = bn == 64 ? launch_gather_lds<64, false>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather_lds<32, false>(p, grid, vsr::S(stream))
                                                                                                      : launch_gather_lds<16, false>(p, grid, vsr::S(stream));
         if (rc) return rc;
-    } else {
+    } else
+#endif
+    {
         const int rc = bn == 64 ? launch_gather<64, false>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather<32, false>(p, grid, vsr::S(stream))
                                                                                                  : launch_gather<16, false>(p, grid, vsr::S(stream));
         if (rc) return rc;
@@ -1904,11 +1880,14 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const dim3 grid(vsr::cdiv(M, BM), cout_pad / bn, 1);
     vsr::route("gather<%d,stem>", bn);
-    if (g_patch_mode == 8) {
+#if VSR_X
+    if (g_patch_mode == 8) {   // the first gather build (pixel operand through LDS): cross-check / A-B
         const int rc = bn == 64 ? launch_gather_lds<64, true>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather_lds<32, true>(p, grid, vsr::S(stream))
                                                                                                     : launch_gather_lds<16, true>(p, grid, vsr::S(stream));
         if (rc) return rc;
-    } else {
+    } else
+#endif
+    {
         const int rc = bn == 64 ? launch_gather<64, true>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather<32, true>(p, grid, vsr::S(stream))
                                                                                                 : launch_gather<16, true>(p, grid, vsr::S(stream));
         if (rc) return rc;
@@ -2043,6 +2022,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         g_patch_mode != 1) {
         p.ws = nullptr;
         p.splits = 1;
+#if VSR_X
         // 128 input channels, 8-aligned output slice: the build with contiguous KiB accesses on both sides (k_conv1x1_t)
         const size_t t_lds = w_lds + (size_t)cout_pad * 4 + (size_t)4 * 2 * C1T_SLOT;
         if (g_c1t_mode >= 1 && cin == 128 && (cout & 7) == 0 && (out_ld & 7) == 0 && (out_coff & 7) == 0 && t_lds <= 160 * 1024 &&
@@ -2059,6 +2039,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
             hipLaunchKernelGGL(k_conv1x1_t, dim3(grid), dim3(256), t_lds, vsr::S(stream), p);
             return vsr::launched("conv2d_nhwc_f16/1x1t");
         }
+#endif  // VSR_X
         typedef void (*k1_t)(const ConvP);
         static const k1_t k1[C1_MAX_CHUNKS] = {k_conv1x1_stream<1>, k_conv1x1_stream<2>, k_conv1x1_stream<3>, k_conv1x1_stream<4>,
                                                k_conv1x1_stream<5>, k_conv1x1_stream<6>, k_conv1x1_stream<7>, k_conv1x1_stream<8>};
@@ -2097,11 +2078,14 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     p.splits = splits;
     const dim3 grid(gx, gy, splits);
     vsr::route(splits > 1 ? "gather<%d>+splitk%d" : "gather<%d>", bn, splits);
+#if VSR_X
     if (g_patch_mode == 8) {   // the first gather build (pixel operand through LDS): cross-check / A-B
         const int rc = bn == 64 ? launch_gather_lds<64, false>(p, grid, vsr::S(stream)) : bn == 32 ? launch_gather_lds<32, false>(p, grid, vsr::S(stream))
                                                                                                      : launch_gather_lds<16, false>(p, grid, vsr::S(stream));
         if (rc) return rc;
-    } else {
+    } else
+#endif
+    {
         const int rc = bn == 128 ? launch_gather<128, false>(p, grid, vsr::S(stream)) : bn == 64 ? launch_gather<64, false>(p, grid, vsr::S(stream))
                      : bn == 32 ? launch_gather<32, false>(p, grid, vsr::S(stream)) : launch_gather<16, false>(p, grid, vsr::S(stream));
         if (rc) return rc;
@@ -2112,17 +2096,6 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         hipLaunchKernelGGL(k_splitk_finish, dim3(vsr::cdiv(M * (cout_pad >> 2), 256)), dim3(256), 0, vsr::S(stream), p);
     }
     return vsr::launched("conv2d_nhwc_f16");
-}
-
-/* the common case: one stride for rows and columns */
-int vsr_conv2d_nhwc_f16(const void* in, int in_ld, int in_coff, const void* w_packed, const float* bias, void* out,
-                        int out_ld, int out_coff, int N, int H, int W, int cin, int Ho, int Wo, int cout, int cout_pad,
-                        int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off,
-                        int ox_mul, int ox_off, int act, float slope, void* splitk_ws, size_t splitk_ws_bytes,
-                        vsr_stream_t stream) {
-    return vsr_conv2d_nhwc_sx_f16(in, in_ld, in_coff, w_packed, bias, out, out_ld, out_coff, N, H, W, cin, Ho, Wo, cout, cout_pad, kh, kw,
-                                  stride, stride, pad_y, pad_x, outH, outW, oy_mul, oy_off, ox_mul, ox_off, act, slope, splitk_ws,
-                                  splitk_ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -475,6 +475,7 @@ __global__ void __launch_bounds__(kBlock) k_flow_up_warp_concat16(const float* _
 // move per value (`row_shl:1`; the last lane of each 16-lane row and lanes whose neighbour samples elsewhere read it themselves).
 // A sample outside the staged tile (displacement beyond the halo) falls back to the global load of the gather build.  Same values
 // into the same arithmetic: bit-identical to k_flow_up_warp_concat16 (tests/test_gpu_flow_ops.py).
+#if VSR_X   // the LDS-staged warp of north_star's wording (1.0-1.9x slower than the gather build): cross-check library only
 constexpr int WT_Y = 4, WT_X = 64, WT_R = 8, WP_H = WT_Y + 2 * WT_R, WP_W = WT_X + 2 * WT_R;
 __device__ __forceinline__ float dpp_next_lane(float v) {   // lane i <- lane i + 1 inside each row of 16 lanes (lane 15: 0)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));
@@ -545,6 +546,7 @@ __global__ void __launch_bounds__(kBlock) k_flow_up_warp_concat16_lds(const floa
     *reinterpret_cast<h8g*>(o + 8) = h8g{(_Float16)wv[2], (_Float16)(dx * inv_div), (_Float16)(dy * inv_div), (_Float16)sqrtf(acc),
                                          (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
 }
+#endif  // VSR_X
 
 // models.py:106-125 in one pass: the two nearest-upsampled flows (FlowNetS #2 x div_flow, FlowNetSD / div_flow), their norms,
 // the two brightness errors of the warps, concatenated with frame a -- straight into the NHWC half map [B,H,W,32] the fusion
@@ -652,17 +654,19 @@ inline unsigned grid_for(size_t n) {
 // Measured at 2 x 512 x 960, rounds interleaved (tools/warp_rates.py): smooth flow 16.6 us (gathers) vs 31.3 us (LDS-staged), ~2 px
 // 19.1 vs 29.9, ~20 px 39.5 vs 39.5, ~160 px 50.6 vs 67.1 -- a 4 x 64 tile with a halo of 8 stages 6.25 x its own pixels, while the
 // gathers' neighbour re-reads hit L1 (FETCH = 2 x the planes read once, profiles/r02_frame_hbm_table.txt): the gather build stays.
-static int g_warp_variant = 1;
+[[maybe_unused]] VSR_TUNABLE g_warp_variant = 1;
 
 }  // namespace
 
 extern "C" {
 
+#if VSR_X
 int vsr_flownet_warp_variant(int v) {
     VSR_REQUIRE(v == 0 || v == 1, "flownet_warp_variant: 0 LDS-staged tile + wave shuffles, 1 gathers");
     g_warp_variant = v;
     return VSR_OK;
 }
+#endif
 
 int vsr_abi_version(void) { return VSR_ABI_VERSION; }
 const char* vsr_last_error(void) { return vsr::err_buf(); }
@@ -794,11 +798,13 @@ int vsr_flownet_up_warp_concat16_f16(const float* x6, const void* flow2_nhwc, in
                                      int B, int H, int W, vsr_stream_t stream) {
     VSR_REQUIRE(x6 && flow2_nhwc && out16, "up_warp_concat16: null pointer");
     VSR_REQUIRE(B > 0 && H >= 4 && W >= 4 && (H & 3) == 0 && (W & 3) == 0 && ld >= 2, "up_warp_concat16: bad shape (H, W multiples of 4)");
+#if VSR_X
     if (g_warp_variant == 0 && B <= 65535 && (H + WT_Y - 1) / WT_Y <= 65535) {   // LDS-staged tile + DPP neighbour hand-over
         hipLaunchKernelGGL(k_flow_up_warp_concat16_lds, dim3((W + WT_X - 1) / WT_X, (H + WT_Y - 1) / WT_Y, B), dim3(kBlock), 0, vsr::S(stream), x6,
                            (const _Float16*)flow2_nhwc, ld, bilinear, mul, inv_div, (_Float16*)out16, H, W);
         return vsr::launched("up_warp_concat16/lds");
     }
+#endif
     hipLaunchKernelGGL(k_flow_up_warp_concat16, dim3(grid_for((size_t)H * W), B), dim3(kBlock), 0, vsr::S(stream), x6,
                        (const _Float16*)flow2_nhwc, ld, bilinear, mul, inv_div, (_Float16*)out16, H, W);
     return vsr::launched("up_warp_concat16");

@@ -29,6 +29,7 @@
 
 namespace {
 
+#if VSR_X   // k_utd: the fused stage with two waves per SIMD and an LDS ring (superseded by k_utd3; also the deconv-only mode): cross-check library only
 // MODE 0: full up -> tran -> down stage, `out` = LR map [N,h,w,32] fp16.
 // MODE 1: deconv + PReLU only, `out` = HR map [N,4h,4w,32] fp16 (used for the `out` DeconvBlock of the tail).
 // ALLMAX: every PReLU slope of the stage is <= 1, so prelu(v) = max(v, a*v) (one compare-free packed op);
@@ -325,6 +326,8 @@ k_utd(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _
         }
     }
 }
+
+#endif  // VSR_X
 
 // ---- 1x1 conv over up to three NHWC fp16 inputs (+ fp32 NHWC constant map) + bias + PReLU -> NHWC fp16, on MFMA.
 //      HBM-bound (64 B in per input + 64 B out per pixel).  One wave = 16 consecutive pixels per trip:
@@ -764,6 +767,7 @@ k_head_h(const float* __restrict__ x, const float* __restrict__ sub_scale, const
     }
 }
 
+#if VSR_X   // k_utd2 (producer / consumer waves) and k_tail (LDS-ring tail): superseded by k_utd3 / k_tail3; cross-check library only
 // ---------------------------------------------------------------------------------------------------------------
 // k_utd2: the same fused stage with SPECIALISED wave roles.  In k_utd every wave runs P2 then P1 and both waves of
 // a SIMD stall in step on their own MFMA->VALU->MFMA chains (PMC: MFMA pipe busy 45 %, 38 % of wave time parked).
@@ -1164,6 +1168,9 @@ k_tail(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     }
 }
 
+#endif  // VSR_X
+
+#if VSR_X   // the fusion MLP without the skip (k_tail applies the skip itself): cross-check library only
 // ---- fusion MLP over the 8 pre-fusion planes (SRProjectionModule.py:126-131,146), fully unrolled
 template <int NPL, int HID>
 __global__ void __launch_bounds__(256)
@@ -1193,6 +1200,8 @@ k_fc_planes(const float* __restrict__ prefc, const float* __restrict__ w1, const
 //      Every product-sum below is an explicit fma (contraction off), so the one-pixel build (decimated pass) and the
 //      four-pixel build (full frame) round identically: the decimated frame IS the full frame at (4i, 4j), bit for bit.
 #pragma clang fp contract(off)
+#endif  // VSR_X
+
 __device__ __forceinline__ float fc_lerp4(float v00, float v01, float v10, float v11, float lx, float ly) {
     const float top = __builtin_fmaf(lx, v01, (1.0f - lx) * v00), bot = __builtin_fmaf(lx, v11, (1.0f - lx) * v10);
     return __builtin_fmaf(ly, bot, (1.0f - ly) * top);
@@ -1294,23 +1303,27 @@ k_fc_planes_skip4(const float* __restrict__ raw, const float* __restrict__ x, co
 
 }  // namespace
 
-static int g_utd_variant = 0;
+[[maybe_unused]] VSR_TUNABLE g_utd_variant = 0;
 
 namespace vsr {
 int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                 int diag, hipStream_t stream);
 int utd3_set_stamps(void* buf);
 int tail3_set_stamps(void* buf, int totals_only);
+size_t utd_s2_blob_bytes();
+int utd_s2_strip_width();
+size_t tail_s2_blob_bytes();
 int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* prefc, int N,
                  int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream, const void* in2 = nullptr,
                  const float* cmap = nullptr);
 }
 
-static int g_fc_one_pixel = 0;     // 1: full frames through the one-pixel fusion build too (cross-check)
-static int g_chain_generic = 0;   // 1: every chain through the generic build (cross-check / A-B)
+VSR_TUNABLE g_fc_one_pixel = 0;     // 1: full frames through the one-pixel fusion build too (cross-check)
+VSR_TUNABLE g_chain_generic = 0;   // 1: every chain through the generic build (cross-check / A-B)
 
 extern "C" {
 
+#if VSR_X
 int vsr_sr_chain_variant(int generic) {
     const int old = g_chain_generic | (g_fc_one_pixel << 1);
     g_chain_generic = generic & 1;
@@ -1332,9 +1345,18 @@ int vsr_sr_utd_stamp_buffer(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_ptr), &buf, sizeof(buf));
 }
 
-size_t vsr_sr_utd_blob_bytes(void) { return BLOB_BYTES; }
+#endif  // VSR_X
 
-int vsr_sr_utd_strip_width(void) { return TX; }
+size_t vsr_sr_query(int what) {
+    switch (what) {
+        case VSR_Q_UTD_BLOB_BYTES: return BLOB_BYTES;
+        case VSR_Q_UTD_STRIP_WIDTH: return TX;
+        case VSR_Q_UTD_S2_BLOB_BYTES: return vsr::utd_s2_blob_bytes();
+        case VSR_Q_UTD_S2_STRIP_WIDTH: return (size_t)vsr::utd_s2_strip_width();
+        case VSR_Q_TAIL_S2_BLOB_BYTES: return vsr::tail_s2_blob_bytes();
+        default: return 0;
+    }
+}
 
 int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int deconv_only,
                    int slopes_le_one, vsr_stream_t stream) {
@@ -1342,6 +1364,11 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg != 0 && rows_per_seg >= -65535 && N <= 65535, "sr_utd: bad shape");
     VSR_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0, "sr_utd: pointers must be 16-byte aligned");
+#if !VSR_X
+    // the shipping library holds the one-wave-per-SIMD build (k_utd3, sr_utd3.hip) only
+    if (deconv_only) return vsr::fail(VSR_E_UNSUPPORTED, "sr_utd: the deconv-only mode lives in the cross-check library (libvsr_hip_xcheck.so)");
+    return vsr::launch_utd3(in, blob, out, N, h, w, rows_per_seg, slopes_le_one, 0, vsr::S(stream));
+#else
     const bool one_wave_build = !deconv_only && (g_utd_variant == 0 || g_utd_variant == 2 || g_utd_variant == 4);
     if (rows_per_seg < 0 && !one_wave_build) rows_per_seg = h;   // the flat split exists in the one-wave-per-SIMD build only: one march per strip (same values)
     const unsigned strips = vsr::cdiv(w, TX), segs = rows_per_seg > 0 ? vsr::cdiv(h, rows_per_seg) : 1;
@@ -1366,6 +1393,7 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
     hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(512), UTD_LDS, vsr::S(stream), (const _Float16*)in,
                        (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
     return vsr::launched("sr_utd");
+#endif
 }
 
 int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* in1, const float* w1, int ldw1,
@@ -1413,7 +1441,7 @@ int vsr_sr_chain1x1_f16(const vsr_chain1x1_t* chain, int N, int P, vsr_stream_t 
         for (int t = 0; t < 2; ++t) min_mask |= cp.st[s].in[t] ? 1 << (2 * s + t) : 0;
         if (s > 0 && cp.st[s].cmap) cmap_late = 1;
     }
-    const int key = g_chain_generic || cmap_late || total >= (1ull << 26) ? -1 : chain->nstages * 1000 + min_mask * 10 + cmap0;
+    const int key = g_chain_generic != 0 || cmap_late || total >= (1ull << 26) ? -1 : chain->nstages * 1000 + min_mask * 10 + cmap0;
 #define VSR_CHAIN_CASE(NS_, MIN_, CM_)                                                                                   \
     case NS_ * 1000 + MIN_ * 10 + CM_:                                                                                   \
         hipLaunchKernelGGL((k_chain1x1_s<NS_, MIN_, (CM_ != 0)>), dim3(grid), dim3(256), 0, vsr::S(stream), cp, (unsigned)P, \
@@ -1442,6 +1470,7 @@ int vsr_sr_head_f16(const float* x, const float* sub_scale3, const float* sub_bi
     return vsr::launched("sr_head_f16");
 }
 
+#if VSR_X
 int vsr_sr_utd2_f16(const void* in, const void* blob_v2, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                     vsr_stream_t stream) {
     VSR_REQUIRE(in && blob_v2 && out, "sr_utd2: null pointer");
@@ -1502,6 +1531,8 @@ int vsr_sr_tail_dec_f16(const void* hid_nhwc, const void* blob, const void* conv
     return tail_launch(hid_nhwc, blob, conv_out_frags, tail_params, x, prefc_dec, N, h, w, rows_per_seg, slopes_le_one, true, stream);
 }
 
+#endif  // VSR_X
+
 int vsr_sr_tail3_f16(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* raw,
                      int N, int h, int w, int rows_per_seg, int slopes_le_one, int decimate, vsr_stream_t stream) {
     VSR_REQUIRE(hid_nhwc && blob && conv3_frags && tail_params && raw, "sr_tail3_f16: null pointer");
@@ -1529,7 +1560,7 @@ int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tai
     if (nplanes != 8 || hidden != 32)
         return vsr::fail(VSR_E_UNSUPPORTED, "sr_fc_planes_skip: %d planes / %d hidden units (the reference fuses 8 through 32)", nplanes, hidden);
     const size_t P = decimate ? (size_t)h * w : (size_t)16 * h * w;
-    if (decimate || g_fc_one_pixel)
+    if (decimate != 0 || g_fc_one_pixel != 0)
         hipLaunchKernelGGL((k_fc_planes_skip<8, 32>), dim3(vsr::cdiv(P, 256), 3), dim3(256), 0, vsr::S(stream), raw, x, tail_params, w1, b1,
                            w2, b2, out, h, w, decimate);
     else
@@ -1538,6 +1569,7 @@ int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tai
     return vsr::launched("sr_fc_planes_skip");
 }
 
+#if VSR_X
 int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,
                          int nplanes, int hidden, float* out, int P, int out_nhwc, vsr_stream_t stream) {
     VSR_REQUIRE(prefc && w1 && b1 && w2 && b2 && out, "sr_fc_planes: null pointer");
@@ -1548,6 +1580,6 @@ int vsr_sr_fc_planes_f32(const float* prefc, const float* w1, const float* b1, c
                        (size_t)P, out_nhwc);
     return vsr::launched("sr_fc_planes");
 }
-
+#endif  // VSR_X
 
 }  // extern "C"

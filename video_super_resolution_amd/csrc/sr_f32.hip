@@ -260,7 +260,7 @@ int vsr_sr_head_f32(const float* x, const float* sub_scale3, const float* sub_bi
     return vsr::launched("sr_head");
 }
 
-static int g_f32_variant = 0;   // 0: the (de)convolutions on v_mfma_f32_32x32x2_f32 (sr_f32_mfma.hip); 1: one pixel per thread (cross-check); 2: as 0 with the
+VSR_TUNABLE g_f32_variant = 0;   // 0: the (de)convolutions on v_mfma_f32_32x32x2_f32 (sr_f32_mfma.hip); 1: one pixel per thread (cross-check); 2: as 0 with the
                                 // convolution's per-tap MFMA build (measurements)
 
 int vsr_sr_conv1x1_f32(const float* in0, const float* w0, int ldw0, const float* in1, const float* w1, int ldw1,
@@ -278,11 +278,13 @@ int vsr_sr_conv1x1_f32(const float* in0, const float* w0, int ldw0, const float*
     return vsr::launched("sr_conv1x1");
 }
 
+#if VSR_X
 int vsr_sr_f32_variant(int v) {
     const int old = g_f32_variant;
     g_f32_variant = v < 0 || v > 2 ? 0 : v;
     return old;
 }
+#endif
 
 int vsr_sr_deconv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
                       int h, int w, int scale, vsr_stream_t stream) {
@@ -305,23 +307,15 @@ int vsr_sr_conv_f32(const float* in, const float* weight_packed, const float* bi
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && h <= 65535 && N <= 65535, "sr_conv: bad shape");
     if (g_f32_variant == 0 && vsr::launch_conv_f32_mfma(in, weight_packed, bias, slope, out, N, h, w, scale, vsr::S(stream)))
         return vsr::launched("sr_conv_mfma");
+#if VSR_X
     if (g_f32_variant == 2 && vsr::launch_conv_f32_mfma_per_tap(in, weight_packed, bias, slope, out, N, h, w, scale, vsr::S(stream)))
         return vsr::launched("sr_conv_mfma_per_tap");
+#endif
     const dim3 grid(vsr::cdiv(w, kBlock), h, N);
     if (scale == 4) hipLaunchKernelGGL((k_conv<8, 4>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
     else if (scale == 3) hipLaunchKernelGGL((k_conv<7, 3>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
     else hipLaunchKernelGGL((k_conv<6, 2>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
     return vsr::launched("sr_conv");
-}
-
-int vsr_sr_deconv8s4_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
-                         int h, int w, vsr_stream_t stream) {
-    return vsr_sr_deconv_f32(in, weight_packed, bias, slope, out, N, h, w, 4, stream);
-}
-
-int vsr_sr_conv8s4_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
-                       int h, int w, vsr_stream_t stream) {
-    return vsr_sr_conv_f32(in, weight_packed, bias, slope, out, N, h, w, 4, stream);
 }
 
 int vsr_sr_tail_scale_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
@@ -334,12 +328,6 @@ int vsr_sr_tail_scale_f32(const float* hr, const float* w_out, const float* b_ou
     hipLaunchKernelGGL(k_tail, dim3(vsr::cdiv((long long)scale * w, kBlock), scale * h, N), dim3(kBlock), 0, vsr::S(stream), hr, w_out,
                        b_out, x, sub_scale3, sub_bias3, add_scale3, add_bias3, prefc, h, w, scale);
     return vsr::launched("sr_tail");
-}
-
-int vsr_sr_tail_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
-                    const float* sub_bias3, const float* add_scale3, const float* add_bias3, float* prefc, int N, int h,
-                    int w, vsr_stream_t stream) {
-    return vsr_sr_tail_scale_f32(hr, w_out, b_out, x, sub_scale3, sub_bias3, add_scale3, add_bias3, prefc, N, h, w, 4, stream);
 }
 
 int vsr_sr_fc_fuse_f32(const float* prefc, const float* w1, const float* b1, const float* w2, const float* b2,

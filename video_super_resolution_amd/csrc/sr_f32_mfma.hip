@@ -18,6 +18,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float prelu(float v, float slope) { return v >= 0.0f ? v : v * slope; }
 
+#if VSR_X   // the per-tap build (reloads the pixel operand per tap; measurements / cross-check library only)
 // Conv2d(32,32,K,S,p2) + PReLU: out[co, iy, ix] = b + sum_{ky,kx,ci} in[ci, S iy - 2 + ky, S ix - 2 + kx] W[ky][kx][ci][co].
 // Workgroup = 4 waves = 4 consecutive output rows x 64 output columns (the rows share K - S input rows through L1); a wave holds
 // two 32 x 32 accumulator tiles (pixels ix0 .. ix0+31, ix0+32 .. ix0+63) that share every weight fragment.
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma(const float* __restrict__ in,
         }
     }
 }
+#endif  // VSR_X
 
 // The same convolution with the pixel operand loaded ONCE per (input row, channel pair, column class) instead of once per tap:
 // the taps kx = c, c + S, c + 2S, .. of a row read the same strided sequence V_c[p] = in[ci, Y, S p - 2 + c] shifted by 0, 1, 2, ..
@@ -155,6 +157,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma_sh(const float* __restrict__ 
     }
 }
 
+#if VSR_X   // per-tap build of the transposed convolution: cross-check library only
 // ConvTranspose2d(32,32,K,S,p2) + PReLU: HR pixel (Y, X), iy = (Y+2)/S, py = (Y+2)%S, q = (X+2)/S, px = (X+2)%S:
 //   out = b + sum_{dy, dx < T: py + S dy < K, px + S dx < K} sum_ci in[ci, iy - dy, q - dx] W[py + S dy][px + S dx][ci][co].
 // A wave owns one HR row Y and 64 consecutive q (two pixel tiles); the pixel operand of a (dy, dx, channel pair) does not depend
@@ -227,6 +230,7 @@ __global__ void __launch_bounds__(256) k_deconv_mfma(const float* __restrict__ i
         }
     }
 }
+#endif  // VSR_X
 
 // The transposed convolution with the pixel operand loaded once per (input row, channel pair): the T column taps dx of a row read
 // the same pixels shifted by dx (ds_bpermute_b32, as k_conv_mfma_sh); a wave owns NT pixel tiles (each weight fragment serves
@@ -393,6 +397,7 @@ bool launch_conv_f32_mfma(const float* in, const float* wp, const float* bias, f
     return true;
 }
 
+#if VSR_X
 // (the per-tap build of the convolution: reachable for measurements only)
 bool launch_conv_f32_mfma_per_tap(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale,
                                   hipStream_t stream) {
@@ -403,6 +408,7 @@ bool launch_conv_f32_mfma_per_tap(const float* in, const float* wp, const float*
     else hipLaunchKernelGGL((k_conv_mfma<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
     return true;
 }
+#endif  // VSR_X
 
 void launch_conv1x1_f32_mfma(const float* in0, const float* w0, int ld0, const float* in1, const float* w1, int ld1, const float* in2,
                              const float* w2, int ld2, const float* bias, const float* cmap, float slope, float* out, int N, size_t P,
@@ -415,11 +421,16 @@ bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias,
                             bool per_tap, hipStream_t stream) {
     if ((size_t)NF * h * w * 4 >= (1ull << 32) - 16 || (scale * h + 3) / 4 > 65535) return false;
     const dim3 grid(vsr::cdiv(w + 1, 64), vsr::cdiv(scale * h, 4), N);
+#if VSR_X
     if (per_tap) {
         if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma<8, 4>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
         else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma<7, 3>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
         else hipLaunchKernelGGL((k_deconv_mfma<6, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
-    } else if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma_sh<8, 4, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+        return true;
+    }
+#endif
+    (void)per_tap;
+    if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma_sh<8, 4, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
     else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma_sh<7, 3, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
     else   // (two pixel tiles per wave; four measured level: 3.27-3.50 vs 3.39-3.43 ms, at one wave per SIMD instead of two)
         hipLaunchKernelGGL((k_deconv_mfma_sh<6, 2, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);

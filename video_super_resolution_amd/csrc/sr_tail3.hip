@@ -726,19 +726,28 @@ k_tail3(const _Float16* __restrict__ in, const _Float16* __restrict__ in2, const
 
 namespace vsr {
 
+#if VSR_X   // the stamped diagnostic builds: cross-check library only
 static int g_t3_diag = 0;
 int tail3_set_stamps(void* buf, int totals_only) {
     g_t3_diag = buf ? (totals_only ? 2 : 1) : 0;
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_t3_ptr), &buf, sizeof(buf));
 }
+#endif
 
 int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags, const float* tail_params, float* prefc, int N,
                  int h, int w, int rows_per_seg, int slopes_le_one, int dec, hipStream_t stream, const void* in2, const float* cmap) {
     typedef void (*kern_t)(const _Float16*, const _Float16*, const float*, const unsigned char*, const unsigned char*, const float*,
                            float*, int, int, int);
+#if VSR_X
     static const kern_t kerns[10] = {k_tail3<false, false, false>, k_tail3<true, false, false>, k_tail3<false, true, false>,
                                     k_tail3<true, true, false>,   k_tail3<false, false, true>, k_tail3<true, false, true>,
                                     k_tail3<false, true, true>,   k_tail3<true, true, true>,   k_tail3<true, false, true, 1>, k_tail3<true, false, true, 2>};
+#else
+    static const kern_t kerns[8] = {k_tail3<false, false, false>, k_tail3<true, false, false>, k_tail3<false, true, false>,
+                                   k_tail3<true, true, false>,   k_tail3<false, false, true>, k_tail3<true, false, true>,
+                                   k_tail3<false, true, true>,   k_tail3<true, true, true>};
+    constexpr int g_t3_diag = 0;
+#endif
     static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
     if (!vsr::device_marked(attr_devs)) {
         for (kern_t k : kerns)
@@ -750,7 +759,7 @@ int launch_tail3(const void* hid_nhwc, const void* blob, const void* conv3_frags
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
     if (in2 && (size_t)h * w * NF * 4 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail3: constant map beyond 2 GiB");
     const int ki = (in2 ? 4 : 0) + (dec ? 2 : 0) + (slopes_le_one ? 1 : 0);
-    hipLaunchKernelGGL(kerns[g_t3_diag && ki == 5 ? 7 + g_t3_diag : ki], dim3(strips, segs, N), dim3(256), T3_LDS, stream,
+    hipLaunchKernelGGL(kerns[g_t3_diag != 0 && ki == 5 ? 7 + g_t3_diag : ki], dim3(strips, segs, N), dim3(256), T3_LDS, stream,
                        (const _Float16*)hid_nhwc, (const _Float16*)in2, cmap, (const unsigned char*)blob,
                        (const unsigned char*)conv3_frags, tail_params, prefc, h, w, rows_per_seg);
     return vsr::launched("sr_tail3");

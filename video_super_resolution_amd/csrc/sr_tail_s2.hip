@@ -195,7 +195,7 @@ k_tail_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blo
 
 extern "C" {
 
-size_t vsr_sr_tail_s2_blob_bytes(void) { return T2_BLOB_BYTES; }
+
 
 int vsr_sr_tail_s2_f16(const void* hid_nhwc, const void* blob, float* raw, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                        int decimate, vsr_stream_t stream) {
@@ -216,3 +216,5 @@ int vsr_sr_tail_s2_f16(const void* hid_nhwc, const void* blob, float* raw, int N
 }
 
 }  // extern "C"
+
+namespace vsr { size_t tail_s2_blob_bytes() { return T2_BLOB_BYTES; } }

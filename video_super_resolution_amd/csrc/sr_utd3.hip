@@ -531,13 +531,20 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
 
 namespace vsr {
 
+#if VSR_X   // the stamped diagnostic builds: cross-check library only
 int utd3_set_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp3_ptr), &buf, sizeof(buf)); }
+#endif
 
 // launch of the fused stage on k_utd3 (called by vsr_sr_utd_f16, which has validated the arguments)
 int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                 int diag, hipStream_t stream) {
     typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int, int);
+#if VSR_X
     static const kern_t kerns[4] = {k_utd3<false, 0>, k_utd3<true, 0>, k_utd3<true, 1>, k_utd3<true, 2>};
+#else
+    static const kern_t kerns[2] = {k_utd3<false, 0>, k_utd3<true, 0>};
+    diag = 0;
+#endif
     static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
     if (!vsr::device_marked(attr_devs)) {
         for (kern_t k : kerns)

@@ -260,18 +260,18 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
 
 }  // namespace
 
-static int g_utd_s2_variant = 0;
+[[maybe_unused]] VSR_TUNABLE g_utd_s2_variant = 0;
 
 extern "C" {
 
+#if VSR_X
 int vsr_sr_utd_s2_variant(int v) {
     const int old = g_utd_s2_variant;
     g_utd_s2_variant = v & 1;
     return old;
 }
+#endif
 
-size_t vsr_sr_utd_s2_blob_bytes(void) { return S2_BLOB_BYTES; }
-int vsr_sr_utd_s2_strip_width(void) { return S2_TX; }
 
 int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                       vsr_stream_t stream) {
@@ -283,10 +283,18 @@ int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h,
     const unsigned strips = vsr::cdiv(w, S2_TX), segs = vsr::cdiv(h, rows_per_seg);
     VSR_REQUIRE(segs <= 65535, "sr_utd_s2: too many row segments");
     typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
+#if VSR_X   // (+ the branch-free "flat" build: bit-identical, measured level; cross-check library only)
     static const kern_t kerns[4] = {k_utd_s2<false, false>, k_utd_s2<true, false>, k_utd_s2<false, true>, k_utd_s2<true, true>};
-    hipLaunchKernelGGL(kerns[2 * g_utd_s2_variant + (slopes_le_one ? 1 : 0)], dim3(strips, segs, N), dim3(256), S2_LDS, vsr::S(stream),
+    const int kidx = 2 * g_utd_s2_variant + (slopes_le_one ? 1 : 0);
+#else
+    static const kern_t kerns[2] = {k_utd_s2<false, false>, k_utd_s2<true, false>};
+    const int kidx = slopes_le_one ? 1 : 0;
+#endif
+    hipLaunchKernelGGL(kerns[kidx], dim3(strips, segs, N), dim3(256), S2_LDS, vsr::S(stream),
                        (const _Float16*)in, (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
     return vsr::launched("sr_utd_s2");
 }
 
 }  // extern "C"
+
+namespace vsr { size_t utd_s2_blob_bytes() { return S2_BLOB_BYTES; }  int utd_s2_strip_width() { return S2_TX; } }

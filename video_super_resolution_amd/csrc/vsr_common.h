@@ -56,6 +56,19 @@ inline void mark_device(unsigned long long& mask) { mask |= 1ull << current_devi
 
 }  // namespace vsr
 
+// Two libraries are built from these sources (Makefile): libvsr_hip.so -- the shipping kernels behind include/vsr_hip.h -- and
+// libvsr_hip_xcheck.so (-DVSR_BUILD_XCHECK: include/vsr_hip_xcheck.h on top), which ALSO holds the superseded builds kept as
+// bit-identity cross-checks (the first gather kernel, the two-waves-per-SIMD fused stage, the LDS-ring tail, the transposing 1x1,
+// the five-set ring, the LDS warp ...), the stamped diagnostic builds and the run-time switches that select them.  In the shipping
+// library the switches are compile-time constants at their defaults and the superseded kernels do not exist.
+#ifdef VSR_BUILD_XCHECK
+#define VSR_X 1
+#define VSR_TUNABLE static int
+#else
+#define VSR_X 0
+#define VSR_TUNABLE static constexpr int
+#endif
+
 #define VSR_REQUIRE(cond, ...) \
     do {                       \
         if (!(cond)) return vsr::fail(VSR_E_ARG, __VA_ARGS__); \

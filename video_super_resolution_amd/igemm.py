@@ -349,13 +349,8 @@ def resize_add(a, a_coff, c, out_hw, b=None, b_coff=0, up2=False, b_up2=False):
     N, Ha, Wa, a_ld = a.shape
     H, W = out_hw
     out = torch.empty((N, H, W, c), dtype=torch.float16, device=a.device)
-    if isinstance(a, SegMap) or isinstance(b, SegMap):
-        ap, al, ac, an = _seg_args(a, a_coff, c)
-        bp, bl, bc, bn = _seg_args(b, b_coff, c) if b is not None else (None, None, None, 0)
-        L.check(L.load().vsr_resize_add_segs_nhwc_f16(ap, al, ac, an, Ha, Wa, 1 if up2 else 0, bp, bl, bc, bn, 1 if b_up2 else 0,
-                                                      L.dptr(out, torch.float16), N, H, W, c, L.stream()), "resize_add_segs")
-        return out
-    L.check(L.load().vsr_up2_resize_add_nhwc_f16(L.dptr(a, torch.float16), a_ld, a_coff, Ha, Wa, 1 if up2 else 0, L.optr(b, torch.float16),
-                                                 b.shape[3] if b is not None else 0, b_coff, 1 if b_up2 else 0, L.dptr(out, torch.float16),
-                                                 N, H, W, c, L.stream()), "resize_add")
+    ap, al, ac, an = _seg_args(a, a_coff, c)
+    bp, bl, bc, bn = _seg_args(b, b_coff, c) if b is not None else (None, None, None, 0)
+    L.check(L.load().vsr_resize_add_segs_nhwc_f16(ap, al, ac, an, Ha, Wa, 1 if up2 else 0, bp, bl, bc, bn, 1 if b_up2 else 0,
+                                                  L.dptr(out, torch.float16), N, H, W, c, L.stream()), "resize_add_segs")
     return out

@@ -512,7 +512,7 @@ class SRProjectionModule(nn.Module):
         workgroups, 2 rounds of 186 rows).  `flat_ok` (k_utd3 only): a NEGATIVE result -c asks for the flat split -- c workgroups
         share the N x strips x h rows of the planes' strips laid end to end evenly, a share spanning the end of a strip as two
         marches -- when that beats the best whole-segment split (5 planes: 256 shares of 327 rows against 1.82 rounds)."""
-        strips = -(-w // (strip or L.load().vsr_sr_utd_strip_width()))
+        strips = -(-w // (strip or L.load().vsr_sr_query(L.Q_UTD_STRIP_WIDTH)))
         wgs = strips * N
         best, best_cost = 1, None
         for segs in range(1, max(1, min(-(-h // 8), 32)) + 1):
@@ -528,10 +528,11 @@ class SRProjectionModule(nn.Module):
         return -(-h // best)
 
     def _utd2(self, a, blob_v2, N, h, w):
-        """Fused up -> tran -> down stage, producer/consumer wave roles (experimental variant, see _forward_f16)."""
+        """Fused up -> tran -> down stage, producer/consumer wave roles (k_utd2: a superseded build kept as a cross-check; it lives
+        in the cross-check library, include/vsr_hip_xcheck.h)."""
         out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
         tok = L.TIMER.start("sr_utd2_f16")
-        L.check(L.load().vsr_sr_utd2_f16(L.dptr(a, torch.float16), L.dptr(blob_v2, torch.uint8), L.dptr(out, torch.float16), N, h, w,
+        L.check(L.load_xcheck().vsr_sr_utd2_f16(L.dptr(a, torch.float16), L.dptr(blob_v2, torch.uint8), L.dptr(out, torch.float16), N, h, w,
                                          self._rows_per_segment(N, h, w), int(self._pack["slopes_le_one"]), L.stream()),
                 "sr_utd2_f16")
         L.TIMER.stop(tok)
@@ -546,7 +547,8 @@ class SRProjectionModule(nn.Module):
             out = torch.empty((N, 4 * h, 4 * w, _NF) if deconv_only else (N, h, w, _NF), dtype=torch.float16, device=a.device)
         # (timer names carry the plane count when it is not the full 8: the roofline leg prices a launch by its planes)
         tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else ("sr_utd_f16" if N == 8 else f"sr_utd_f16_p{N}"))
-        L.check(L.load().vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
+        # (the deconv-only mode is served by the two-waves-per-SIMD build k_utd: cross-check library only)
+        L.check((L.load_xcheck() if deconv_only else L.load()).vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
                                         self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256), flat_ok=not deconv_only and getattr(self, "utd_flat_split", True)),
                                         int(deconv_only), int(self._pack["slopes_le_one"]),
                                         L.stream()), "sr_utd_f16")
@@ -679,7 +681,9 @@ class SRProjectionModule(nn.Module):
                                                   int(decimate), L.stream()), "sr_fc_planes_skip")
             L.TIMER.stop(tok)
             return out
-        # k_tail: two waves per SIMD, LDS ring, skip inside the tail (cross-check build; also serves the prefc tap)
+        # k_tail: two waves per SIMD, LDS ring, skip inside the tail (a superseded build in the cross-check library,
+        # include/vsr_hip_xcheck.h; it also serves the prefc tap of the tests)
+        lib = L.load_xcheck()
         tail = lib.vsr_sr_tail_dec_f16 if decimate else lib.vsr_sr_tail_f16
         L.check(tail(L.dptr(hid, torch.float16), L.dptr(P["utd_out"], torch.uint8), L.dptr(P["cv_frags"], torch.float16),
                      L.dptr(P["tail_par"]), L.dptr(x), L.dptr(prefc), N, h, w, self._rows_per_segment(N, h, w),
@@ -779,7 +783,7 @@ def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn
     HR column parity): deconv tap (dy, dx) is kernel element (r + 2 dy, c + 2 dx) of the ConvTranspose2d weight
     [32(in),32(out),6,6]; conv slot (k, s) is kernel element (r + 2 k, c + 2 s) of the Conv2d weight [32(out),32(in),6,6]."""
     dev = up_w.device
-    nbytes = int(L.load().vsr_sr_utd_s2_blob_bytes())
+    nbytes = int(L.load().vsr_sr_query(L.Q_UTD_S2_BLOB_BYTES))
     lane = torch.arange(64, device=dev)
     col_l, g = lane & 15, lane >> 4
     j8 = torch.arange(8, device=dev)
@@ -819,7 +823,7 @@ def pack_tail_s2_blob(out_w, out_b, out_a, cv_w, cv_b) -> torch.Tensor:
     fragment order, conv_out [3,32,3,3] as nine A fragments whose rows 0-2 are its output channels (k index in the
     accumulator-derived channel order of the ring), then b_out[32], b_cv[3] and the PReLU slope."""
     dev = out_w.device
-    nbytes = int(L.load().vsr_sr_tail_s2_blob_bytes())
+    nbytes = int(L.load().vsr_sr_query(L.Q_TAIL_S2_BLOB_BYTES))
     lane = torch.arange(64, device=dev)
     perm = _chunk_channel_order(dev)
     W = torch.arange(4, device=dev).view(4, 1, 1, 1, 1, 1)
@@ -868,7 +872,7 @@ class _FusedStageS2:
             n = min(nb, N - n0)
             tok = L.TIMER.start("sr_utd_s2_f16" if n == 8 else f"sr_utd_s2_f16_p{n}")
             # two workgroups share a CU (256 registers per wave): twice the slots of the x4 kernel per round
-            rows = self.rows_fn(n, h, w, cus=512, strip=int(L.load().vsr_sr_utd_s2_strip_width()))
+            rows = self.rows_fn(n, h, w, cus=512, strip=int(L.load().vsr_sr_query(L.Q_UTD_S2_STRIP_WIDTH)))
             L.check(L.load().vsr_sr_utd_s2_f16(L.dptr(a[n0:n0 + n], torch.float16), L.dptr(self.blob, torch.uint8),
                                                L.dptr(out[n0:n0 + n], torch.float16), n, h, w, rows, int(self.slopes_le_one), L.stream()),
                     "sr_utd_s2_f16")
@@ -939,7 +943,7 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a,
     their K index in the accumulator's channel order (vsr_sr_tail3_fold_f16).
     """
     dev = up_w.device
-    nbytes = int(L.load().vsr_sr_utd_blob_bytes())
+    nbytes = int(L.load().vsr_sr_query(L.Q_UTD_BLOB_BYTES))
     lane = torch.arange(64, device=dev)
     col_l, g = lane & 15, lane >> 4
     j8 = torch.arange(8, device=dev)

@@ -98,7 +98,8 @@ class ConvTranspose2dF32(nn.ConvTranspose2d):
 
     def forward(self, x, output_size=None):
         if (not _ok(x, self.weight) or output_size is not None or self.kernel_size != (4, 4) or self.stride != (2, 2) or self.padding != (1, 1) or
-                self.output_padding != (0, 0) or self.groups != 1 or self.dilation != (1, 1)):
+                self.output_padding != (0, 0) or self.groups != 1 or self.dilation != (1, 1) or
+                not _own_pays(x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.weight.shape[1], 1, 1)):   # (a phase: one launch of H x W pixels)
             return super().forward(x, output_size)
         pk = self.__dict__.setdefault("_vsr_pack", _Packed())
         w = self.weight.detach()
