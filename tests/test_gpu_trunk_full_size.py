@@ -58,7 +58,7 @@ def test_hourglass_exec_at_4x540x960(gpu_vsr):
     print(f"[hourglass 4x{H}x{W} fp16 executor vs fp32 master] max {err:.3e} of range")
     assert got.shape == ref.shape == (4, 1, H, W)
     assert err < 1e-2                          # measured 2.0e-3
-    for k in ("stem7_rows", "conv1x1_stream<4>", "patch_r8<11,1>", "patch_r8<7,1>", "patch_r8<3,1>"):
+    for k in ("hg_front", "conv1x1_stream<4>", "patch_r8<11,1>", "patch_r8<7,1>", "patch_r8<3,1>", "patch_pf<3,1>"):
         assert k in hist, (k, hist)            # the size-dependent kernels the small tests never reach
 
 
@@ -75,6 +75,7 @@ def test_flownet2_exec_at_2_pairs_512x960(gpu_vsr):
     assert got.shape == ref.shape == (2, 2, 512, W)
     assert mx < 2e-2 and mean < 2e-3           # measured 1.2e-3 / 1.4e-4 (smooth scene; the random-pixel golden case: 2.1e-2)
     assert "deconv4s2_patch" in hist and any(k.startswith("patch_r8<3") for k in hist), hist
+    assert sum(v for k, v in hist.items() if k.startswith("flow_head<")) == 21, hist   # the fused heads: 5 per sub-network + the fusion net's first
     assert any("splitk" in k for k in hist), hist
 
 
@@ -134,7 +135,7 @@ def test_trunks_at_1080x1920(gpu_vsr):
         ref = netg(fr[:1].permute(0, 3, 1, 2))
         e = _rel(got, ref)
         print(f"[hourglass 1x{H2}x{W2}] max {e:.3e} of range")
-        assert e < 1e-2 and "stem7_rows" in hist
+        assert e < 1e-2 and "hg_front" in hist
         del got, ref
         torch.cuda.empty_cache()
         # OSVOS, two frames
