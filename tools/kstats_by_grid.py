@@ -11,7 +11,12 @@ g = defaultdict(list)
 for r in rows:
     if flt and flt not in r["Kernel_Name"]:
         continue
-    g[(r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if "Grid_Size" in r:      # (--pmc counter_collection.csv)
+        grid, wg = int(r["Grid_Size"]), int(r["Workgroup_Size"])
+    else:                      # (--kernel-trace kernel_trace.csv: per-dimension columns)
+        grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+    g[(r["Kernel_Name"], grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = sum(sum(v) for v in g.values())
 print(f"total {tot / 1e6 / div:.2f} ms, {sum(len(v) for v in g.values()) / div:.0f} launches (per call); columns: kernel, grid threads, launches per call, ms per call, avg us, min us")
 for (name, grid, wg), v in sorted(g.items(), key=lambda kv: -sum(kv[1]))[:top]:

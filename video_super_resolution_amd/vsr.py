@@ -225,11 +225,19 @@ class VSR(nn.Module):
         if not data.is_cuda:
             raise RuntimeError("VSR runs on the GPU through hand-written HIP kernels; there is no CPU fallback "
                                "(move the module and its inputs to the device first)")
+        ev = self.stage_events = [] if getattr(self, "stage_timing", False) else None
+
+        def mark():   # (measurement hook, tools/frame_stages.py: events on the main stream at the four stage boundaries)
+            if ev is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append(e)
         with torch.no_grad():
             h, w = data.shape[1], data.shape[2]
             d = data.detach().to(torch.float32).contiguous()
             f0, f1, f2 = d[0], d[1], d[2]
             depth_cache = {}
+            mark()
 
             # ---- pass 1 (:26-41)
             if estimated_image is None:
@@ -263,6 +271,7 @@ class VSR(nn.Module):
             pics, z, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,), cacheable=True)
             if s_sr is not None:
                 torch.cuda.current_stream(d.device).wait_stream(s_sr)
+            mark()
             # pass 1's frame is only ever read through the nearest x1/4 resize of :44, i.e. at its pixels (4i,4j): the SR
             # stack evaluates its tail and fusion MLP at exactly those (identical values, 1/16 of the tail work)
             # planes 0-2 (the LR frames) are the same in both SR calls (:40, :62): their FeedbackBlock maps are computed here
@@ -270,12 +279,15 @@ class VSR(nn.Module):
             mid = self.model(self._assemble(d, pics, z, est), decimate=True, shared=shared)[0]  # [3,h,w] = F.interpolate(out1,(h,w))[0]
 
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
+            mark()
             mid_hw3 = mid.permute(1, 2, 0).contiguous()
             pics2, z2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3))
+            mark()
             x8 = self._assemble(d, pics2, z2, mid.contiguous(), mask.contiguous())   # plane 7: mid, zero where mask != 0 (:58-60)
         # ---- pass 2 SR (:62-64): the reference's only call outside no_grad.  Under the caller's no_grad or in eval mode it
         # runs the kernels; in training mode with autograd on it is differentiable (SRProjectionModule.forward)
         out = self.model(x8, shared=shared).permute(0, 2, 3, 1)
+        mark()
         with torch.no_grad():
             if high_frames is not None:
                 high_frames[1] = out.detach()  # :66
