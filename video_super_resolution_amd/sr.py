@@ -22,6 +22,7 @@ so `lr[j]` depends on the input only for j = 0 (mod 3).  All other `lr[j]` are f
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -123,7 +124,7 @@ class SRProjectionModule(nn.Module):
         # CUs the fused-stage launches of `precompute_shared` are split for: they run beside the guidance trunks and take a CU each
         # (tools/overlap_ab.py at 540x960, ms per frame on one box: serial 24.7 / 25.1; beside the trunks with 96 / 128 / 160 / 192 /
         # 256: 23.80 / 23.77-23.82 / 23.92-23.94 / 24.06 / 24.13)
-        self.precompute_cus = 128
+        self.precompute_cus = int(os.environ.get("VSR_PRECOMPUTE_CUS", "128"))
         self.utd_flat_split = True   # k_utd3: share the rows evenly among the CUs when whole row segments cannot (see _rows_per_segment)
         self._pack: Optional[dict] = None
         self._pack_key = None
