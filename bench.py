@@ -427,7 +427,8 @@ def main():
                 # gfx950 correction applied) -- a committed measurement of the same launch geometry, not taken in this run
                 # (file, planes of the profiled launch): the 5-plane flat-split launch has its own passes (round 3)
                 pmcs = {(540, 960, 4): (("r03_k_utd3_pmc.json", 5), ("r02_k_utd3_pmc.json", 8), ("r01_k_utd3_pmc.json", 8)),
-                        (1080, 1920, 2): (("r02_k_utd_s2_pmc.json", 8),)}
+                        (1080, 1920, 2): (("r02_k_utd_s2_pmc.json", 8),),
+                        (2160, 3840, 2): (("r04_c5_k_utd_s2_hbm_pmc.json", 5),)}
                 cands = sorted(pmcs.get((h, w, scale), ()), key=lambda fp: fp[1] != planes_dom)   # the launch's own geometry first
                 for pmc, pl in cands:
                     path = os.path.join(ROOT, "profiles", pmc)
@@ -477,8 +478,14 @@ def main():
             else:
                 flop = 8 * h * w * (STAGE_FLOP_PER_PX[scale] - 2048 * scale ** 2) / 2    # one k x k (de)conv, 8 planes
                 achieved = flop / (ms * 1e-3) / 1e12
+                traffic, traffic_source = None, None
+                pmc = os.path.join(ROOT, "profiles", "r04_c2_deconv_f32_hbm_pmc.json")
+                if name == "sr_deconv_f32" and (h, w, scale) == (540, 960, 2) and os.path.exists(pmc):
+                    with open(pmc) as f:
+                        traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"]
+                    traffic_source = "profiles/r04_c2_deconv_f32_hbm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate run of the 8-plane launch)"
                 roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(achieved / FP32_PEAK_TFLOPS, 4), traffic=None, traffic_source=None, launches_timed=launches,
+                            frac=round(achieved / FP32_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source, launches_timed=launches,
                             avg_ms=round(ms, 4), algorithmic_flop_per_launch=flop)
             # the whole frame against the same peak: FLOPs this implementation executes per forward / wall time per forward
             peak = FP16_MFMA_PEAK_TFLOPS if precision == "fp16" else FP32_PEAK_TFLOPS
