@@ -333,6 +333,16 @@ int vsr_conv2d_f32_pack(const float* weight, float* packed, int Co, int C, int k
 int vsr_conv2d_nchw_f32(const float* in, const float* w_packed, const float* bias, float* out, int N, int C, int H, int W, int Co, int Ho, int Wo,
                         int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off, int ox_mul, int ox_off,
                         vsr_stream_t stream);
+/* The same convolution with the layer's tail fused and a concat slice as destination (Conv2d -> eval-mode BatchNorm2d -> ReLU /
+ * LeakyReLU of the reference's trunks in one launch):
+ *   out[n][out_coff + co][y][x] = act(conv(in)[n][co][y][x] * scale[co] + shift[co]),  out [N, out_ctot, Ho, Wo], Ho = (H + 2 pad_y - kh) / stride + 1
+ * scale (null: 1) / shift (null: 0): the folded BatchNorm (gamma / sqrt(var + eps), beta + (bias - mean) * scale) or the plain bias;
+ * act 0: none, 1: v < 0 -> v * slope (slope 0 = ReLU).  route 0: choose; 1: the flat kernel (any stride); 2: the spatial-reuse
+ * kernels (stride 1: the input patch of a (16 or 8) x 32 pixel tile staged once for all taps; <= 16 out-channels on
+ * v_mfma_f32_16x16x4_f32), VSR_E_UNSUPPORTED where they cannot serve the layer. */
+int vsr_conv2d_act_nchw_f32(const float* in, const float* w_packed, const float* scale, const float* shift, int act, float slope, float* out,
+                            int out_ctot, int out_coff, int N, int C, int H, int W, int Co, int kh, int kw, int stride, int pad_y, int pad_x,
+                            int route, vsr_stream_t stream);
 
 /* The front of the depth hourglass in ONE launch (csrc/conv_hg_front.hip; reference pytorch_DIW_scratch.py:34-41 + the first
  * ChannelConcat of the outermost level): Conv2d(3,128,7,1,3)+BN+ReLU on in4 [N,H,W,4] fp16 (w1_packed / b1 as for

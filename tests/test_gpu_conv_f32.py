@@ -75,6 +75,76 @@ def test_conv_transpose_k4s2_f32_matches_float64(case, monkeypatch):
     assert err <= TOL, err
 
 
+@pytest.mark.parametrize("case", [  # (N, C, H, W, Co, kh, kw, pad_y, pad_x, ctot, coff, bn, slope)
+    (1, 64, 30, 50, 16, 11, 11, 5, 5, 16, 0, False, None),   # thin 11x11 (v_mfma_f32_16x16x4_f32)
+    (2, 32, 21, 70, 16, 7, 7, 3, 3, 48, 32, True, 0.0),      # thin, into a concat slice, BatchNorm + ReLU
+    (1, 64, 17, 33, 1, 3, 3, 1, 1, 1, 0, False, None),       # one out-channel
+    (1, 32, 20, 40, 32, 7, 7, 3, 3, 96, 32, True, 0.0),      # 32 out-channels: 16-row tiles
+    (2, 64, 19, 37, 64, 3, 3, 1, 1, 64, 0, False, 0.1),      # 64 out-channels, LeakyReLU
+    (1, 128, 18, 64, 128, 3, 3, 1, 1, 128, 0, False, 0.0),   # 128 out-channels, 8-channel chunks
+    (1, 64, 12, 40, 128, 5, 5, 2, 2, 128, 0, False, None),   # 128 out-channels, 4-channel chunks (weight block of a kernel row)
+    (1, 6, 10, 35, 64, 3, 3, 1, 1, 64, 0, False, None),      # 6 input channels (padded to 16: the zero chunks are skipped)
+    (1, 473, 8, 16, 256, 3, 3, 1, 1, 256, 0, False, 0.1),    # odd channel count, two 128-channel blocks
+    (1, 64, 16, 32, 64, 11, 11, 5, 5, 64, 0, True, 0.0),     # 11x11 x 64 out-channels: 4-channel chunks
+    (1, 24, 9, 31, 40, 3, 5, 1, 2, 40, 0, False, None),      # rectangular kernel, 40 out-channels (padded to 64)
+    (1, 32, 7, 20, 24, 3, 3, 0, 0, 24, 0, False, None),      # no padding: the output is smaller than the input
+])
+def test_conv2d_f32_spatial_kernels_match_float64(case):
+    """The spatial-reuse kernels (vsr_conv2d_act_nchw_f32, route 2) with the folded BatchNorm / activation / concat-slice epilogue
+    against Conv2d -> BatchNorm2d(eval) -> (Leaky)ReLU in float64; the flat kernel (route 1) through the same entry too."""
+    N, C, H, W, Co, kh, kw, py, px, ctot, coff, bn, slope = case
+    rs = np.random.RandomState(C + 7 * Co + kh)
+    x = torch.from_numpy(rs.randn(N, C, H, W).astype(np.float32))
+    w = torch.from_numpy((rs.randn(Co, C, kh, kw) / np.sqrt(C * kh * kw)).astype(np.float32))
+    b = torch.from_numpy(rs.randn(Co).astype(np.float32))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=(py, px))
+    scale = shift = None
+    if bn:
+        mean, var = torch.from_numpy(rs.randn(Co)).double() * 0.3, torch.from_numpy(rs.rand(Co) + 0.5).double()
+        gamma, beta = torch.from_numpy(rs.rand(Co) + 0.5).double(), torch.from_numpy(rs.randn(Co)).double()
+        ref = F.batch_norm(ref, mean, var, gamma, beta, False, 0.0, 1e-5)
+        sc = gamma / torch.sqrt(var + 1e-5)
+        scale, shift = sc.float().cuda(), (beta + (b.double() - mean) * sc).float().cuda()
+    else:
+        shift = b.cuda()
+    if slope is not None:
+        ref = F.leaky_relu(ref, slope)
+    wp = trunk_f32._pack(w.cuda().contiguous())
+    for route in (2, 1):
+        out = torch.full((N, ctot, ref.shape[2], ref.shape[3]), 7.0, dtype=torch.float32, device="cuda")
+        trunk_f32.conv2d_fused(x.cuda(), wp, scale, shift, slope is not None, slope or 0.0, Co, kh, kw, 1, py, px, route, out=out, coff=coff)
+        got = out[:, coff:coff + Co].cpu().double()
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= TOL, (route, err)
+        rest = torch.cat([out[:, :coff], out[:, coff + Co:]], 1)
+        assert (rest == 7.0).all(), "channels outside the slice were written"
+
+
+def test_fused_sequential_and_concat_match_the_separate_passes(monkeypatch):
+    """FusedSequential / depth.ChannelConcat (Conv2d -> BatchNorm2d -> ReLU in one launch, branches written into the concat buffer in
+    place) against the same modules evaluated child by child on the stock operators."""
+    from video_super_resolution_amd import depth
+    monkeypatch.setattr(trunk_f32, "MIN_TILES", 0)
+    monkeypatch.setattr(trunk_f32, "MIN_WGS", 0)
+    torch.manual_seed(3)
+    blk = depth._build(depth._J).cuda().eval()    # 128 -> 16 + 3 x (64 -> 16, k 3 / 7 / 11)
+    seq = depth._build(("S", [("conv", 3, 128, 7, 3), ("bn", 128, True), "relu", depth._J, ("conv", 64, 1, 3, 1)])).cuda().eval()
+    with torch.no_grad():
+        for m in list(blk.modules()) + list(seq.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+        x = torch.randn(2, 128, 37, 45, device="cuda")
+        img = torch.randn(1, 3, 40, 70, device="cuda")
+        got, got2 = blk(x), seq(img)
+        monkeypatch.setattr(trunk_f32, "FUSE", False)
+        monkeypatch.setattr(trunk_f32, "ENABLED", False)
+        ref, ref2 = blk(x), seq(img)
+    assert got.shape == ref.shape == (2, 64, 37, 45) and got2.shape == ref2.shape
+    assert (got - ref).abs().max().item() <= TOL * ref.abs().max().item()
+    assert (got2 - ref2).abs().max().item() <= 5 * TOL * ref2.abs().max().item()
+
+
 def test_trunks_in_float32_run_on_the_own_kernel(gpu_vsr):
     """The three master trunks on a CUDA float32 input: every nn.Conv2d (and FlowNet's k4 s2 transposed convolutions) is served by
     csrc/conv_f32_nchw.hip, and the results agree with the stock operators (trunk_f32.ENABLED = False) at the float32 bar."""

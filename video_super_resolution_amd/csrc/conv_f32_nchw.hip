@@ -13,6 +13,16 @@
 //   per step: weights [16][32 MT] and pixels [16][128] staged through LDS (double-buffered: the next step's global loads are in
 //   flight while this step is multiplied), 8 MT MFMAs per wave
 // Weights are packed once per parameter version as [tap][cin padded to 16][cout padded to 32] (zero rows / columns).
+//
+// k_conv_f32_sp / k_conv_f32_sp16 (stride-1 k x k layers, the bulk of the hourglass and of OSVOS): SPATIAL reuse.  The kernel above
+// re-reads the input once per tap (2 x 16 KB of L2 -> LDS per 32 MFMAs: 32 FLOP per byte, ~4.5 TB/s of L2 traffic at the MFMA
+// rate).  Here a workgroup owns (4 RW) rows x 32 columns of output pixels and stages, per chunk of KC input channels, the input
+// patch those pixels see ((4 RW + kh - 1) x (32 + kw - 1) x KC floats) ONCE for all kh x kw taps; the weights of one kernel row
+// ([kw][KC][out-channels]) follow through a second LDS block, the next row's already in registers while this one is multiplied.
+// A wave owns RW image rows of 32 pixels (one MFMA pixel tile each).  Layers with <= 16 out-channels (the hourglass's thin 7x7 /
+// 11x11 branches at full resolution) use v_mfma_f32_16x16x4_f32 (k_conv_f32_sp16): no padded rows.
+// Epilogue of all three kernels: out = act(acc * scale[co] + shift[co]) into channels [coff, coff + Co) of an [N, ctot, H, W] tensor --
+// an eval-mode BatchNorm folded to scale / shift, ReLU / LeakyReLU, and the concat buffer of an inception block written in place.
 #include "vsr_common.h"
 
 namespace {
@@ -25,10 +35,21 @@ constexpr int KC = 16, BN = 128;
 struct CF32 {
     const float* in;      // [N,C,H,W]
     const float* wp;      // [taps][cpad][co_pad]
-    const float* bias;    // [Co] or null
-    float* out;           // [N,Co,outH,outW]
-    int N, C, H, W, Co, Ho, Wo, kh, kw, stride, pad_y, pad_x, cpad, co_pad, outH, outW, oy_mul, oy_off, ox_mul, ox_off, segs;
+    const float* scale;   // [Co] or null (1)
+    const float* bias;    // [Co] or null (0): the shift
+    float* out;           // [N,ctot,outH,outW], channels [coff, coff + Co)
+    float slope;          // act != 0: v < 0 -> v * slope (0: ReLU)
+    int act, ctot, coff;
+    int N, C, H, W, Co, Ho, Wo, kh, kw, stride, pad_y, pad_x, cpad, co_pad, outH, outW, oy_mul, oy_off, ox_mul, ox_off;
+    int tiles_x, tiles_y, ps;   // spatial kernels: tile grid, LDS plane stride (floats)
 };
+
+__device__ __forceinline__ float epilogue(const CF32& p, float v, int co) {
+    if (p.scale) v *= p.scale[co];
+    if (p.bias) v += p.bias[co];
+    if (p.act) v = v >= 0.0f ? v : v * p.slope;
+    return v;
+}
 
 template <int MT>
 __global__ void __launch_bounds__(256) k_conv_f32(const CF32 p) {
@@ -109,14 +130,191 @@ __global__ void __launch_bounds__(256) k_conv_f32(const CF32 p) {
     if (mo >= M) return;
     const int on = (int)(mo / hw), orem = (int)(mo - (long long)on * hw);
     const int ooy = orem / p.Wo, oox = orem - ooy * p.Wo;
-    const size_t obase = ((size_t)on * p.Co) * p.outH * p.outW + (size_t)(ooy * p.oy_mul + p.oy_off) * p.outW + (size_t)oox * p.ox_mul + p.ox_off;
+    const size_t obase = ((size_t)on * p.ctot + p.coff) * p.outH * p.outW + (size_t)(ooy * p.oy_mul + p.oy_off) * p.outW + (size_t)oox * p.ox_mul + p.ox_off;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + 32 * mt + 8 * (r >> 2) + 4 * kh2 + (r & 3);
-            if (co < p.Co) p.out[obase + (size_t)co * p.outH * p.outW] = acc[mt][r] + (p.bias ? p.bias[co] : 0.0f);
+            if (co < p.Co) p.out[obase + (size_t)co * p.outH * p.outW] = epilogue(p, acc[mt][r], co);
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- spatial reuse
+// rows of the patch: wave w stages rows w, w + 4, ... (a row = PW <= 64 consecutive floats of one channel: one coalesced load);
+// eight rows' loads are in flight before the first store
+template <int KC>
+__device__ __forceinline__ void stage_patch_f32(const CF32& p, float* patch, int n, int c0, int y0, int x0, int PH, int PW, int wv, int lane) {
+    const int rows = KC * PH;
+    const int x = x0 - p.pad_x + lane;
+    const bool x_ok = lane < PW && (unsigned)x < (unsigned)p.W;
+    for (int rb = wv; rb < rows; rb += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = rb + 4 * u, c = row / PH, py = row - c * PH, y = y0 - p.pad_y + py;
+            const bool ok = row < rows && x_ok && c0 + c < p.C && (unsigned)y < (unsigned)p.H;
+            v[u] = ok ? p.in[(((size_t)n * p.C + c0 + c) * p.H + y) * p.W + x] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = rb + 4 * u, c = row / PH, py = row - c * PH;
+            if (row < rows && lane < PW) patch[c * p.ps + py * PW + lane] = v[u];
+        }
+    }
+}
+
+template <int MT, int RW, int KC>
+__global__ void __launch_bounds__(256, 2) k_conv_f32_sp(const CF32 p) {
+    constexpr int BM = 32 * MT, TH = 4 * RW, TW = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem_sp[];
+    const int PH = TH + p.kh - 1, PW = TW + p.kw - 1;
+    float* const patch = smem_sp;                            // [KC][ps]
+    float* const ws = smem_sp + ((KC * p.ps + 3) & ~3);      // [kw][KC][BM]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 31, kh2 = lane >> 5;
+    const int tx = blockIdx.x % p.tiles_x, t2 = blockIdx.x / p.tiles_x, ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH, co0 = blockIdx.y * BM;
+    const int np = p.kw * KC * (BM / 4);                     // float4 pieces of one kernel row's weight block (<= 1024)
+    f4v wreg[4];
+    auto wload = [&](int c0, int ky) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int q = tid + 256 * a;
+            if (q < np) {
+                const int row = q / (BM / 4), c4 = q % (BM / 4), kx = row / KC, c = row % KC;
+                wreg[a] = *reinterpret_cast<const f4v*>(p.wp + ((size_t)(ky * p.kw + kx) * p.cpad + c0 + c) * p.co_pad + co0 + 4 * c4);
+            }
+        }
+    };
+    auto wstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int q = tid + 256 * a;
+            if (q < np) *reinterpret_cast<f4v*>(ws + 4 * q) = wreg[a];   // piece q = row q / (BM/4), float4 q % (BM/4): ws[row * BM + ..]
+        }
+    };
+    f16v acc[RW][MT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][mt][e] = 0.0f;
+    wload(0, 0);
+    for (int c0 = 0; c0 < p.cpad; c0 += KC) {
+        if (c0 >= p.C) break;   // (cpad pads to 16: whole chunks of zero channels)
+        for (int ky = 0; ky < p.kh; ++ky) {
+            __syncthreads();   // every wave is done with the weight block (and, at ky = 0, with the patch)
+            if (ky == 0) stage_patch_f32<KC>(p, patch, n, c0, y0, x0, PH, PW, wv, lane);
+            wstore();
+            __syncthreads();
+            if (ky + 1 < p.kh) wload(c0, ky + 1);
+            else if (c0 + KC < p.cpad) wload(c0 + KC, 0);
+            const float* prow = patch + kh2 * p.ps + (wv * RW + ky) * PW + col;
+            const float* wrow = ws + kh2 * BM + col;
+            for (int kx = 0; kx < p.kw; ++kx) {
+#pragma unroll
+                for (int kp = 0; kp < KC / 2; ++kp) {
+                    float a[MT], b[RW];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = wrow[(kx * KC + 2 * kp) * BM + 32 * mt];
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) b[r] = prow[2 * kp * p.ps + r * PW + kx];
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[r], acc[r][mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int x = x0 + col;
+    if (x >= p.Wo) return;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int y = y0 + wv * RW + r;
+        if (y >= p.Ho) continue;
+        const size_t obase = (((size_t)n * p.ctot + p.coff) * p.Ho + y) * p.Wo + x;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + 32 * mt + 8 * (e >> 2) + 4 * kh2 + (e & 3);
+                if (co < p.Co) p.out[obase + (size_t)co * p.Ho * p.Wo] = epilogue(p, acc[r][mt][e], co);
+            }
+    }
+}
+
+// <= 16 out-channels: v_mfma_f32_16x16x4_f32 (A[i][k]: lane 16 k + i, B[k][j]: lane 16 k + j, D[i][j]: lane 16 (i / 4) + j, register
+// i % 4), a chunk = the 4 input channels of one MFMA, a wave owns RW rows x two 16-pixel tiles.  The plane stride p.ps is 16 mod 32
+// floats, so that the 32 lanes of one LDS pass (two channels x 16 pixels) fall on 32 different banks.
+template <int RW>
+__global__ void __launch_bounds__(256) k_conv_f32_sp16(const CF32 p) {
+    constexpr int TH = 4 * RW, TW = 32, KC = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem_sp[];
+    const int PH = TH + p.kh - 1, PW = TW + p.kw - 1;
+    float* const patch = smem_sp;                            // [4][ps]
+    float* const ws = smem_sp + ((KC * p.ps + 3) & ~3);      // [kw][4][16]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int tx = blockIdx.x % p.tiles_x, t2 = blockIdx.x / p.tiles_x, ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int np = p.kw * 16;                                // float4 pieces of one kernel row's weight block (<= 256)
+    f4v wreg = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto wload = [&](int c0, int ky) __attribute__((always_inline)) {
+        if (tid < np) {
+            const int row = tid >> 2, c4 = tid & 3, kx = row >> 2, c = row & 3;
+            wreg = *reinterpret_cast<const f4v*>(p.wp + ((size_t)(ky * p.kw + kx) * p.cpad + c0 + c) * p.co_pad + 4 * c4);
+        }
+    };
+    f4v acc[RW][2];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[r][h] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    wload(0, 0);
+    for (int c0 = 0; c0 < p.cpad; c0 += KC) {
+        if (c0 >= p.C) break;   // (cpad pads to 16: whole chunks of zero channels)
+        for (int ky = 0; ky < p.kh; ++ky) {
+            __syncthreads();
+            if (ky == 0) stage_patch_f32<KC>(p, patch, n, c0, y0, x0, PH, PW, wv, lane);
+            if (tid < np) *reinterpret_cast<f4v*>(ws + 4 * tid) = wreg;
+            __syncthreads();
+            if (ky + 1 < p.kh) wload(c0, ky + 1);
+            else if (c0 + KC < p.cpad) wload(c0 + KC, 0);
+            const float* prow = patch + kq * p.ps + (wv * RW + ky) * PW + col;
+            const float* wrow = ws + kq * 16 + col;
+#pragma unroll 2
+            for (int kx = 0; kx < p.kw; ++kx) {
+                const float a = wrow[kx * 64];
+                float b[RW][2];
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) b[r][h] = prow[r * PW + 16 * h + kx];
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[r][h], acc[r][h], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int y = y0 + wv * RW + r;
+        if (y >= p.Ho) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int x = x0 + 16 * h + col;
+            if (x >= p.Wo) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = 4 * kq + e;
+                if (co < p.Co) p.out[(((size_t)n * p.ctot + p.coff + co) * p.Ho + y) * p.Wo + x] = epilogue(p, acc[r][h][e], co);
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -142,6 +340,50 @@ int vsr_conv2d_f32_pack(const float* weight, float* packed, int Co, int C, int k
     return vsr::launched("conv2d_f32_pack");
 }
 
+// route: 0 = choose, 1 = the flat kernel (any stride; pixel blocks of 128, input re-read per tap), 2 = the spatial-reuse kernels
+// (stride 1 only).  Returns VSR_E_UNSUPPORTED when route 2 cannot serve the layer.
+static int launch_conv_f32(CF32& p, int route, hipStream_t st) {
+    const bool plain_out = p.oy_mul == 1 && p.ox_mul == 1 && p.oy_off == 0 && p.ox_off == 0 && p.outH == p.Ho && p.outW == p.Wo;
+    const bool sp_legal = p.stride == 1 && plain_out && p.kw <= 33;
+    if (route == 2 && !sp_legal) return vsr::fail(VSR_E_UNSUPPORTED, "conv2d_nchw_f32: the spatial-reuse kernel serves stride 1 into a plain output only");
+    if (route != 1 && sp_legal && (route == 2 || p.kh * p.kw >= 9)) {
+        const bool thin = p.Co <= 16;
+        const int MT = thin ? 0 : (p.co_pad & 127) == 0 ? 4 : (p.co_pad & 63) == 0 ? 2 : 1;
+        const int BM = thin ? 16 : 32 * MT, RW = (thin || MT == 1) ? 4 : 2, TH = 4 * RW;
+        const int PH = TH + p.kh - 1, PW = 32 + p.kw - 1;
+        p.ps = PH * PW;
+        if (thin) p.ps += (16 - (p.ps & 31) + 32) & 31;   // = 16 mod 32
+        int KC = thin ? 4 : 8;
+        auto lds_of = [&](int kc) { return (size_t)(((kc * p.ps + 3) & ~3) + p.kw * kc * BM) * 4; };
+        if (!thin && (p.kw * KC * BM > 4096 || lds_of(KC) > 64 * 1024)) KC = 4;
+        const bool fits = p.kw * KC * BM <= 4096 && lds_of(KC) <= 64 * 1024;
+        if (fits) {
+            p.tiles_x = (p.Wo + 31) / 32;
+            p.tiles_y = (p.Ho + TH - 1) / TH;
+            const long long gx = (long long)p.N * p.tiles_x * p.tiles_y;
+            if (gx >= (1ll << 31)) return vsr::fail(VSR_E_ARG, "conv2d_nchw_f32: too many tiles");
+            const dim3 grid((unsigned)gx, thin ? 1 : p.co_pad / BM);
+            const size_t lds = lds_of(KC);
+            if (thin) hipLaunchKernelGGL(k_conv_f32_sp16<4>, grid, dim3(256), lds, st, p);
+            else if (MT == 4 && KC == 8) hipLaunchKernelGGL((k_conv_f32_sp<4, 2, 8>), grid, dim3(256), lds, st, p);
+            else if (MT == 4) hipLaunchKernelGGL((k_conv_f32_sp<4, 2, 4>), grid, dim3(256), lds, st, p);
+            else if (MT == 2 && KC == 8) hipLaunchKernelGGL((k_conv_f32_sp<2, 2, 8>), grid, dim3(256), lds, st, p);
+            else if (MT == 2) hipLaunchKernelGGL((k_conv_f32_sp<2, 2, 4>), grid, dim3(256), lds, st, p);
+            else if (KC == 8) hipLaunchKernelGGL((k_conv_f32_sp<1, 4, 8>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((k_conv_f32_sp<1, 4, 4>), grid, dim3(256), lds, st, p);
+            return vsr::launched("conv2d_nchw_f32 (spatial)");
+        }
+        if (route == 2) return vsr::fail(VSR_E_UNSUPPORTED, "conv2d_nchw_f32: kernel row of %d taps x %d out-channels exceeds the spatial kernel's weight block", p.kw, BM);
+    }
+    const long long gx = ((long long)p.N * p.Ho * p.Wo + BN - 1) / BN;
+    VSR_REQUIRE(gx < (1ll << 31) && (long long)p.Ho * p.Wo < (1ll << 31), "conv2d_nchw_f32: too many pixel blocks");
+    // widest out-channel block the padded count fills
+    if ((p.co_pad & 127) == 0) hipLaunchKernelGGL(k_conv_f32<4>, dim3((unsigned)gx, p.co_pad / 128), dim3(256), 0, st, p);
+    else if ((p.co_pad & 63) == 0) hipLaunchKernelGGL(k_conv_f32<2>, dim3((unsigned)gx, p.co_pad / 64), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_conv_f32<1>, dim3((unsigned)gx, p.co_pad / 32), dim3(256), 0, st, p);
+    return vsr::launched("conv2d_nchw_f32");
+}
+
 int vsr_conv2d_nchw_f32(const float* in, const float* w_packed, const float* bias, float* out, int N, int C, int H, int W, int Co, int Ho, int Wo,
                         int kh, int kw, int stride, int pad_y, int pad_x, int outH, int outW, int oy_mul, int oy_off, int ox_mul, int ox_off,
                         vsr_stream_t stream) {
@@ -149,20 +391,30 @@ int vsr_conv2d_nchw_f32(const float* in, const float* w_packed, const float* bia
     VSR_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Co > 0 && Ho > 0 && Wo > 0 && kh > 0 && kw > 0 && stride > 0, "conv2d_nchw_f32: bad shape");
     VSR_REQUIRE((Ho - 1) * oy_mul + oy_off < outH && (Wo - 1) * ox_mul + ox_off < outW && oy_off >= 0 && ox_off >= 0 && oy_mul > 0 && ox_mul > 0,
                 "conv2d_nchw_f32: output window exceeds the destination tensor");
-    CF32 p;
+    CF32 p = {};
     p.in = in; p.wp = w_packed; p.bias = bias; p.out = out;
+    p.ctot = Co;
     p.N = N; p.C = C; p.H = H; p.W = W; p.Co = Co; p.Ho = Ho; p.Wo = Wo; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
     p.cpad = (C + 15) / 16 * 16; p.co_pad = (Co + 31) / 32 * 32;
     p.outH = outH; p.outW = outW; p.oy_mul = oy_mul; p.oy_off = oy_off; p.ox_mul = ox_mul; p.ox_off = ox_off;
-    p.segs = 0;
-    const long long gx = ((long long)N * Ho * Wo + BN - 1) / BN;
-    VSR_REQUIRE(gx < (1ll << 31) && (long long)Ho * Wo < (1ll << 31), "conv2d_nchw_f32: too many pixel blocks");
-    hipStream_t st = vsr::S(stream);
-    // widest out-channel block the padded count fills
-    if ((p.co_pad & 127) == 0) hipLaunchKernelGGL(k_conv_f32<4>, dim3((unsigned)gx, p.co_pad / 128), dim3(256), 0, st, p);
-    else if ((p.co_pad & 63) == 0) hipLaunchKernelGGL(k_conv_f32<2>, dim3((unsigned)gx, p.co_pad / 64), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(k_conv_f32<1>, dim3((unsigned)gx, p.co_pad / 32), dim3(256), 0, st, p);
-    return vsr::launched("conv2d_nchw_f32");
+    return launch_conv_f32(p, 1, vsr::S(stream));
+}
+
+int vsr_conv2d_act_nchw_f32(const float* in, const float* w_packed, const float* scale, const float* shift, int act, float slope, float* out,
+                            int out_ctot, int out_coff, int N, int C, int H, int W, int Co, int kh, int kw, int stride, int pad_y, int pad_x,
+                            int route, vsr_stream_t stream) {
+    VSR_REQUIRE(in && w_packed && out, "conv2d_act_nchw_f32: null pointer");
+    VSR_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && pad_y >= 0 && pad_x >= 0, "conv2d_act_nchw_f32: bad shape");
+    VSR_REQUIRE(H + 2 * pad_y >= kh && W + 2 * pad_x >= kw, "conv2d_act_nchw_f32: kernel larger than the padded input");
+    VSR_REQUIRE(out_coff >= 0 && out_coff + Co <= out_ctot && route >= 0 && route <= 2, "conv2d_act_nchw_f32: bad channel slice / route");
+    CF32 p = {};
+    p.in = in; p.wp = w_packed; p.scale = scale; p.bias = shift; p.out = out;
+    p.act = act ? 1 : 0; p.slope = slope; p.ctot = out_ctot; p.coff = out_coff;
+    p.N = N; p.C = C; p.H = H; p.W = W; p.Co = Co; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.Ho = (H + 2 * pad_y - kh) / stride + 1; p.Wo = (W + 2 * pad_x - kw) / stride + 1;
+    p.cpad = (C + 15) / 16 * 16; p.co_pad = (Co + 31) / 32 * 32;
+    p.outH = p.Ho; p.outW = p.Wo; p.oy_mul = 1; p.ox_mul = 1;
+    return launch_conv_f32(p, route, vsr::S(stream));
 }
 
 }  // extern "C"

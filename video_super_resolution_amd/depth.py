@@ -11,7 +11,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .trunk_f32 import Conv2dF32
+from . import trunk_f32
+from .trunk_f32 import Conv2dF32, FusedSequential
 
 # ("I", cin, o0, (mid,k,out) x3): inception block = concat of a 1x1 branch and three 1x1 -> kxk branches,
 # every conv followed by BatchNorm(affine=False) + ReLU (pytorch_DIW_scratch.py:42-72 is one instance).
@@ -39,6 +40,17 @@ class FanOut(nn.Sequential):
 
 class ChannelConcat(nn.Sequential):
     def forward(self, x):
+        # float32 on the GPU, outside autograd: every branch's last Conv2d -> BatchNorm2d -> ReLU launch writes its channels of
+        # the concatenation in place (trunk_f32.FusedSequential); the branches are stride-1 "same" convolutions
+        if (trunk_f32.FUSE and trunk_f32.ENABLED and x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad) and
+                all(isinstance(m, FusedSequential) for m in self)):
+            widths = [[c for c in m if isinstance(c, nn.Conv2d)][-1].out_channels for m in self]
+            out = torch.empty((x.shape[0], sum(widths), x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
+            off = 0
+            for m, wd in zip(self, widths):
+                m(x, into=(out, off))
+                off += wd
+            return out
         return torch.cat([m(x) for m in self], 1)
 
 
@@ -69,13 +81,13 @@ def _build(node) -> nn.Module:
     if tag == "bn":
         return nn.BatchNorm2d(node[1]) if node[2] else nn.BatchNorm2d(node[1], 1e-05, 0.1, False)
     if tag == "S":
-        return nn.Sequential(*[_build(c) for c in node[1]])
+        return FusedSequential(*[_build(c) for c in node[1]])
     if tag == "M":
         return FanOut(*[_build(c) for c in node[1]])
     if tag == "I":
         _, cin, o0, *rest = node
-        return ChannelConcat(nn.Sequential(*_cbr(cin, o0, 1)),
-                             *[nn.Sequential(*(_cbr(cin, mid, 1) + _cbr(mid, out, k))) for (mid, k, out) in rest])
+        return ChannelConcat(FusedSequential(*_cbr(cin, o0, 1)),
+                             *[FusedSequential(*(_cbr(cin, mid, 1) + _cbr(mid, out, k))) for (mid, k, out) in rest])
     raise ValueError(node)
 
 

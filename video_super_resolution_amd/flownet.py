@@ -13,13 +13,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .trunk_f32 import Conv2dF32, ConvTranspose2dF32
+from .trunk_f32 import Conv2dF32, ConvTranspose2dF32, FusedSequential
 
 
 def conv(in_planes, out_planes, kernel_size=3, stride=1):
     """Conv2d(pad=(k-1)//2, bias) + LeakyReLU(0.1); batchNorm is False everywhere on this path (models.py:28)."""
-    return nn.Sequential(Conv2dF32(in_planes, out_planes, kernel_size, stride, (kernel_size - 1) // 2, bias=True),
-                         nn.LeakyReLU(0.1, inplace=True))
+    return FusedSequential(Conv2dF32(in_planes, out_planes, kernel_size, stride, (kernel_size - 1) // 2, bias=True),
+                           nn.LeakyReLU(0.1, inplace=True))
 
 
 def i_conv(in_planes, out_planes):

@@ -58,37 +58,153 @@ def conv2d_packed(x, wp, bias, co, kh, kw, stride, pad_y, pad_x, out=None, out_h
 
 
 ROUTE = os.environ.get("VSR_TRUNK_F32_ROUTE", "1") != "0"   # True: the layers the stock operator runs faster stay on it (below)
+SPATIAL = os.environ.get("VSR_TRUNK_F32_SPATIAL", "1") != "0"   # False: no spatial-reuse kernels (the round-4 flat kernel everywhere; A/B)
+FUSE = os.environ.get("VSR_TRUNK_F32_FUSE", "1") != "0"     # False: BatchNorm / ReLU / LeakyReLU / concat as separate stock passes (A/B; tests)
+
+STOCK, FLAT, SPATIAL_K = 0, 1, 2
+MIN_TILES, MIN_WGS = 256, 192   # launches smaller than these stay off the spatial / the flat kernel (tests set them to 0)
+
+
+def _route(N, C, H, W, Co, kh, kw, stride, pad_y, pad_x) -> int:
+    """Which implementation serves a layer -- per-layer device times at the C2 size (tools/conv_f32_ab.py,
+    profiles/r04_conv_f32_ab.txt, profiles/r04_conv_f32_spatial_ab.txt):
+      * stride-1 k x k layers with <= 16 out-channels (k >= 3; v_mfma_f32_16x16x4_f32, no padded rows) or 32 out-channels (k >= 5) and
+        enough tiles to fill the chip: the spatial-reuse kernels;
+      * otherwise the flat kernel, except (a) launches of a few dozen workgroups (FlowNet's 1/32 and 1/64-resolution layers: no
+        split-K; 8 x 15 x 1024 -> 1024: 0.95 vs 0.19 ms), (b) RGB stems (3 input channels padded to a 16-channel K step), (c) k x k
+        layers with <= 16 out-channels (half of each 32-row MFMA tile is padding): the stock operator."""
+    if not ROUTE:
+        return FLAT
+    Ho, Wo = (H + 2 * pad_y - kh) // stride + 1, (W + 2 * pad_x - kw) // stride + 1
+    co_pad = (Co + 31) // 32 * 32
+    bm = 128 if co_pad % 128 == 0 else (64 if co_pad % 64 == 0 else 32)
+    # spatial-reuse kernels: <= 16 out-channels from 3x3 up (112 vs 41 flat / 50 stock TFLOP/s on 4 x 540 x 960 64 -> 16 11x11), 32
+    # out-channels from 5x5 up (83-111 vs 76-79 / 50-98); with 64+ out-channels the flat kernel's 128-pixel blocks win (61 vs 94)
+    if SPATIAL and stride == 1 and kh * kw >= 9 and kw <= 33 and C > 4 and (Co <= 16 or (co_pad == 32 and kh * kw >= 25) or MIN_TILES == 0):
+        thin = Co <= 16
+        th = 16 if (thin or bm == 32) else 8
+        tiles = N * -(-Ho // th) * -(-Wo // 32) * (1 if thin else co_pad // bm)
+        if tiles >= MIN_TILES and kw * 4 * (16 if thin else bm) <= 4096:
+            return SPATIAL_K
+    wgs = -(-(N * Ho * Wo) // 128) * (co_pad // bm)
+    if wgs < MIN_WGS or C <= 4:
+        return STOCK
+    if Co <= 16 and kh * kw >= 9:
+        return STOCK
+    return FLAT
 
 
 def _own_pays(N, C, H, W, Co, k, stride) -> bool:
-    """Where the own kernel beats the stock operator -- per-layer device times of both at the C2 size, tools/conv_f32_ab.py,
-    profiles/r04_conv_f32_ab.txt: NOT on (a) launches of a few dozen workgroups (FlowNet's 1/32 and 1/64-resolution layers: the
-    kernel has no split-K; 8 x 15 x 1024 -> 1024: 0.95 vs 0.19 ms), (b) RGB stems (3 input channels padded to a 16-channel K step),
-    (c) k x k layers with <= 16 out-channels (half of each 32-row MFMA tile is padding)."""
-    if not ROUTE:
-        return True
-    Ho, Wo = (H + 2 * ((k - 1) // 2) - k) // stride + 1, (W + 2 * ((k - 1) // 2) - k) // stride + 1
-    co_pad = (Co + 31) // 32 * 32
-    bm = 128 if co_pad % 128 == 0 else (64 if co_pad % 64 == 0 else 32)
-    wgs = -(-(N * Ho * Wo) // 128) * (co_pad // bm)
-    if wgs < 192 or C <= 4:
-        return False
-    if Co <= 16 and k >= 3:
-        return False
-    return True
+    return _route(N, C, H, W, Co, k, k, stride, (k - 1) // 2, (k - 1) // 2) != STOCK
+
+
+def conv2d_fused(x, wp, scale, shift, act, slope, co, kh, kw, stride, pad_y, pad_x, route, out=None, coff=0):
+    """One launch: act(conv(x) * scale + shift) into channels [coff, coff + co) of `out` (allocated [N,co,Ho,Wo] when None)."""
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 * pad_y - kh) // stride + 1, (W + 2 * pad_x - kw) // stride + 1
+    if out is None:
+        out = torch.empty((N, co, Ho, Wo), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.shape[0] == N and out.shape[2:] == (Ho, Wo), (out.shape, (N, co, Ho, Wo))
+    L.check(L.load().vsr_conv2d_act_nchw_f32(L.dptr(x), L.dptr(wp), L.optr(scale), L.optr(shift), int(act), L.cf(slope), L.dptr(out), out.shape[1], coff,
+                                             N, C, H, W, co, kh, kw, stride, pad_y, pad_x, route, L.stream()), "conv2d_act_nchw_f32")
+    return out
+
+
+def _conv_plain(conv) -> bool:
+    return (isinstance(conv, Conv2dF32) and conv.groups == 1 and conv.dilation == (1, 1) and conv.padding_mode == "zeros" and
+            not isinstance(conv.padding, str) and conv.stride[0] == conv.stride[1])
+
+
+def _conv_route(conv, x) -> int:
+    if not _ok(x, conv.weight) or not _conv_plain(conv):
+        return STOCK
+    return _route(x.shape[0], x.shape[1], x.shape[2], x.shape[3], conv.weight.shape[0], conv.weight.shape[2], conv.weight.shape[3], conv.stride[0],
+                  conv.padding[0], conv.padding[1])
+
+
+class _Folded:
+    """scale / shift of Conv2d bias + eval-mode BatchNorm2d, rebuilt when any of the tensors involved changes."""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, conv, bn):
+        ts = [conv.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias]
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+        if key != self.key:
+            with torch.no_grad():
+                scale = torch.rsqrt(bn.running_var.float() + bn.eps)
+                if bn.weight is not None:
+                    scale = scale * bn.weight.float()
+                shift = -bn.running_mean.float() * scale
+                if bn.bias is not None:
+                    shift = shift + bn.bias.float()
+                if conv.bias is not None:
+                    shift = shift + conv.bias.float() * scale
+                self.val, self.key = (scale.contiguous(), shift.contiguous()), key
+        return self.val
+
+
+def run_conv_group(conv, bn, act, x, out=None, coff=0):
+    """Conv2dF32 [-> BatchNorm2d (eval)] [-> ReLU / LeakyReLU] in one launch; None when the layer is not served by the own kernels."""
+    route = _conv_route(conv, x)
+    if route == STOCK:
+        return None
+    if bn is not None and (bn.training or bn.running_mean is None):
+        return None
+    pk = conv.__dict__.setdefault("_vsr_pack", _Packed())
+    with torch.cuda.device(x.device):
+        wp = pk.get(conv.weight, lambda: _pack(conv.weight.detach().contiguous()))
+        if bn is not None:
+            scale, shift = conv.__dict__.setdefault("_vsr_fold", _Folded()).get(conv, bn)
+        else:
+            scale, shift = None, (None if conv.bias is None else conv.bias.detach())
+        slope = 0.0 if act is None or isinstance(act, nn.ReLU) else float(act.negative_slope)
+        co, _, kh, kw = conv.weight.shape
+        return conv2d_fused(x, wp, scale, shift, act is not None, slope, co, kh, kw, conv.stride[0], conv.padding[0], conv.padding[1], route, out=out, coff=coff)
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential (same children, same state_dict keys, same results) whose forward runs every Conv2dF32 -> [BatchNorm2d] ->
+    [ReLU | LeakyReLU] run of children as ONE launch of the float32 convolution (folded BatchNorm, activation in the epilogue)
+    for a float32 CUDA tensor outside autograd; everything else child by child.  `into` = (tensor [N, ctot, H, W], coff): the last
+    child group writes its channels there (the concat buffer of an inception block) instead of into a tensor of its own."""
+
+    def forward(self, x, into=None):
+        mods = list(self)
+        i, n = 0, len(mods)
+        fast = FUSE and ENABLED and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
+        while i < n:
+            m = mods[i]
+            if fast and isinstance(m, Conv2dF32):
+                j = i + 1
+                bn = mods[j] if j < n and isinstance(mods[j], nn.BatchNorm2d) else None
+                j += bn is not None
+                act = mods[j] if j < n and isinstance(mods[j], (nn.ReLU, nn.LeakyReLU)) else None
+                j += act is not None
+                last = j == n and into is not None
+                y = run_conv_group(m, bn, act, x, out=into[0] if last else None, coff=into[1] if last else 0)
+                if y is not None:
+                    if last:
+                        return None   # written in place
+                    x, i = y, j
+                    continue
+            x = m(x)
+            i += 1
+        if into is not None:
+            into[0][:, into[1]:into[1] + x.shape[1]].copy_(x)
+            return None
+        return x
 
 
 class Conv2dF32(nn.Conv2d):
     def _conv_forward(self, x, weight, bias):
-        if (not _ok(x, weight) or self.groups != 1 or self.dilation != (1, 1) or self.padding_mode != "zeros" or isinstance(self.padding, str) or
-                self.stride[0] != self.stride[1] or
-                not _own_pays(x.shape[0], x.shape[1], x.shape[2], x.shape[3], weight.shape[0], weight.shape[2], self.stride[0])):
-            return super()._conv_forward(x, weight, bias)
-        pk = self.__dict__.setdefault("_vsr_pack", _Packed())
-        with torch.cuda.device(x.device):
-            wp = pk.get(weight, lambda: _pack(weight.detach().contiguous()))
-            co, _, kh, kw = weight.shape
-            return conv2d_packed(x, wp, None if bias is None else bias.detach(), co, kh, kw, self.stride[0], self.padding[0], self.padding[1])
+        if weight is self.weight and bias is self.bias:
+            y = run_conv_group(self, None, None, x)
+            if y is not None:
+                return y
+        return super()._conv_forward(x, weight, bias)
 
 
 class ConvTranspose2dF32(nn.ConvTranspose2d):

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .trunk_f32 import Conv2dF32
+from .trunk_f32 import Conv2dF32, FusedSequential
 
 _STAGES = [[64, 64], ["M", 128, 128], ["M", 256, 256, 256], ["M", 512, 512, 512], ["M", 512, 512, 512]]
 _STAGE_IN = [3, 64, 128, 256, 512]
@@ -25,7 +25,7 @@ def _stage(cfg, cin):
         else:
             layers += [Conv2dF32(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
             cin = v
-    return nn.Sequential(*layers)
+    return FusedSequential(*layers)
 
 
 def _center_crop(x, hh, ww):
