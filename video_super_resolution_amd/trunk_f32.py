@@ -62,7 +62,7 @@ SPATIAL = os.environ.get("VSR_TRUNK_F32_SPATIAL", "1") != "0"   # False: no spat
 FUSE = os.environ.get("VSR_TRUNK_F32_FUSE", "1") != "0"     # False: BatchNorm / ReLU / LeakyReLU / concat as separate stock passes (A/B; tests)
 
 STOCK, FLAT, SPATIAL_K = 0, 1, 2
-MIN_TILES, MIN_WGS = 256, 192   # launches smaller than these stay off the spatial / the flat kernel (tests set them to 0)
+MIN_TILES, MIN_WGS = 120, 192   # launches smaller than these stay off the spatial / the flat kernel (tests set them to 0)
 
 
 def _route(N, C, H, W, Co, kh, kw, stride, pad_y, pad_x) -> int:
@@ -79,13 +79,17 @@ def _route(N, C, H, W, Co, kh, kw, stride, pad_y, pad_x) -> int:
     co_pad = (Co + 31) // 32 * 32
     bm = 128 if co_pad % 128 == 0 else (64 if co_pad % 64 == 0 else 32)
     # spatial-reuse kernels: <= 16 out-channels from 3x3 up (112 vs 41 flat / 50 stock TFLOP/s on 4 x 540 x 960 64 -> 16 11x11), 32
-    # out-channels from 5x5 up (83-111 vs 76-79 / 50-98); with 64+ out-channels the flat kernel's 128-pixel blocks win (61 vs 94)
-    if SPATIAL and stride == 1 and kh * kw >= 9 and kw <= 33 and C > 4 and (Co <= 16 or (co_pad == 32 and kh * kw >= 25) or MIN_TILES == 0):
+    # out-channels from 5x5 up (83-111 vs 76-79 / 50-98), the RGB stems from 5x5 up (3 -> 128 7x7: 1.28 vs 3.83 / 2.59 ms); with 64+
+    # out-channels the flat kernel's 128-pixel blocks win (61 vs 94)
+    if SPATIAL and stride == 1 and kh * kw >= 9 and kw <= 33 and (C > 4 or kh * kw >= 25) and \
+            (Co <= 16 or ((co_pad == 32 or C <= 4) and kh * kw >= 25) or MIN_TILES == 0):
         thin = Co <= 16
         th = 16 if (thin or bm == 32) else 8
         tiles = N * -(-Ho // th) * -(-Wo // 32) * (1 if thin else co_pad // bm)
         if tiles >= MIN_TILES and kw * 4 * (16 if thin else bm) <= 4096:
             return SPATIAL_K
+    if Co <= 4 and kh * kw >= 9 and C > 4:
+        return FLAT     # FlowNet's predict_flow heads (c -> 2, 3x3, up to 1026 channels on 8 x 15 ... 128 x 240 pixels): 0.14-0.47 vs 0.33-1.05 ms
     wgs = -(-(N * Ho * Wo) // 128) * (co_pad // bm)
     if wgs < MIN_WGS or C <= 4:
         return STOCK
@@ -204,6 +208,11 @@ class Conv2dF32(nn.Conv2d):
             y = run_conv_group(self, None, None, x)
             if y is not None:
                 return y
+        if _ok(x, weight) and not x.is_contiguous():
+            # A permuted [h,w,3] frame is channels_last-strided: the stock operator would then produce a channels_last map, and every
+            # consumer below (the own kernels read NCHW) would copy the full-resolution 128-channel stem output once per inception
+            # branch (4.9 ms each at 4 x 540 x 960: 29 ms of a C2 frame, profiles/r04_c2_kernel_stats_spatial_fused.txt).
+            x = x.contiguous()
         return super()._conv_forward(x, weight, bias)
 
 
