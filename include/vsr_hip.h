@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VSR_ABI_VERSION 2
+#define VSR_ABI_VERSION 3
 
 #define VSR_OK 0
 #define VSR_E_ARG (-1)     /* null pointer / non-positive size / unsupported parameter */
@@ -143,9 +143,12 @@ int vsr_sr_conv1x1_f32(const float* in0, const float* w0, int ldw0, const float*
  * weight [32(out),32(in),8,8] permuted to [ky][kx][in][out].  Both with the scale as a parameter: the two blocks for every row of SRFBN's (kernel, stride) table: scale 4 = (8,4) the reference's literals
  * (SRProjectionModule.py:10-12,101-103), 3 = (7,3), 2 = (6,2); padding 2 in all.  This is the "scale-2 extension" of
  * SURVEY.md 7-1 / 8(d) (configs C1/C2/C3-B/C5 are labelled x2); the reference itself crashes for upscale_factor != 4.
- * in [N,32,h,w] <-> [N,32,scale*h,scale*w]; weight_packed [ky][kx][in][out] as above with K x K taps. */
+ * in [N,32,h,w] <-> [N,32,scale*h,scale*w]; weight_packed [ky][kx][in][out] as above with K x K taps.
+ * dt_frags (optional, null: none): the FeedbackBlock's downtran 1x1 + PReLU (SRProjectionModule.py:77-79; the x S map's only consumer
+ * under the zero-fill semantic) applied to the tile before it is stored: out = PReLU(W_dt . PReLU(deconv) + dt_bias, dt_slope).
+ * dt_frags [16][64] float32: fragment r, lane l = W_dt[out = l % 32][in = 8 (r / 4) + 4 (l / 32) + r % 4] (sr.py:pack_dt_frags). */
 int vsr_sr_deconv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
-                      int h, int w, int scale, vsr_stream_t stream);
+                      int h, int w, int scale, const float* dt_frags, const float* dt_bias, float dt_slope, vsr_stream_t stream);
 int vsr_sr_conv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
                     int h, int w, int scale, vsr_stream_t stream);
 /* conv_out 3x3 (32->3, no activation) + bilinear skip of sub_mean(x) + add_mean (:136,:142-143), the skip's factor (=

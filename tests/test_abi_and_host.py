@@ -28,7 +28,7 @@ def test_libraries_build_and_export_exactly_what_their_headers_declare():
     exported = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
     extra = sorted(set(ln.split()[-1] for ln in exported.splitlines() if " T vsr_" in ln) - set(declared))
     assert not extra, extra                                          # ... and nothing the header does not declare
-    assert lib.vsr_abi_version() == 2 and xlib.vsr_abi_version() == 2
+    assert lib.vsr_abi_version() == 3 and xlib.vsr_abi_version() == 3
     lib.vsr_sr_query.restype = ctypes.c_size_t
     assert lib.vsr_sr_query(_lib.Q_UTD_BLOB_BYTES) % 16 == 0 and lib.vsr_sr_query(_lib.Q_UTD_STRIP_WIDTH) == 31
     # code object is built for gfx950 only

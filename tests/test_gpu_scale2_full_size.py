@@ -90,7 +90,7 @@ def test_c2_fp32_full_size_band_and_mfma_build_identity():
         for variant in (0, 1):
             lib.vsr_sr_f32_variant(variant)
             hr = torch.empty((8, 32, 2 * h, 2 * w), dtype=torch.float32, device="cuda")
-            L.check(lib.vsr_sr_deconv_f32(L.dptr(a), L.dptr(wd), L.dptr(b), L.cf(0.2), L.dptr(hr), 8, h, w, 2, L.stream()), "deconv")
+            L.check(lib.vsr_sr_deconv_f32(L.dptr(a), L.dptr(wd), L.dptr(b), L.cf(0.2), L.dptr(hr), 8, h, w, 2, None, None, L.cf(0.0), L.stream()), "deconv")
             lr = torch.empty((8, 32, h, w), dtype=torch.float32, device="cuda")
             L.check(lib.vsr_sr_conv_f32(L.dptr(hr), L.dptr(wc), L.dptr(b), L.cf(0.2), L.dptr(lr), 8, h, w, 2, L.stream()), "conv")
             outs.append((hr, lr))

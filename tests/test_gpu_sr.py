@@ -8,6 +8,7 @@ summation order, so it is held to 2e-5 of the range -- 50x tighter than the stat
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -114,7 +115,7 @@ def test_f32_mfma_builds_bit_identical(scale, shape):
         for variant in (0, 1, 2):
             lib.vsr_sr_f32_variant(variant)
             hr = torch.empty((N, 32, scale * h, scale * w), dtype=torch.float32, device="cuda")
-            L.check(lib.vsr_sr_deconv_f32(L.dptr(x), L.dptr(wp_d), L.dptr(b), L.cf(slope), L.dptr(hr), N, h, w, scale, L.stream()), "deconv")
+            L.check(lib.vsr_sr_deconv_f32(L.dptr(x), L.dptr(wp_d), L.dptr(b), L.cf(slope), L.dptr(hr), N, h, w, scale, None, None, L.cf(0.0), L.stream()), "deconv")
             lr = torch.empty((N, 32, h, w), dtype=torch.float32, device="cuda")
             L.check(lib.vsr_sr_conv_f32(L.dptr(hr), L.dptr(wp_c), L.dptr(b), L.cf(slope), L.dptr(lr), N, h, w, scale, L.stream()), "conv")
             outs.append((hr, lr))
@@ -127,6 +128,57 @@ def test_f32_mfma_builds_bit_identical(scale, shape):
     lr_ref = F.prelu(F.conv2d(hr0.double(), wt_c.double(), b.double(), stride=scale, padding=2), a.double())
     _close(hr0.double(), hr_ref.cpu().numpy(), TOL_FP32, "deconv")
     _close(lr0.double(), lr_ref.cpu().numpy(), TOL_FP32, "conv")
+
+
+@pytest.mark.parametrize("case", [(2, 9, 13, 2), (1, 20, 70, 2), (1, 7, 40, 4), (1, 6, 33, 3)])
+def test_f32_deconv_with_fused_downtran_matches_the_two_launches(case):
+    """vsr_sr_deconv_f32 with the downtran 1x1 + PReLU in its epilogue (dt_frags) against the deconvolution followed by
+    vsr_sr_conv1x1_f32: the same products, the 1x1's sum in another order -> 1e-6 of the range, and the float32 bar against float64."""
+    import ctypes
+    from video_super_resolution_amd import _lib as L
+    from video_super_resolution_amd.sr import pack_dt_frags
+    N, h, w, S = case
+    K = {2: 6, 3: 7, 4: 8}[S]
+    rs = np.random.RandomState(h * 3 + w + S)
+    lib = L.load()
+    x = torch.from_numpy(rs.randn(N, 32, h, w).astype(np.float32)).cuda()
+    wt = torch.from_numpy((rs.randn(32, 32, K, K) / (4.0 * K)).astype(np.float32)).cuda()       # ConvTranspose2d weight [in, out, K, K]
+    wp = wt.permute(2, 3, 0, 1).contiguous()
+    b = torch.from_numpy(rs.randn(32).astype(np.float32)).cuda()
+    wdt = torch.from_numpy((rs.randn(32, 32 * 3) / 6.0).astype(np.float32)).cuda()              # downtran matrix [out, ld]; this map reads columns 32 ..
+    bdt = torch.from_numpy(rs.randn(32).astype(np.float32)).cuda()
+    fr = pack_dt_frags(wdt, 32)
+    fused = torch.empty((N, 32, S * h, S * w), dtype=torch.float32, device="cuda")
+    L.check(lib.vsr_sr_deconv_f32(L.dptr(x), L.dptr(wp), L.dptr(b), L.cf(0.2), L.dptr(fused), N, h, w, S, L.dptr(fr), L.dptr(bdt), L.cf(0.3), L.stream()), "deconv+dt")
+    hr = torch.empty_like(fused)
+    L.check(lib.vsr_sr_deconv_f32(L.dptr(x), L.dptr(wp), L.dptr(b), L.cf(0.2), L.dptr(hr), N, h, w, S, None, None, L.cf(0.0), L.stream()), "deconv")
+    two = torch.empty_like(fused)
+    P = S * S * h * w
+    L.check(lib.vsr_sr_conv1x1_f32(L.dptr(hr), ctypes.c_void_p(wdt.data_ptr() + 4 * 32), wdt.shape[1], L.optr(None), L.optr(None), 0, L.optr(None), L.optr(None), 0,
+                                   L.dptr(bdt), L.optr(None), L.cf(0.3), L.dptr(two), N, P, L.stream()), "conv1x1")
+    rng = two.abs().max().item()
+    assert (fused - two).abs().max().item() <= 1e-6 * rng
+    ref = F.prelu(F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=S, padding=2), torch.tensor([0.2], device="cuda").double())
+    ref = torch.einsum("oc,nchw->nohw", wdt[:, 32:64].double(), ref) + bdt.double()[None, :, None, None]
+    ref = torch.where(ref >= 0, ref, 0.3 * ref)
+    _close(fused.double(), ref.cpu().numpy(), TOL_FP32, "deconv+dt")
+
+
+def test_f32_forward_fused_downtran_matches_separate_launches():
+    """SRProjectionModule (float32, x2 and x4): the forward with the downtran 1x1 fused into the deconvolution (default) against
+    fuse_dt_f32 = False."""
+    from video_super_resolution_amd import SRProjectionModule
+    from video_super_resolution_amd.weights import fill_module_
+    for scale in (2, 4):
+        m = fill_module_(SRProjectionModule(upscale_factor=scale).eval(), seed=0, prefix="model.").cuda()
+        m.precision = "fp32"
+        x = torch.from_numpy(np.random.RandomState(scale).randint(0, 256, (8, 3, 24, 40)).astype(np.float32)).cuda()
+        with torch.no_grad():
+            a = m(x)
+            m.fuse_dt_f32 = False
+            b = m(x)
+            m.fuse_dt_f32 = True
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
 
 
 @pytest.mark.parametrize("case", [(2, 1000, 1, False), (1, 4097, 2, True), (3, 70, 3, True), (1, 31, 1, True)])

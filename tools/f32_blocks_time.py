@@ -24,7 +24,7 @@ def t(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 for variant in (0, 1, 0):
     lib.vsr_sr_f32_variant(variant)
-    td = t(lambda: L.check(lib.vsr_sr_deconv_f32(L.dptr(x), L.dptr(wp), L.dptr(b), L.cf(0.2), L.dptr(hr), N, h, w, S, L.stream())))
+    td = t(lambda: L.check(lib.vsr_sr_deconv_f32(L.dptr(x), L.dptr(wp), L.dptr(b), L.cf(0.2), L.dptr(hr), N, h, w, S, None, None, L.cf(0.0), L.stream())))
     tc = t(lambda: L.check(lib.vsr_sr_conv_f32(L.dptr(hr), L.dptr(wp), L.dptr(b), L.cf(0.2), L.dptr(lr), N, h, w, S, L.stream())))
     print(f"variant {variant} ({'MFMA' if variant == 0 else 'one pixel per thread'}): deconv {td:.3f} ms = {flop / td / 1e9:.1f} TFLOP/s, conv {tc:.3f} ms = {flop / tc / 1e9:.1f} TFLOP/s  (of 157)")
 lib.vsr_sr_f32_variant(0)

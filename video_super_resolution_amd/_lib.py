@@ -56,7 +56,7 @@ def _open(path: str) -> ctypes.CDLL:
     lib.vsr_last_route.restype = ctypes.c_char_p
     for fn in ("vsr_sr_query", "vsr_train_corr_dw_ws_floats", "vsr_train_prelu_bwd_ws_floats"):
         getattr(lib, fn).restype = ctypes.c_size_t
-    if lib.vsr_abi_version() != 2:
+    if lib.vsr_abi_version() != 3:
         raise VsrHipError(f"{os.path.basename(path)}: ABI version mismatch")
     return lib
 

@@ -317,6 +317,51 @@ __global__ void __launch_bounds__(256) k_conv_f32_sp16(const CF32 p) {
     }
 }
 
+// Few out-channels (<= 4) over MANY input channels on small maps: FlowNet's predict_flow heads (Conv2d(c, 2, 3, 1, 1), c up to 1026, on
+// 8 x 15 ... 128 x 240 pixels).  Both other kernels walk K serially inside a handful of workgroups (0.46 ms for 0.04 GFLOP); here a
+// workgroup owns 16 consecutive output pixels and its sixteen waves share the K walk (tap x 4-channel steps, wave w takes steps w, w + 16,
+// ..): v_mfma_f32_16x16x4_f32 with both operands straight from global memory (A: 16 consecutive floats of the packed weights per channel,
+// B: each lane its own pixel), eight steps' loads in flight per wave; the partial tiles meet in LDS and are summed in wave order.
+constexpr int HEAD_WAVES = 16;
+__global__ void __launch_bounds__(64 * HEAD_WAVES) k_conv_f32_head(const CF32 p) {
+    __shared__ f4v part[HEAD_WAVES][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const long long M = (long long)p.N * p.Ho * p.Wo, m = (long long)blockIdx.x * 16 + col;
+    const bool px_ok = m < M;
+    const int hw = p.Ho * p.Wo;
+    const int n = px_ok ? (int)(m / hw) : 0, rem = px_ok ? (int)(m - (long long)n * hw) : 0;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int nq = p.cpad >> 2, nsteps = p.kh * p.kw * nq;
+    const float* in_n = p.in + (size_t)n * p.C * p.H * p.W;
+    f4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s0 = wv; s0 < nsteps; s0 += 8 * HEAD_WAVES) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + HEAD_WAVES * u;
+            const int tap = s / nq, c = 4 * (s - tap * nq) + kq;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            const int iy = oy - p.pad_y + ky, ix = ox - p.pad_x + kx;
+            const bool live = s < nsteps;
+            const bool ok = live && px_ok && c < p.C && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            a[u] = live ? p.wp[((size_t)tap * p.cpad + c) * p.co_pad + col] : 0.0f;
+            b[u] = ok ? in_n[((size_t)c * p.H + iy) * p.W + ix] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv != 0 || kq != 0 || !px_ok) return;   // D[i][j]: lane 16 (i / 4) + j, register i % 4: out-channels 0..3 sit in lanes 0-15
+    f4v sum = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < HEAD_WAVES; ++k) sum += part[k][lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (e < p.Co) p.out[(((size_t)n * p.ctot + p.coff + e) * p.Ho + oy) * p.Wo + ox] = epilogue(p, sum[e], e);
+}
+
 }  // namespace
 
 extern "C" {
@@ -345,6 +390,12 @@ int vsr_conv2d_f32_pack(const float* weight, float* packed, int Co, int C, int k
 static int launch_conv_f32(CF32& p, int route, hipStream_t st) {
     const bool plain_out = p.oy_mul == 1 && p.ox_mul == 1 && p.oy_off == 0 && p.ox_off == 0 && p.outH == p.Ho && p.outW == p.Wo;
     const bool sp_legal = p.stride == 1 && plain_out && p.kw <= 33;
+    // predict_flow-shaped layers: the K-sharing head kernel (route 0 and 1; measured 0.46 -> see profiles/r04_c2_route_table_after_tuning.txt)
+    if (route != 2 && p.stride == 1 && plain_out && p.Co <= 4 && p.kh * p.kw >= 9 && p.C >= 256 && (long long)p.N * p.Ho * p.Wo <= 131072) {
+        const long long gx = ((long long)p.N * p.Ho * p.Wo + 15) / 16;
+        hipLaunchKernelGGL(k_conv_f32_head, dim3((unsigned)gx), dim3(64 * HEAD_WAVES), 0, st, p);
+        return vsr::launched("conv2d_nchw_f32 (head)");
+    }
     if (route == 2 && !sp_legal) return vsr::fail(VSR_E_UNSUPPORTED, "conv2d_nchw_f32: the spatial-reuse kernel serves stride 1 into a plain output only");
     if (route != 1 && sp_legal && (route == 2 || p.kh * p.kw >= 9)) {
         const bool thin = p.Co <= 16;

@@ -245,7 +245,7 @@ bool launch_conv_f32_mfma_per_tap(const float* in, const float* wp, const float*
 void launch_conv1x1_f32_mfma(const float* in0, const float* w0, int ld0, const float* in1, const float* w1, int ld1, const float* in2, const float* w2,
                              int ld2, const float* bias, const float* cmap, float slope, float* out, int N, size_t P, hipStream_t stream);
 bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale, bool per_tap,
-                            hipStream_t stream);
+                            hipStream_t stream, const float* dtw, const float* dtb, float dts);
 }  // namespace vsr
 
 extern "C" {
@@ -287,12 +287,15 @@ int vsr_sr_f32_variant(int v) {
 #endif
 
 int vsr_sr_deconv_f32(const float* in, const float* weight_packed, const float* bias, float slope, float* out, int N,
-                      int h, int w, int scale, vsr_stream_t stream) {
+                      int h, int w, int scale, const float* dt_frags, const float* dt_bias, float dt_slope, vsr_stream_t stream) {
     VSR_REQUIRE(in && weight_packed && bias && out, "sr_deconv: null pointer");
+    VSR_REQUIRE(!dt_frags || dt_bias, "sr_deconv: the fused 1x1 needs its bias");
     VSR_REQUIRE(scale >= 2 && scale <= 4, "sr_deconv: scale %d (2: k6 s2, 3: k7 s3, 4: k8 s4; padding 2)", scale);
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && (long long)scale * h <= 65535 && N <= 65535, "sr_deconv: bad shape");
-    if (g_f32_variant != 1 && vsr::launch_deconv_f32_mfma(in, weight_packed, bias, slope, out, N, h, w, scale, g_f32_variant == 2, vsr::S(stream)))
+    if (g_f32_variant != 1 && vsr::launch_deconv_f32_mfma(in, weight_packed, bias, slope, out, N, h, w, scale, g_f32_variant == 2, vsr::S(stream),
+                                                          dt_frags, dt_bias, dt_slope))
         return vsr::launched("sr_deconv_mfma");
+    if (dt_frags) return vsr::fail(VSR_E_UNSUPPORTED, "sr_deconv: the fused 1x1 tail exists in the matrix-core build only (tensor beyond 4 GiB, or a per-pixel variant selected)");
     const dim3 grid(vsr::cdiv(w + 1, kBlock), scale * h, N);
     if (scale == 4) hipLaunchKernelGGL((k_deconv<8, 4>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);
     else if (scale == 3) hipLaunchKernelGGL((k_deconv<7, 3>), grid, dim3(kBlock), 0, vsr::S(stream), in, weight_packed, bias, slope, out, h, w);

@@ -236,9 +236,16 @@ __global__ void __launch_bounds__(256) k_deconv_mfma(const float* __restrict__ i
 // the same pixels shifted by dx (ds_bpermute_b32, as k_conv_mfma_sh); a wave owns NT pixel tiles (each weight fragment serves
 // S x NT MFMAs).  All 16 channel pairs of the row are resident (16 (NT + 1) registers),
 // the sum of an output still runs (dy, dx, ci) ascending: bit-identical maps.
-template <int K, int S, int NT>
+// DT: the 1x1 convolution + PReLU that consumes the x S map (the FeedbackBlock's downtran, SRProjectionModule.py:77-79 under the
+// zero-fill semantic: the map's only consumer) applied to the accumulator tile before it is stored -- the map crosses HBM once instead of
+// three times.  No data movement: register r of a 32 x 32 accumulator tile holds channel 8 (r/4) + r%4 in lanes 0-31 and channel
+// 8 (r/4) + 4 + r%4 in lanes 32-63 of the SAME pixel, which is exactly the B operand of v_mfma_f32_32x32x2_f32 for that pair of input
+// channels; dtw [16][64] holds the matching weight fragments.  The 1x1's sum then runs over the pairs in register order (0,4,1,5,2,6,
+// 3,7,8,12,..) instead of ascending: equal to the separate 1x1 launch up to float32 rounding, not bit for bit (tests: 1e-6 of range).
+template <int K, int S, int NT, bool DT = false>
 __global__ void __launch_bounds__(256) k_deconv_mfma_sh(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
-                                                        float slope, float* __restrict__ out, int h, int w) {
+                                                        float slope, float* __restrict__ out, int h, int w,
+                                                        const float* __restrict__ dtw = nullptr, const float* __restrict__ dtb = nullptr, float dts = 0.0f) {
     constexpr int T = (K + S - 1) / S;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = lane & 31, kh = lane >> 5;
@@ -304,6 +311,31 @@ __global__ void __launch_bounds__(256) k_deconv_mfma_sh(const float* __restrict_
             }
         }
     }
+    float slope_out = slope;
+    if (DT) {
+        f16v a2[S][NT];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float b = dtb[8 * (r >> 2) + 4 * kh + (r & 3)];
+#pragma unroll
+            for (int px = 0; px < S; ++px)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a2[px][t][r] = b;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = dtw[64 * r + lane];
+#pragma unroll
+            for (int px = 0; px < S; ++px)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a2[px][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, prelu(acc[px][t][r], slope), a2[px][t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int px = 0; px < S; ++px)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[px][t] = a2[px][t];
+        slope_out = dts;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int q = q0 + 32 * t + col;   // this lane's LR column index, in [0, w]
@@ -315,7 +347,7 @@ __global__ void __launch_bounds__(256) k_deconv_mfma_sh(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = 8 * (r >> 2) + 4 * kh + (r & 3);
-                out[((size_t)n * NF + co) * HW + (size_t)Y * W + X] = prelu(acc[px][t][r], slope);
+                out[((size_t)n * NF + co) * HW + (size_t)Y * W + X] = prelu(acc[px][t][r], slope_out);
             }
         }
     }
@@ -418,9 +450,16 @@ void launch_conv1x1_f32_mfma(const float* in0, const float* w0, int ld0, const f
 }
 
 bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale,
-                            bool per_tap, hipStream_t stream) {
+                            bool per_tap, hipStream_t stream, const float* dtw, const float* dtb, float dts) {
     if ((size_t)NF * h * w * 4 >= (1ull << 32) - 16 || (scale * h + 3) / 4 > 65535) return false;
     const dim3 grid(vsr::cdiv(w + 1, 64), vsr::cdiv(scale * h, 4), N);
+    if (dtw) {   // the fused 1x1 tail exists in the shifted-operand builds only
+        if (per_tap) return false;
+        if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma_sh<8, 4, 2, true>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w, dtw, dtb, dts);
+        else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma_sh<7, 3, 2, true>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w, dtw, dtb, dts);
+        else hipLaunchKernelGGL((k_deconv_mfma_sh<6, 2, 2, true>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w, dtw, dtb, dts);
+        return true;
+    }
 #if VSR_X
     if (per_tap) {
         if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma<8, 4>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
@@ -430,10 +469,10 @@ bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias,
     }
 #endif
     (void)per_tap;
-    if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma_sh<8, 4, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
-    else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma_sh<7, 3, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+    if (scale == 4) hipLaunchKernelGGL((k_deconv_mfma_sh<8, 4, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w, nullptr, nullptr, 0.0f);
+    else if (scale == 3) hipLaunchKernelGGL((k_deconv_mfma_sh<7, 3, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w, nullptr, nullptr, 0.0f);
     else   // (two pixel tiles per wave; four measured level: 3.27-3.50 vs 3.39-3.43 ms, at one wave per SIMD instead of two)
-        hipLaunchKernelGGL((k_deconv_mfma_sh<6, 2, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w);
+        hipLaunchKernelGGL((k_deconv_mfma_sh<6, 2, 2>), grid, dim3(256), 0, stream, in, wp, bias, slope, out, h, w, nullptr, nullptr, 0.0f);
     return true;
 }
 

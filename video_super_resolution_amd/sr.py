@@ -94,6 +94,17 @@ class FeedbackBlock(nn.Module):
         raise RuntimeError("FeedbackBlock is a parameter container; call SRProjectionModule.forward")
 
 
+def pack_dt_frags(dt_w: torch.Tensor, col: int) -> torch.Tensor:
+    """The 32 x 32 slice [:, col:col+32] of a downtran weight matrix [32(out), ld(in)] as the 16 A-operand fragments of the fused tail of
+    csrc/sr_f32_mfma.hip:k_deconv_mfma_sh<.., DT>: fragment r, lane l = W[out = l % 32][in = 8 (r // 4) + 4 (l // 32) + r % 4]."""
+    w = dt_w[:, col:col + _NF].detach().float()
+    r = torch.arange(16).view(16, 1)
+    l = torch.arange(64).view(1, 64)
+    ci = 8 * (r // 4) + 4 * (l // 32) + r % 4
+    co = (l % 32).expand(16, 64)
+    return w[co.to(w.device), ci.to(w.device)].contiguous()
+
+
 class SRProjectionModule(nn.Module):
     def __init__(self, in_channels=3, out_channels=3, num_features=32, upscale_factor=4, num_steps=3, num_groups=6,
                  act_type="prelu", norm_type=None):
@@ -234,12 +245,14 @@ class SRProjectionModule(nn.Module):
                 "sr_conv1x1")
         return out
 
-    def _up(self, x, w, b, a, N, h, w_):
+    def _up(self, x, w, b, a, N, h, w_, dt=None):
+        """dt = (fragments [16,64], bias, slope): the downtran 1x1 + PReLU applied in the deconvolution's epilogue (`pack_dt_frags`)."""
         S = self.upscale_factor
         out = torch.empty((N, _NF, S * h, S * w_), dtype=torch.float32, device=x.device)
         tok = L.TIMER.start("sr_deconv8s4_f32" if S == 4 else "sr_deconv_f32")
-        L.check(L.load().vsr_sr_deconv_f32(L.dptr(x), L.dptr(w), L.dptr(b), L.cf(a), L.dptr(out), N, h, w_, S, L.stream()),
-                "sr_deconv")
+        fr, fb, fa = dt if dt is not None else (None, None, 0.0)
+        L.check(L.load().vsr_sr_deconv_f32(L.dptr(x), L.dptr(w), L.dptr(b), L.cf(a), L.dptr(out), N, h, w_, S, L.optr(fr), L.optr(fb), L.cf(fa),
+                                           L.stream()), "sr_deconv")
         L.TIMER.stop(tok)
         return out
 
@@ -253,16 +266,23 @@ class SRProjectionModule(nn.Module):
         return out
 
     # ------------------------------------------------------------------ group recurrences
-    def _hr_from(self, P, i, lr_prev, N, h, w):
-        """hr[i] for i >= 1 from lr[i-1]."""
+    def _hr_from(self, P, i, lr_prev, N, h, w, dt_for=None):
+        """hr[i] for i >= 1 from lr[i-1].  dt_for = k: the map is only read by `_lr_from(P, k, hr[i], ..)`, whose downtran 1x1 is applied
+        here, in the deconvolution's epilogue (float32 matrix-core build; `_lr_from(.., dt_done=True)` then skips its own)."""
         a = self._c1([(lr_prev.view(N, _NF, h * w), P["ut_w"][i - 1], _NF * i)], P["ut_b"][i - 1], P["ut_a"][i - 1], N, h * w)
-        return self._up(a.view(N, _NF, h, w), P["up_w"][i], P["up_b"][i], P["up_a"][i], N, h, w)
+        dt = None
+        if dt_for is not None:
+            fr = P.setdefault("dt_frags", {})
+            if dt_for not in fr:
+                fr[dt_for] = pack_dt_frags(P["dt_w"][dt_for - 1], _NF * dt_for)
+            dt = (fr[dt_for], P["dt_b"][dt_for - 1], P["dt_a"][dt_for - 1])
+        return self._up(a.view(N, _NF, h, w), P["up_w"][i], P["up_b"][i], P["up_a"][i], N, h, w, dt=dt)
 
-    def _lr_from(self, P, i, hr_prev, N, h, w):
+    def _lr_from(self, P, i, hr_prev, N, h, w, dt_done=False):
         """lr[i+1] for i >= 1 from hr[i-1]."""
         S = self.upscale_factor
-        b = self._c1([(hr_prev.view(N, _NF, S * S * h * w), P["dt_w"][i - 1], _NF * i)], P["dt_b"][i - 1], P["dt_a"][i - 1], N,
-                     S * S * h * w)
+        b = hr_prev if dt_done else self._c1([(hr_prev.view(N, _NF, S * S * h * w), P["dt_w"][i - 1], _NF * i)], P["dt_b"][i - 1],
+                                             P["dt_a"][i - 1], N, S * S * h * w)
         return self._down(b.view(N, _NF, S * h, S * w), P["dn_w"][i], P["dn_b"][i], P["dn_a"][i], N, h, w)
 
     def _const_map(self, P, h, w, dev) -> torch.Tensor:
@@ -418,8 +438,9 @@ class SRProjectionModule(nn.Module):
             live = {0: lr0.view(N, _NF, h, w)}
             j = 0
             while j + 3 <= G:  # lr[j] -> hr[j+1] -> lr[j+3]
-                hr = self._hr_from(P, j + 1, live[j], N, h, w)
-                live[j + 3] = self._lr_from(P, j + 2, hr, N, h, w)
+                fuse = bool(getattr(self, "fuse_dt_f32", True)) and taps is None
+                hr = self._hr_from(P, j + 1, live[j], N, h, w, dt_for=j + 2 if fuse else None)
+                live[j + 3] = self._lr_from(P, j + 2, hr, N, h, w, dt_done=fuse)
                 del hr
                 j += 3
             ins = [(live[k].view(N, _NF, hp), P["co_w"], _NF * (k - 1)) for k in sorted(live) if k > 0]

@@ -66,18 +66,22 @@ MIN_TILES, MIN_WGS = 120, 192   # launches smaller than these stay off the spati
 
 
 def _route(N, C, H, W, Co, kh, kw, stride, pad_y, pad_x) -> int:
-    """Which implementation serves a layer -- per-layer device times at the C2 size (tools/conv_f32_ab.py,
-    profiles/r04_conv_f32_ab.txt, profiles/r04_conv_f32_spatial_ab.txt):
-      * stride-1 k x k layers with <= 16 out-channels (k >= 3; v_mfma_f32_16x16x4_f32, no padded rows) or 32 out-channels (k >= 5) and
-        enough tiles to fill the chip: the spatial-reuse kernels;
+    """Which implementation serves a layer -- per-layer device times of all three at the C2 size (tools/f32_route_table.py,
+    profiles/r04_c2_route_table_after_tuning.txt; tools/conv_f32_ab.py, profiles/r04_conv_f32_spatial_ab.txt):
+      * predict_flow-shaped layers (<= 4 out-channels, 3x3, >= 64 input channels, small maps): the flat route, which the library serves
+        with its K-sharing head kernel from 256 input channels up (0.06-0.14 ms where the stock operator takes 0.2-1.05);
+      * stride-1 k x k layers with <= 16 out-channels (k >= 3; v_mfma_f32_16x16x4_f32, no padded rows), with 32 out-channels (k >= 5),
+        the RGB stems (k >= 5), given enough tiles to fill the chip: the spatial-reuse kernels;
       * otherwise the flat kernel, except (a) launches of a few dozen workgroups (FlowNet's 1/32 and 1/64-resolution layers: no
-        split-K; 8 x 15 x 1024 -> 1024: 0.95 vs 0.19 ms), (b) RGB stems (3 input channels padded to a 16-channel K step), (c) k x k
-        layers with <= 16 out-channels (half of each 32-row MFMA tile is padding): the stock operator."""
+        split-K; 8 x 15 x 1024 -> 1024: 0.95 vs 0.19 ms), (b) the remaining RGB stems, (c) k x k layers with <= 16 out-channels that the
+        spatial kernels did not take: the stock operator."""
     if not ROUTE:
         return FLAT
     Ho, Wo = (H + 2 * pad_y - kh) // stride + 1, (W + 2 * pad_x - kw) // stride + 1
     co_pad = (Co + 31) // 32 * 32
     bm = 128 if co_pad % 128 == 0 else (64 if co_pad % 64 == 0 else 32)
+    if Co <= 4 and kh * kw >= 9 and C >= 64 and stride == 1 and N * Ho * Wo <= 131072:
+        return FLAT     # FlowNet's predict_flow heads (c -> 2, 3x3, up to 1026 channels on 8 x 15 ... 128 x 240 pixels): the K-sharing head kernel
     # spatial-reuse kernels: <= 16 out-channels from 3x3 up (112 vs 41 flat / 50 stock TFLOP/s on 4 x 540 x 960 64 -> 16 11x11), 32
     # out-channels from 5x5 up (83-111 vs 76-79 / 50-98), the RGB stems from 5x5 up (3 -> 128 7x7: 1.28 vs 3.83 / 2.59 ms); with 64+
     # out-channels the flat kernel's 128-pixel blocks win (61 vs 94)
@@ -88,8 +92,6 @@ def _route(N, C, H, W, Co, kh, kw, stride, pad_y, pad_x) -> int:
         tiles = N * -(-Ho // th) * -(-Wo // 32) * (1 if thin else co_pad // bm)
         if tiles >= MIN_TILES and kw * 4 * (16 if thin else bm) <= 4096:
             return SPATIAL_K
-    if Co <= 4 and kh * kw >= 9 and C > 4:
-        return FLAT     # FlowNet's predict_flow heads (c -> 2, 3x3, up to 1026 channels on 8 x 15 ... 128 x 240 pixels): 0.14-0.47 vs 0.33-1.05 ms
     wgs = -(-(N * Ho * Wo) // 128) * (co_pad // bm)
     if wgs < MIN_WGS or C <= 4:
         return STOCK
