@@ -73,7 +73,7 @@ def synthetic_clip(clip_id: int, n_frames: int, h: int, w: int) -> np.ndarray:
     return np.stack(frames).astype(np.float32)
 
 
-def executed_flop_per_frame(h, w, scale, shared_planes=3):
+def executed_flop_per_frame(h, w, scale, shared_planes=3, precision="fp16"):
     """FLOPs one VSR.forward executes in this implementation: the SR net's head + FeedbackBlock on 8 planes in pass 1 and
     on the 8 - `shared_planes` planes pass 2 does not share with it (the three LR frames are evaluated once), its tail on
     8 planes in both passes (pass 1 at the pixels (s i, s j) only: ~0.6 of the tail's MFMAs) + 4 FlowNet2 runs on the
@@ -84,6 +84,8 @@ def executed_flop_per_frame(h, w, scale, shared_planes=3):
     tail = 2 * 32 * 32 * k * k + 1728 * scale ** 2            # `out` deconv + conv_out per LR pixel and plane
     trunk = SR_FLOP_PER_PX[scale] - tail                       # head + 3 FeedbackBlock steps
     sr = h * w * ((8 + 8 - shared_planes) * trunk + 8 * tail * (1.0 + 0.6))
+    if precision == "fp32":   # the float32 path keeps the shared planes' PRE-FUSION maps: pass 2 skips their tail too; no decimated tail
+        sr = h * w * (8 + 8 - shared_planes) * (trunk + tail)
     trunks = 4 * crop * TRUNK_FLOP_PER_PX["flownet2"] + 5 * h * w * TRUNK_FLOP_PER_PX["hourglass"] + \
         2 * h * w * TRUNK_FLOP_PER_PX["osvos"]
     return sr + trunks
@@ -280,7 +282,7 @@ def main():
     # side stream beside the guidance trunks: VSR.overlap_shared); 8-plane launches only with plane sharing switched off
     dom_names = {"sr_utd_f16", "sr_utd_f16_p5", "sr_utd_f16_p3"} if (precision == "fp16" and scale == 4) else \
         ({"sr_utd_s2_f16", "sr_utd_s2_f16_p5", "sr_utd_s2_f16_p3", "sr_stage_up", "sr_stage_dt", "sr_stage_dn"} if precision == "fp16" else
-         {"sr_conv8s4_f32", "sr_deconv8s4_f32", "sr_conv_f32", "sr_deconv_f32"})
+         {f"{k}{p}" for k in ("sr_conv8s4_f32", "sr_deconv8s4_f32", "sr_conv_f32", "sr_deconv_f32", "sr_deconv_dt_f32") for p in ("", "_p5", "_p3")})
     with torch.no_grad():
         # initialisation, not a step: both entry paths of forward (no estimate yet / recurrent estimate) run once so that
         # weight packing, executor construction and the caching allocator's first-touch hipMallocs are outside the clock
@@ -476,20 +478,24 @@ def main():
                             frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, traffic_source=None, launches_timed=launches,
                             avg_ms=round(ms, 4), algorithmic_bytes_per_launch=nbytes, planes_per_launch=planes)
             else:
-                flop = 8 * h * w * (STAGE_FLOP_PER_PX[scale] - 2048 * scale ** 2) / 2    # one k x k (de)conv, 8 planes
+                planes = int(name.rsplit("_p", 1)[1]) if "_p" in name[-3:] else 8    # (the second SR pass runs on the 5 planes the passes do not share)
+                name = name[:-3] if "_p" in name[-3:] else name
+                flop = planes * h * w * (STAGE_FLOP_PER_PX[scale] - 2048 * scale ** 2) / 2    # one k x k (de)conv
+                if name == "sr_deconv_dt_f32":
+                    flop += planes * h * w * 2048 * scale ** 2    # + the downtran 1x1 (32 x 32 MACs per HR pixel) in its epilogue
                 achieved = flop / (ms * 1e-3) / 1e12
                 traffic, traffic_source = None, None
                 pmc = os.path.join(ROOT, "profiles", "r04_c2_deconv_f32_hbm_pmc.json")
-                if name == "sr_deconv_f32" and (h, w, scale) == (540, 960, 2) and os.path.exists(pmc):
+                if name == "sr_deconv_f32" and planes == 8 and (h, w, scale) == (540, 960, 2) and os.path.exists(pmc):
                     with open(pmc) as f:
                         traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"]
                     traffic_source = "profiles/r04_c2_deconv_f32_hbm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate run of the 8-plane launch)"
                 roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / FP32_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source, launches_timed=launches,
-                            avg_ms=round(ms, 4), algorithmic_flop_per_launch=flop)
+                            avg_ms=round(ms, 4), algorithmic_flop_per_launch=flop, planes_per_launch=planes)
             # the whole frame against the same peak: FLOPs this implementation executes per forward / wall time per forward
             peak = FP16_MFMA_PEAK_TFLOPS if precision == "fp16" else FP32_PEAK_TFLOPS
-            exe = executed_flop_per_frame(h, w, scale)
+            exe = executed_flop_per_frame(h, w, scale, precision=precision)
             roof["whole_frame"] = dict(executed_flop_per_frame=exe, achieved_tflops=round(exe / (ms_per_frame * 1e-3) / 1e12, 2),
                                        frac_of_peak=round(exe / (ms_per_frame * 1e-3) / 1e12 / peak, 4), peak_tflops=peak)
         line = dict(metric=f"HR frames/sec, 1080p->4K x4 VSR (LR {h}x{w} -> {H}x{W}), VSR.forward end-to-end" if (args.config, h, w, scale) == ("C3A", 540, 960, 4)

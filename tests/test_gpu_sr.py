@@ -216,3 +216,23 @@ def test_f32_conv1x1_mfma_bit_identical(case):
         ref = ref + torch.einsum("oc,ncp->nop", wfull[:, 32 * i + 3:32 * i + 35].double(), ins[i].double())
     ref = torch.where(ref >= 0, ref, 0.25 * ref)
     _close(outs[0].double(), ref.cpu().numpy(), TOL_FP32, "conv1x1")
+
+
+def test_f32_shared_planes_bit_identical():
+    """float32 path: a second call that shares its first three planes with the first (`shared`) reuses their pre-fusion maps and
+    evaluates the network on its other five planes only -- the same frame, bit for bit, as the call on all eight."""
+    from video_super_resolution_amd import SRProjectionModule
+    from video_super_resolution_amd.weights import fill_module_
+    m = fill_module_(SRProjectionModule(upscale_factor=2).eval(), seed=0, prefix="model.").cuda()
+    m.precision = "fp32"
+    rs = np.random.RandomState(11)
+    x1 = torch.from_numpy(rs.randint(0, 256, (8, 3, 20, 36)).astype(np.float32)).cuda()
+    x2 = x1.clone()
+    x2[3:] = torch.from_numpy(rs.randint(0, 256, (5, 3, 20, 36)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        shared = {"n": 3}
+        a1 = m(x1, shared=shared)
+        assert "prefc_f32" in shared
+        a2 = m(x2, shared=shared)
+        b1, b2 = m(x1), m(x2)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
