@@ -15,14 +15,15 @@ st = m._packed()["stage"][0]
 a = (torch.randn(N, h, w, 32, device="cuda") * 20).half()
 from video_super_resolution_amd import _lib as L
 lib = L.load()
+VARS = tuple(int(v) for v in os.environ.get("S2_VARIANTS", "0,1").split(","))   # (0: shipping build, 1: branch-free build)
 outs = {}
-res = {0: [], 1: []}
-for v in (0, 1):
+res = {v: [] for v in VARS}
+for v in VARS:
     lib.vsr_sr_utd_s2_variant(v)
     for _ in range(2): outs[v] = st(a, m._chain).clone()
 torch.cuda.synchronize()
 for r in range(4):   # interleaved rounds on one device
-    for v in (0, 1):
+    for v in VARS:
         lib.vsr_sr_utd_s2_variant(v)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -31,6 +32,7 @@ for r in range(4):   # interleaved rounds on one device
         res[v].append(e0.elapsed_time(e1) / reps)
 lib.vsr_sr_utd_s2_variant(0)
 for v, name in ((0, "branches"), (1, "flat")):
+    if v not in VARS: continue
     ms = sorted(res[v])[len(res[v]) // 2]
     print(f"k_utd_s2 [{name:8s}] {N}x{h}x{w}: {ms:.3f} ms  -> {N*h*w*155648/ms/1e9:.1f} TFLOP/s")
-print("bit-identical:", torch.equal(outs[0], outs[1]))
+if len(VARS) > 1: print("bit-identical:", torch.equal(outs[0], outs[1]))

@@ -341,7 +341,9 @@ class SRProjectionModule(nn.Module):
     def precompute_shared(self, x_first: torch.Tensor, shared: dict, live: dict) -> None:
         """The FeedbackBlock maps of the FIRST `shared["n"]` planes of a later `forward(x, shared=shared)` call, computed ahead of
         it: `x_first` [n,3,h,w] are those planes, `live` = {3: buf, 6: buf} the caller's [planes,h*w,32] half buffers the maps go
-        into (rows 0..n-1; the later calls write their own planes beside them).  The planes are independent up to the fusion
+        into (rows 0..n-1; the later calls write their own planes beside them); optional `live["prefc"]`: a [planes,3,4h,4w] float32
+        buffer -- the first planes' pre-fusion tail output is then evaluated too (x4, folded tail), and the later calls run their
+        tail on the other planes only.  The planes are independent up to the fusion
         MLP, so VSR.forward runs this on a side stream next to the guidance trunks, which the LR frames do not depend on
         (video_super_resolution.py:26-40): same kernels on the same values as the call that evaluated all planes at once
         (tests/test_gpu_sr_f16.py::test_shared_planes_bit_identical, ::test_precomputed_planes_bit_identical)."""
@@ -672,6 +674,20 @@ class SRProjectionModule(nn.Module):
                     taps[f"lr{k}"] = nchw(v)
         if precompute is not None:
             shared.update(live={k: precompute[k] for k in (3, 6)}, key=skey)
+            pre = precompute.get("prefc")
+            if (pre is not None and self.upscale_factor == 4 and self.fold_tail and self.tail_build == 3 and "utd_out_fold" in P and
+                    tuple(pre.shape) == (N_tot, 3, 4 * h, 4 * w)):
+                # ... and their pre-fusion planes at FULL resolution (rows 0..N-1 of the caller's buffer): pass 2's tail then runs on
+                # its other planes only, and pass 1 reads its pixels (4i, 4j) out of these (the decimated tail returns exactly the full
+                # tail's values there: tests/test_gpu_sr_f16.py::test_decimated_output_is_a_subset_of_the_full_frame)
+                tok = L.TIMER.start("sr_tail_f16_p%d" % N)
+                L.check(lib.vsr_sr_tail3_fold_f16(L.dptr(precompute[3], torch.float16), L.dptr(precompute[6], torch.float16), L.dptr(cmap_nhwc),
+                                                  L.dptr(P["utd_out_fold"], torch.uint8), L.dptr(P["cv_frags3"], torch.float16),
+                                                  L.dptr(P["tail_par"]), L.dptr(pre), N, h, w,
+                                                  self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256)),
+                                                  int(P["slopes_le_one"]), 0, L.stream()), "sr_tail3_fold_f16")
+                L.TIMER.stop(tok)
+                shared["prefc_all"] = pre
             return None
         if n0:
             live = {k: shared["live"][k] for k in (3, 6)}
@@ -688,12 +704,20 @@ class SRProjectionModule(nn.Module):
             return self._tail_unfused(x, hid.view(N, h, w, _NF), P, decimate, taps)
         if self.fold_tail and taps is None and self.tail_build == 3 and "utd_out_fold" in P and sorted(k for k in live if k > 0) == [3, 6]:
             # compress_out inside the tail (k_tail3<.., FOLD>): no `hid` tensor, one launch less
-            prefc = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
+            # the shared planes' pre-fusion planes were evaluated ahead (precompute_shared): the tail runs on the others only
+            pre = shared.get("prefc_all") if (n0 and shared is not None and shared.get("key") == skey) else None
+            nt = n0 if (pre is not None and tuple(pre.shape) == (N, 3, S * h, S * w) and pre.device == dev) else 0
+            if nt and not decimate:
+                prefc = pre
+            else:
+                prefc = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
+                if nt:
+                    prefc[:nt].copy_(pre[:nt, :, ::S, ::S])
             out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=dev)
-            tok = L.TIMER.start("sr_tail_dec_f16" if decimate else "sr_tail_f16")
-            L.check(lib.vsr_sr_tail3_fold_f16(L.dptr(live[3], torch.float16), L.dptr(live[6], torch.float16), L.dptr(cmap_nhwc),
+            tok = L.TIMER.start(("sr_tail_dec_f16" if decimate else "sr_tail_f16") + (f"_p{N - nt}" if nt else ""))
+            L.check(lib.vsr_sr_tail3_fold_f16(L.dptr(live[3][nt:], torch.float16), L.dptr(live[6][nt:], torch.float16), L.dptr(cmap_nhwc),
                                               L.dptr(P["utd_out_fold"], torch.uint8), L.dptr(P["cv_frags3"], torch.float16),
-                                              L.dptr(P["tail_par"]), L.dptr(prefc), N, h, w, self._rows_per_segment(N, h, w),
+                                              L.dptr(P["tail_par"]), L.dptr(prefc[nt:]), N - nt, h, w, self._rows_per_segment(N - nt, h, w),
                                               int(P["slopes_le_one"]), int(decimate), L.stream()), "sr_tail3_fold_f16")
             L.TIMER.stop(tok)
             tok = L.TIMER.start("sr_fc_planes_skip_dec" if decimate else "sr_fc_planes_skip") if L.TIMER.enabled else None

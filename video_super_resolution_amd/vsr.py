@@ -27,6 +27,8 @@ What differs, on purpose:
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Optional
 
 import torch
@@ -68,6 +70,7 @@ class VSR(nn.Module):
         # "fp32": SR stack in exact float32 kernels, trunks on stock float32 convolutions (the parity configuration).
         self.precision = "fp16"
         self.share_planes = True   # evaluate the three LR-frame planes once per forward (both SR passes read them)
+        self.share_tail = os.environ.get("VSR_SHARE_TAIL", "1") != "0"   # ... their tail (pre-fusion planes) too (A/B switch)
         self.overlap_shared = True  # ... and do so on a side stream beside the guidance trunks of pass 1 (fp16 configuration)
         # Opt-in streaming mode (OFF by default; the headline benchmark leaves it off): consecutive windows of a clip share
         # two of their three LR frames (utils/video_utils.py:25), so the depth prediction of a frame and the flow picture of a
@@ -260,6 +263,9 @@ class VSR(nn.Module):
                 x_first = d.permute(0, 3, 1, 2).contiguous()
                 n_planes = self.model.fc[0].in_features   # 8: the planes of one SR call (video_super_resolution.py:40)
                 live = {k: torch.empty((n_planes, h * w, 32), dtype=torch.float16, device=d.device) for k in (3, 6)}
+                if self.model.upscale_factor == 4 and self.share_tail:
+                    # ... and their pre-fusion planes (the tail's output) at full resolution: both passes' tails skip them
+                    live["prefc"] = torch.empty((n_planes, 3, 4 * h, 4 * w), dtype=torch.float32, device=d.device)
                 s_sr = self._side_streams(d.device)[2]
                 s_sr.wait_stream(main)
                 with torch.cuda.stream(s_sr):
