@@ -35,4 +35,4 @@ for v, name in ((0, "branches"), (1, "flat")):
     if v not in VARS: continue
     ms = sorted(res[v])[len(res[v]) // 2]
     print(f"k_utd_s2 [{name:8s}] {N}x{h}x{w}: {ms:.3f} ms  -> {N*h*w*155648/ms/1e9:.1f} TFLOP/s")
-if len(VARS) > 1: print("bit-identical:", torch.equal(outs[0], outs[1]))
+if len(VARS) > 1: print("bit-identical:", all(torch.equal(outs[VARS[0]], outs[v]) for v in VARS))
