@@ -235,4 +235,13 @@ def test_f32_shared_planes_bit_identical():
         assert "prefc_f32" in shared
         a2 = m(x2, shared=shared)
         b1, b2 = m(x1), m(x2)
+        # the shared planes evaluated AHEAD of both calls, on another stream (what VSR.forward does beside the guidance trunks)
+        ahead = {"n": 3}
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            m.precompute_shared(x1[:3].contiguous(), ahead, None)
+        torch.cuda.current_stream().wait_stream(st)
+        c1, c2 = m(x1, shared=ahead), m(x2, shared=ahead)
     assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    assert torch.equal(c1, b1) and torch.equal(c2, b2)

@@ -347,8 +347,20 @@ class SRProjectionModule(nn.Module):
         MLP, so VSR.forward runs this on a side stream next to the guidance trunks, which the LR frames do not depend on
         (video_super_resolution.py:26-40): same kernels on the same values as the call that evaluated all planes at once
         (tests/test_gpu_sr_f16.py::test_shared_planes_bit_identical, ::test_precomputed_planes_bit_identical)."""
+        if self.precision == "fp32":
+            # float32 configuration: the shared planes' pre-fusion maps (what later calls keep anyway), ahead of the first call
+            n, _, h, w = x_first.shape
+            if n != int(shared.get("n", 0)) or n <= 0:
+                raise ValueError(f"precompute_shared: {n} planes given, shared['n'] = {shared.get('n')}")
+            x = x_first.detach().float().contiguous()
+            P = self._packed()
+            S = self.upscale_factor
+            kept = torch.empty((n, 3, S * h, S * w), dtype=torch.float32, device=x.device)
+            self._f32_planes(x, P, self._const_map(P, h, w, x.device), None, kept)
+            shared["prefc_f32"] = kept
+            return
         if self.precision != "fp16" or self.block.num_groups != 6:
-            raise ValueError("precompute_shared: the fp16 configuration with six groups only")
+            raise ValueError("precompute_shared: the fp16 configuration with six groups only (or the float32 configuration)")
         n, _, h, w = x_first.shape
         total = live[3].shape[0]
         if n != int(shared.get("n", 0)) or not 0 < n < total:
@@ -426,17 +438,37 @@ class SRProjectionModule(nn.Module):
         if self.precision != "fp32":
             raise ValueError(f"precision must be 'fp16' or 'fp32', got {self.precision!r}")
         # `shared` (see _forward_f16): the planes are independent up to the fusion MLP, so the pre-fusion maps of the first shared["n"]
-        # planes -- the three LR frames, the same in both SR passes of VSR.forward -- are computed by the first call and kept in the
-        # caller's dict; the second call runs the network on its other planes only.  Same kernels on the same values: identical frames
-        # (tests/test_gpu_sr.py::test_f32_shared_planes_bit_identical).
+        # planes -- the three LR frames, the same in both SR passes of VSR.forward -- are computed by the first call (or ahead of it,
+        # `precompute_shared`) and kept in the caller's dict; later calls run the network on their other planes only.  Same kernels on
+        # the same values: identical frames (tests/test_gpu_sr.py::test_f32_shared_planes_bit_identical).
         S = self.upscale_factor
-        N_all, x_all = N, x
         n_sh = int(shared.get("n", 0)) if (shared is not None and taps is None) else 0
         kept = shared.get("prefc_f32") if n_sh else None
-        reuse = kept is not None and 0 < n_sh < N_all and tuple(kept.shape) == (n_sh, 3, S * h, S * w) and kept.device == dev
+        reuse = kept is not None and 0 < n_sh < N and tuple(kept.shape) == (n_sh, 3, S * h, S * w) and kept.device == dev
+        prefc = torch.empty((N, 3, S * h, S * w), dtype=torch.float32, device=dev)
         if reuse:
-            x = x_all[n_sh:].contiguous()
-            N = N_all - n_sh
+            prefc[:n_sh].copy_(kept)
+            self._f32_planes(x[n_sh:].contiguous(), P, cmap, None, prefc[n_sh:])
+        else:
+            self._f32_planes(x, P, cmap, taps, prefc)
+            if 0 < n_sh < N:
+                shared["prefc_f32"] = prefc[:n_sh]
+        if taps is not None:
+            taps[f"prefc{self.num_steps - 1}"] = prefc
+        out = torch.empty((1, 3, S * h, S * w), dtype=torch.float32, device=dev)
+        L.check(lib.vsr_sr_fc_fuse_f32(L.dptr(prefc), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]), L.dptr(P["fc_w2"]),
+                                       L.dptr(P["fc_b2"]), N, P["fc_w1"].shape[0], L.dptr(out), S * S * h * w, 0, L.stream()),
+                "sr_fc_fuse")
+        return out[..., ::S, ::S].contiguous() if decimate else out
+
+    def _f32_planes(self, x, P, cmap, taps, prefc_out):
+        """float32 path, planes [N,3,h,w] -> their pre-fusion maps (head, FeedbackBlock steps, `out` deconvolution, conv_out + skip +
+        add_mean) written to `prefc_out` [N,3,Sh,Sw] (contiguous rows of the caller's tensor)."""
+        lib = L.load()
+        N, _, h, w = x.shape
+        dev = x.device
+        G = self.block.num_groups
+        S = self.upscale_factor
         nmid = P["w_in"].shape[0]
         feat = torch.empty((N, _NF, h, w), dtype=torch.float32, device=dev)
         L.check(lib.vsr_sr_head_f32(L.dptr(x), L.dptr(P["sub_s"]), L.dptr(P["sub_b"]), L.dptr(P["w_in"]), L.dptr(P["b_in"]),
@@ -469,24 +501,9 @@ class SRProjectionModule(nn.Module):
                     for k, v in live.items():
                         taps[f"lr{k}"] = v
         up = self._up(hid.view(N, _NF, h, w), P["out_w"], P["out_b"], P["out_a"], N, h, w)
-        prefc = torch.empty((N_all, 3, S * h, S * w), dtype=torch.float32, device=dev)
-        own = prefc[N_all - N:]    # (contiguous: the planes this call evaluated)
         L.check(lib.vsr_sr_tail_scale_f32(L.dptr(up), L.dptr(P["cv_w"]), L.dptr(P["cv_b"]), L.dptr(x), L.dptr(P["sub_s"]),
-                                          L.dptr(P["sub_b"]), L.dptr(P["add_s"]), L.dptr(P["add_b"]), L.dptr(own), N, h, w, S,
+                                          L.dptr(P["sub_b"]), L.dptr(P["add_s"]), L.dptr(P["add_b"]), L.dptr(prefc_out), N, h, w, S,
                                           L.stream()), "sr_tail")
-        del up
-        if reuse:
-            prefc[:n_sh].copy_(kept)
-        elif 0 < n_sh < N_all:
-            shared["prefc_f32"] = prefc[:n_sh]
-        N = N_all
-        if taps is not None:
-            taps[f"prefc{self.num_steps - 1}"] = prefc
-        out = torch.empty((1, 3, S * h, S * w), dtype=torch.float32, device=dev)
-        L.check(lib.vsr_sr_fc_fuse_f32(L.dptr(prefc), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]), L.dptr(P["fc_w2"]),
-                                       L.dptr(P["fc_b2"]), N, P["fc_w1"].shape[0], L.dptr(out), S * S * h * w, 0, L.stream()),
-                "sr_fc_fuse")
-        return out[..., ::S, ::S].contiguous() if decimate else out
 
     # ------------------------------------------------------------------ MFMA path (fp16 storage, NHWC)
     @staticmethod

@@ -71,6 +71,7 @@ class VSR(nn.Module):
         self.precision = "fp16"
         self.share_planes = True   # evaluate the three LR-frame planes once per forward (both SR passes read them)
         self.share_tail = os.environ.get("VSR_SHARE_TAIL", "1") != "0"   # ... their tail (pre-fusion planes) too (A/B switch)
+        self.f32_streams = os.environ.get("VSR_F32_STREAMS", "1") != "0"   # float32 configuration: the trunks (and the shared planes' SR maps) on separate streams too (A/B switch; +7.6 % same box)
         self.overlap_shared = True  # ... and do so on a side stream beside the guidance trunks of pass 1 (fp16 configuration)
         # Opt-in streaming mode (OFF by default; the headline benchmark leaves it off): consecutive windows of a clip share
         # two of their three LR frames (utils/video_utils.py:25), so the depth prediction of a frame and the flow picture of a
@@ -153,9 +154,10 @@ class VSR(nn.Module):
         (joined before the 8-plane assembly).  `extra_depth`: frames whose depth is wanted later (batched now)."""
         h, w = trip[0].shape[:2]
         fast = self._fast()
+        par = fast or self.f32_streams     # the trunks on their own streams (float32 configuration: opt-in, see __init__)
         main = torch.cuda.current_stream(trip[0].device)
-        s_depth, s_vos = self._side_streams(trip[0].device)[:2] if fast else (main, main)
-        if fast:
+        s_depth, s_vos = self._side_streams(trip[0].device)[:2] if par else (main, main)
+        if par:
             s_depth.wait_stream(main)
             s_vos.wait_stream(main)
 
@@ -199,7 +201,7 @@ class VSR(nn.Module):
             tc["flow"] = {k: (a, b, p) for k, (a, b), p in zip(keys, pairs, pics_l)}
         else:
             pics = self.FlowModule.forward_pairs(pairs, net)
-        if fast:
+        if par:
             main.wait_stream(s_depth)
             main.wait_stream(s_vos)
         z = [depth_cache[f.data_ptr()][1] for f in trip]
@@ -258,7 +260,17 @@ class VSR(nn.Module):
             # (whose low-resolution layers leave most CUs idle); both SR calls then run head + FeedbackBlock on planes 3-7 only
             shared = {"n": 3} if self.share_planes else None
             s_sr = None
-            if shared is not None and self.overlap_shared and self._fast() and self.model.block.num_groups == 6:
+            if shared is not None and self.overlap_shared and not self._fast() and self.f32_streams:
+                # float32 configuration: the same overlap; the SR module keeps the planes' pre-fusion maps in `shared`
+                main = torch.cuda.current_stream(d.device)
+                x_first = d.permute(0, 3, 1, 2).contiguous()
+                s_sr = self._side_streams(d.device)[2]
+                s_sr.wait_stream(main)
+                with torch.cuda.stream(s_sr):
+                    self.model.precompute_shared(x_first, shared, None)
+                    shared["prefc_f32"].record_stream(main)
+                x_first.record_stream(s_sr)
+            elif shared is not None and self.overlap_shared and self._fast() and self.model.block.num_groups == 6:
                 main = torch.cuda.current_stream(d.device)
                 x_first = d.permute(0, 3, 1, 2).contiguous()
                 n_planes = self.model.fc[0].in_features   # 8: the planes of one SR call (video_super_resolution.py:40)
