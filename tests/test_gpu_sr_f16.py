@@ -318,7 +318,7 @@ def test_precomputed_planes_bit_identical(shape, scale):
         for side, with_tail in ((False, False), (True, False), (False, True), (True, True)):
             shared = {"n": 3}
             live = {k: torch.empty((8, h * w, 32), dtype=torch.float16, device="cuda") for k in (3, 6)}
-            if with_tail:   # the shared planes' pre-fusion tail output too (x4): both later calls run their tail on five planes
+            if with_tail:   # the shared planes' pre-fusion tail output too: both later calls run their tail on five planes
                 live["prefc"] = torch.full((8, 3, scale * h, scale * w), float("nan"), dtype=torch.float32, device="cuda")
             first = a[:3].contiguous()
             if side:
@@ -330,7 +330,7 @@ def test_precomputed_planes_bit_identical(shape, scale):
             else:
                 m.precompute_shared(first, shared, live)
             assert shared.get("live") is not None
-            assert ("prefc_all" in shared) == (with_tail and scale == 4)
+            assert ("prefc_all" in shared) == with_tail
             assert torch.equal(m(a, decimate=True, shared=shared), ref_a)
             assert torch.equal(m(b, shared=shared), ref_b)
     with pytest.raises(ValueError):

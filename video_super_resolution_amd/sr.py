@@ -341,9 +341,9 @@ class SRProjectionModule(nn.Module):
     def precompute_shared(self, x_first: torch.Tensor, shared: dict, live: dict) -> None:
         """The FeedbackBlock maps of the FIRST `shared["n"]` planes of a later `forward(x, shared=shared)` call, computed ahead of
         it: `x_first` [n,3,h,w] are those planes, `live` = {3: buf, 6: buf} the caller's [planes,h*w,32] half buffers the maps go
-        into (rows 0..n-1; the later calls write their own planes beside them); optional `live["prefc"]`: a [planes,3,4h,4w] float32
-        buffer -- the first planes' pre-fusion tail output is then evaluated too (x4, folded tail), and the later calls run their
-        tail on the other planes only.  The planes are independent up to the fusion
+        into (rows 0..n-1; the later calls write their own planes beside them); optional `live["prefc"]`: a [planes,3,Sh,Sw] float32
+        buffer -- the first planes' pre-fusion tail output is then evaluated too (x4 folded tail, x2 one-launch tail), and the later
+        calls run their tail on the other planes only.  The planes are independent up to the fusion
         MLP, so VSR.forward runs this on a side stream next to the guidance trunks, which the LR frames do not depend on
         (video_super_resolution.py:26-40): same kernels on the same values as the call that evaluated all planes at once
         (tests/test_gpu_sr_f16.py::test_shared_planes_bit_identical, ::test_precomputed_planes_bit_identical)."""
@@ -705,6 +705,12 @@ class SRProjectionModule(nn.Module):
                                                   int(P["slopes_le_one"]), 0, L.stream()), "sr_tail3_fold_f16")
                 L.TIMER.stop(tok)
                 shared["prefc_all"] = pre
+            elif (pre is not None and self.upscale_factor != 4 and "tail_s2" in P and tuple(pre.shape) == (N_tot, 3, self.upscale_factor * h, self.upscale_factor * w) and
+                  len(co(live)["ins"]) <= 2):
+                # scale 2: the same for the one-launch tail of csrc/sr_tail_s2.hip (compress_out of the kept maps first)
+                hid = self._chain([co(live)], N, hp, keep=[True])[0]
+                self._tail_raw(hid.view(N, h, w, _NF), P, False, pre[:N], cus=2 * getattr(self, "_utd_cus", 256))
+                shared["prefc_all"] = pre
             return None
         if n0:
             live = {k: shared["live"][k] for k in (3, 6)}
@@ -714,6 +720,13 @@ class SRProjectionModule(nn.Module):
         S = self.upscale_factor
         ho, wo = (h, w) if decimate else (S * h, S * w)
         if S != 4:
+            # the shared planes' raw tail output was evaluated ahead (precompute_shared): compress_out + tail on the others only
+            pre = shared.get("prefc_all") if (n0 and shared is not None and shared.get("key") == skey and taps is None) else None
+            nt = n0 if (pre is not None and tuple(pre.shape) == (N, 3, S * h, S * w) and pre.device == dev and len(co(live)["ins"]) <= 2) else 0
+            if nt:
+                live_t = {k: v[nt:] for k, v in live.items()}
+                hid = self._chain([co(live_t)], N - nt, hp, keep=[True])[0]
+                return self._tail_unfused(x, hid.view(N - nt, h, w, _NF), P, decimate, taps, pre=pre)
             hid = self._chain([co(live)], N, hp, keep=[True])[0] if len(co(live)["ins"]) <= 2 else \
                 self._c1h(co(live)["ins"], P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
             if taps is not None:
@@ -776,22 +789,18 @@ class SRProjectionModule(nn.Module):
             taps[f"prefc{self.num_steps - 1}"] = prefc
         return out
 
-    def _tail_unfused(self, x, hid, P, decimate, taps):
-        """`out` DeconvBlock -> conv_out 3x3 -> skip + add_mean + fusion MLP for upscale factors other than 4
-        (SRProjectionModule.py:142-146): phase convolutions on the generic MFMA kernel, then csrc/sr_scale.hip."""
+    def _tail_raw(self, hid, P, decimate, raw, cus=512):
+        """`out` DeconvBlock -> conv_out 3x3 of the planes of `hid` [n,h,w,32] into `raw` [n,3,.,.] (rows of the caller's tensor)."""
         lib = L.load()
         N, h, w, _ = hid.shape
         S = self.upscale_factor
-        dev = hid.device
-        ho, wo = (h, w) if decimate else (S * h, S * w)
-        raw = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
         nb = _planes_per_chunk(N, S * h, S * w)
         if "tail_s2" in P:   # scale 2: deconvolution + conv_out in one launch, the x2 map stays in LDS (csrc/sr_tail_s2.hip)
             nbt = max(1, min(N, ((1 << 32) - 32) // (h * w * _NF * 2)))
             for n0 in range(0, N, nbt):
                 n = min(nbt, N - n0)
                 tok = L.TIMER.start("sr_tail_s2_dec_f16" if decimate else "sr_tail_s2_f16") if L.TIMER.enabled else None
-                rows = self._rows_per_segment(n, h, w, cus=512, strip=30)
+                rows = self._rows_per_segment(n, h, w, cus=cus, strip=30)
                 L.check(lib.vsr_sr_tail_s2_f16(L.dptr(hid[n0:n0 + n], torch.float16), L.dptr(P["tail_s2"], torch.uint8), L.dptr(raw[n0:n0 + n]),
                                                n, h, w, rows, int(P["slopes_le_one"]), int(decimate), L.stream()), "sr_tail_s2_f16")
                 L.TIMER.stop(tok)
@@ -803,6 +812,26 @@ class SRProjectionModule(nn.Module):
                                                   hr.shape[0], S * h, S * w, S if decimate else 1, L.stream()), "sr_convout_planes")
             L.TIMER.stop(tok)
             del hr
+
+    def _tail_unfused(self, x, hid, P, decimate, taps, pre=None):
+        """`out` DeconvBlock -> conv_out 3x3 -> skip + add_mean + fusion MLP for upscale factors other than 4
+        (SRProjectionModule.py:142-146): phase convolutions on the generic MFMA kernel, then csrc/sr_scale.hip.  `x`: all planes;
+        `hid`: the LAST hid.shape[0] of them -- the first ones' raw tail output is rows 0.. of `pre` [planes,3,Sh,Sw] (evaluated
+        ahead at full resolution, precompute_shared)."""
+        lib = L.load()
+        N = x.shape[0]
+        Nh, h, w, _ = hid.shape
+        nt = N - Nh
+        S = self.upscale_factor
+        dev = hid.device
+        ho, wo = (h, w) if decimate else (S * h, S * w)
+        if nt and not decimate:
+            raw = pre
+        else:
+            raw = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
+            if nt:
+                raw[:nt].copy_(pre[:nt, :, ::S, ::S])
+        self._tail_raw(hid, P, decimate, raw[nt:])
         out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=dev)
         tok = L.TIMER.start("sr_fc_planes_skip_scale") if L.TIMER.enabled else None
         L.check(lib.vsr_sr_fc_planes_skip_scale_f32(L.dptr(raw), L.dptr(x), L.dptr(P["tail_par"]), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]),

@@ -275,9 +275,10 @@ class VSR(nn.Module):
                 x_first = d.permute(0, 3, 1, 2).contiguous()
                 n_planes = self.model.fc[0].in_features   # 8: the planes of one SR call (video_super_resolution.py:40)
                 live = {k: torch.empty((n_planes, h * w, 32), dtype=torch.float16, device=d.device) for k in (3, 6)}
-                if self.model.upscale_factor == 4 and self.share_tail:
+                if self.model.upscale_factor in (4, 2) and self.share_tail:
                     # ... and their pre-fusion planes (the tail's output) at full resolution: both passes' tails skip them
-                    live["prefc"] = torch.empty((n_planes, 3, 4 * h, 4 * w), dtype=torch.float32, device=d.device)
+                    S = self.model.upscale_factor
+                    live["prefc"] = torch.empty((n_planes, 3, S * h, S * w), dtype=torch.float32, device=d.device)
                 s_sr = self._side_streams(d.device)[2]
                 s_sr.wait_stream(main)
                 with torch.cuda.stream(s_sr):
