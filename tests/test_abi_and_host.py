@@ -168,3 +168,40 @@ def test_video_dataset_takes_one_clip_as_one_clip():
     assert len(ds) == 21
     item = ds[0]
     assert len(item) == 2 and np.asarray(item[0]).shape == (3, 8, 8, 3)
+
+
+def test_float32_trunk_host_logic_on_the_cpu():
+    """trunk_f32 without a GPU: the router's decisions on the layers it was tuned on, FusedSequential == nn.Sequential on CPU tensors
+    (child by child: no own kernel runs there), the folded BatchNorm's scale / shift, the fused downtran's fragment layout."""
+    import torch
+    import torch.nn as nn
+    from video_super_resolution_amd import depth, trunk_f32
+    from video_super_resolution_amd.sr import pack_dt_frags
+    R = trunk_f32._route
+    assert R(4, 64, 540, 960, 16, 11, 11, 1, 5, 5) == trunk_f32.SPATIAL_K      # thin 11x11 at full resolution
+    assert R(4, 32, 270, 480, 32, 7, 7, 1, 3, 3) == trunk_f32.SPATIAL_K        # 32 out-channels from 5x5 up
+    assert R(4, 32, 270, 480, 32, 3, 3, 1, 1, 1) == trunk_f32.FLAT             # ... not 3x3
+    assert R(2, 512, 68, 120, 512, 3, 3, 1, 1, 1) == trunk_f32.FLAT            # thick layers: the flat kernel
+    assert R(2, 1024, 8, 15, 1024, 3, 3, 1, 1, 1) == trunk_f32.STOCK           # a few dozen workgroups: the stock operator
+    assert R(2, 1026, 16, 30, 2, 3, 3, 1, 1, 1) == trunk_f32.FLAT              # predict_flow: the K-sharing head kernel behind the flat route
+    assert R(4, 3, 540, 960, 128, 7, 7, 1, 3, 3) == trunk_f32.SPATIAL_K        # the hourglass stem
+    assert R(2, 64, 512, 960, 64, 3, 3, 2, 1, 1) == trunk_f32.FLAT             # stride 2 never goes to the spatial kernels
+    torch.manual_seed(0)
+    blk = depth._build(depth._H).eval()
+    ref = nn.Sequential(*[nn.Sequential(*list(b)) for b in blk])               # the same children as plain containers
+    x = torch.randn(1, 128, 9, 11)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+        assert torch.equal(blk(x), torch.cat([b(x) for b in ref], 1))
+        conv, bn = blk[1][3], blk[1][4]
+        scale, shift = trunk_f32._Folded().get(conv, bn)
+        y = conv(blk[1][:3](x))
+        assert torch.allclose(bn(y), (y - conv.bias.view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), atol=1e-5)
+    w = torch.arange(32 * 96, dtype=torch.float32).view(32, 96)
+    fr = pack_dt_frags(w, 32)
+    assert fr.shape == (16, 64)
+    for r, lane in ((0, 0), (5, 37), (15, 63), (9, 31)):
+        assert fr[r, lane] == w[lane % 32, 32 + 8 * (r // 4) + 4 * (lane // 32) + r % 4]
