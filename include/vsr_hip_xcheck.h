@@ -46,9 +46,6 @@ int vsr_sr_f32_variant(int v);
 
 /* vsr_sr_utd_s2_f16: 0 the step with its uniform branches (default), 1 the branch-free step (bit-identical). */
 int vsr_sr_utd_s2_variant(int variant);
-/* k_utd_s2p's stamped build (variant 3): per workgroup and wave 8 words = cycles in {deconvolution slots, convolution slots, stores,
- * barrier} summed over the steady iterations + their count (tools/utd_s2_stamps.py). */
-int vsr_sr_utd_s2_stamp_buffer(void* buf);
 
 /* vsr_sr_utd_f16: 0 k_utd3 (default; the only build of libvsr_hip.so), 1 k_utd (two waves per SIMD, LDS ring: the first
  * design, 17 % slower), 2 / 3 builds 0 / 1 with s_memtime stamps around their phases, 4 build 0 stamped around the whole march.

@@ -194,9 +194,8 @@ def test_fused_x2_tail_segmentations_and_unfused_build(monkeypatch, hw):
     assert (unf - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
-@pytest.mark.parametrize("shape", [(2, 5, 7), (3, 20, 70), (1, 33, 31), (1, 1, 3), (2, 2, 40)])
-def test_fused_x2_stage_flat_variant_bit_identical(shape, variant):
+@pytest.mark.parametrize("shape", [(2, 5, 7), (3, 20, 70), (1, 33, 31)])
+def test_fused_x2_stage_flat_variant_bit_identical(shape):
     """k_utd_s2's branch-free step (vsr_sr_utd_s2_variant(1): out-of-image pairs computed and zeroed, partial tiles always
     stored, rows that are not output stored out of range) against the step with its uniform branches."""
     from video_super_resolution_amd import _lib as L
@@ -209,7 +208,7 @@ def test_fused_x2_stage_flat_variant_bit_identical(shape, variant):
     try:
         lib.vsr_sr_utd_s2_variant(0)
         ref = st(a, m._chain).clone()
-        lib.vsr_sr_utd_s2_variant(variant)   # 1: branch-free step, 2: software-pipelined build (k_utd_s2p), 4: twelve steps per loop trip (k_utd_s2u)
+        lib.vsr_sr_utd_s2_variant(1)
         got = st(a, m._chain).clone()
         out = torch.empty_like(got)
         L.check(lib.vsr_sr_utd_s2_f16(L.dptr(a, torch.float16), L.dptr(st.blob, torch.uint8), L.dptr(out, torch.float16), N, h, w, 4, 1, L.stream()))

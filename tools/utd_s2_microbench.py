@@ -31,7 +31,7 @@ for r in range(4):   # interleaved rounds on one device
         e1.record(); torch.cuda.synchronize()
         res[v].append(e0.elapsed_time(e1) / reps)
 lib.vsr_sr_utd_s2_variant(0)
-for v, name in ((0, "branches"), (1, "flat"), (2, "pipelined"), (4, "unrolled x12")):
+for v, name in ((0, "branches"), (1, "flat")):
     if v not in VARS: continue
     ms = sorted(res[v])[len(res[v]) // 2]
     print(f"k_utd_s2 [{name:8s}] {N}x{h}x{w}: {ms:.3f} ms  -> {N*h*w*155648/ms/1e9:.1f} TFLOP/s")

@@ -982,7 +982,7 @@ class _FusedStageS2:
             n = min(nb, N - n0)
             tok = L.TIMER.start("sr_utd_s2_f16" if n == 8 else f"sr_utd_s2_f16_p{n}")
             # two workgroups share a CU (256 registers per wave): twice the slots of the x4 kernel per round
-            rows = self.rows_fn(n, h, w, cus=int(os.environ.get("VSR_S2_SLOTS", "512")), strip=int(L.load().vsr_sr_query(L.Q_UTD_S2_STRIP_WIDTH)))
+            rows = self.rows_fn(n, h, w, cus=512, strip=int(L.load().vsr_sr_query(L.Q_UTD_S2_STRIP_WIDTH)))
             L.check(L.load().vsr_sr_utd_s2_f16(L.dptr(a[n0:n0 + n], torch.float16), L.dptr(self.blob, torch.uint8),
                                                L.dptr(out[n0:n0 + n], torch.float16), n, h, w, rows, int(self.slopes_le_one), L.stream()),
                     "sr_utd_s2_f16")
