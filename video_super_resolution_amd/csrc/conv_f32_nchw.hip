@@ -285,7 +285,6 @@ __global__ void __launch_bounds__(256) k_conv_f32_sp16(const CF32 p) {
             else if (c0 + KC < p.cpad) wload(c0 + KC, 0);
             const float* prow = patch + kq * p.ps + (wv * RW + ky) * PW + col;
             const float* wrow = ws + kq * 16 + col;
-#pragma unroll 2
             for (int kx = 0; kx < p.kw; ++kx) {
                 const float a = wrow[kx * 64];
                 float b[RW][2];
