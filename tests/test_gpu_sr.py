@@ -245,3 +245,42 @@ def test_f32_shared_planes_bit_identical():
         c1, c2 = m(x1, shared=ahead), m(x2, shared=ahead)
     assert torch.equal(a1, b1) and torch.equal(a2, b2)
     assert torch.equal(c1, b1) and torch.equal(c2, b2)
+
+
+@pytest.mark.parametrize("case", [(2, 9, 13), (1, 33, 70), (3, 5, 31)])
+def test_f32_head_on_the_matrix_cores_matches_one_pixel_per_thread(case):
+    """vsr_sr_head_f32 (sub_mean -> conv_in 3x3 + PReLU -> feat_in 1x1 + PReLU) on v_mfma_f32_32x32x2_f32 against its one-pixel-per-thread
+    build (variant 1): stage 1 sums in the same order, stage 2 in register-pair order -> 1e-6 of the range; and the float32 bar against
+    float64."""
+    from video_super_resolution_amd import _lib as L
+    N, h, w = case
+    nmid = 128
+    rs = np.random.RandomState(h + w)
+    lib = L.load()
+    lib.vsr_sr_f32_variant.restype = __import__("ctypes").c_int
+    x = torch.from_numpy(rs.randint(0, 256, (N, 3, h, w)).astype(np.float32)).cuda()
+    ss = torch.from_numpy((rs.rand(3) + 0.5).astype(np.float32)).cuda()
+    sb = torch.from_numpy((-100 * rs.rand(3)).astype(np.float32)).cuda()
+    w_in = torch.from_numpy((rs.randn(nmid, 27) / 40.0).astype(np.float32)).cuda()
+    b_in = torch.from_numpy(rs.randn(nmid).astype(np.float32)).cuda()
+    w_feat = torch.from_numpy((rs.randn(32, nmid) / 11.0).astype(np.float32)).cuda()
+    b_feat = torch.from_numpy(rs.randn(32).astype(np.float32)).cuda()
+    outs = []
+    try:
+        for variant in (0, 1):
+            lib.vsr_sr_f32_variant(variant)
+            out = torch.full((N, 32, h, w), float("nan"), dtype=torch.float32, device="cuda")
+            L.check(lib.vsr_sr_head_f32(L.dptr(x), L.dptr(ss), L.dptr(sb), L.dptr(w_in), L.dptr(b_in), L.cf(0.2), nmid, L.dptr(w_feat), L.dptr(b_feat),
+                                        L.cf(0.3), L.dptr(out), N, h, w, L.stream()), "head")
+            outs.append(out)
+    finally:
+        lib.vsr_sr_f32_variant(0)
+    rng = outs[1].abs().max().item()
+    assert torch.isfinite(outs[0]).all()
+    assert (outs[0] - outs[1]).abs().max().item() <= 1e-6 * rng
+    xs = x.double() * ss.double().view(1, 3, 1, 1) + sb.double().view(1, 3, 1, 1)
+    f = F.conv2d(xs, w_in.double().view(nmid, 3, 3, 3), b_in.double(), padding=1)
+    f = torch.where(f >= 0, f, 0.2 * f)
+    ref = F.conv2d(f, w_feat.double().view(32, nmid, 1, 1), b_feat.double())
+    ref = torch.where(ref >= 0, ref, 0.3 * ref)
+    _close(outs[0].double(), ref.cpu().numpy(), TOL_FP32, "head")

@@ -244,24 +244,28 @@ bool launch_conv_f32_mfma(const float* in, const float* wp, const float* bias, f
 bool launch_conv_f32_mfma_per_tap(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale, hipStream_t stream);
 void launch_conv1x1_f32_mfma(const float* in0, const float* w0, int ld0, const float* in1, const float* w1, int ld1, const float* in2, const float* w2,
                              int ld2, const float* bias, const float* cmap, float slope, float* out, int N, size_t P, hipStream_t stream);
+bool launch_head_f32_mfma(const float* x, const float* sub_scale3, const float* sub_bias3, const float* w_in, const float* b_in, float slope_in, int nmid,
+                          const float* w_feat, const float* b_feat, float slope_feat, float* out, int N, int h, int w, hipStream_t stream);
 bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale, bool per_tap,
                             hipStream_t stream, const float* dtw, const float* dtb, float dts);
 }  // namespace vsr
 
 extern "C" {
 
+VSR_TUNABLE g_f32_variant = 0;   // 0: the (de)convolutions on v_mfma_f32_32x32x2_f32 (sr_f32_mfma.hip); 1: one pixel per thread (cross-check); 2: as 0 with the
+                                // convolution's per-tap MFMA build (measurements)
+
 int vsr_sr_head_f32(const float* x, const float* sub_scale3, const float* sub_bias3, const float* w_in,
                     const float* b_in, float slope_in, int nmid, const float* w_feat, const float* b_feat,
                     float slope_feat, float* out, int N, int h, int w, vsr_stream_t stream) {
     VSR_REQUIRE(x && sub_scale3 && sub_bias3 && w_in && b_in && w_feat && b_feat && out, "sr_head: null pointer");
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && nmid > 0 && N <= 65535, "sr_head: bad shape");
+    if (g_f32_variant != 1 && vsr::launch_head_f32_mfma(x, sub_scale3, sub_bias3, w_in, b_in, slope_in, nmid, w_feat, b_feat, slope_feat, out, N, h, w, vsr::S(stream)))
+        return vsr::launched("sr_head_mfma");
     hipLaunchKernelGGL(k_head, dim3(vsr::cdiv((long long)h * w, kBlock), N), dim3(kBlock), 0, vsr::S(stream), x,
                        sub_scale3, sub_bias3, w_in, b_in, slope_in, nmid, w_feat, b_feat, slope_feat, out, h, w);
     return vsr::launched("sr_head");
 }
-
-VSR_TUNABLE g_f32_variant = 0;   // 0: the (de)convolutions on v_mfma_f32_32x32x2_f32 (sr_f32_mfma.hip); 1: one pixel per thread (cross-check); 2: as 0 with the
-                                // convolution's per-tap MFMA build (measurements)
 
 int vsr_sr_conv1x1_f32(const float* in0, const float* w0, int ldw0, const float* in1, const float* w1, int ldw1,
                        const float* in2, const float* w2, int ldw2, const float* bias, const float* cmap, float slope,

@@ -9,6 +9,7 @@
 // Operand layout of v_mfma_f32_32x32x2_f32 (wave64): A[i][k]: lane = 32 k + i (one VGPR), B[k][j]: lane = 32 k + j,
 // D[i][j]: lane = 32 (i/4 % 2) + j, register = 4 (i / 8) + i % 4.  Here i = out-channel, j = pixel, k = input-channel parity:
 // A = 64 consecutive floats of the packed weights [ky][kx][ci][co] (ci = 2 cp + k), one coalesced 256-byte load per MFMA pair.
+#include <algorithm>
 #include "vsr_common.h"
 
 namespace {
@@ -411,6 +412,78 @@ __global__ void __launch_bounds__(256) k_conv1x1_mfma(const float* __restrict__ 
     }
 }
 
+
+// Head of the SR net (sub_mean -> conv_in 3x3 (3 -> nmid) + PReLU -> feat_in 1x1 (nmid -> 32) + PReLU, SRProjectionModule.py:108-111,134-135)
+// on the matrix cores.  sr_f32.hip:k_head is one pixel per thread: 7552 v_fmac per pixel at 0.28 of the float32 VALU rate (2.9 ms for 8
+// planes of 540 x 960).  Here a wave owns 32 pixels: stage 1 is [nmid x 28] x [28 x 32] (K = the 27 taps of the mean-shifted, zero-padded
+// 3x3 patch + one zero), k ascending exactly as k_head sums; its 32 x 32 accumulator tiles are, register by register, the B operands of
+// stage 2 (register r: channels j and j + 4 of one pixel -- the channel-pair trick of k_deconv_mfma_sh<.., DT>), so the nmid-channel map
+// never leaves the registers.  Stage 2's sum runs in register-pair order: equal to k_head up to float32 rounding (1e-6 of range), not
+// bit for bit.  Weight fragments are staged in LDS once per workgroup (nmid x 240 bytes), workgroups walk the pixel tiles.
+__global__ void __launch_bounds__(256) k_head_mfma(const float* __restrict__ x, const float* __restrict__ sub_scale, const float* __restrict__ sub_bias,
+                                                   const float* __restrict__ w_in, const float* __restrict__ b_in, float slope_in, int nmid,
+                                                   const float* __restrict__ w_feat, const float* __restrict__ b_feat, float slope_feat,
+                                                   float* __restrict__ out, int h, int w) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    const int JB = nmid >> 5;
+    float* const A1 = hsm;                    // [JB][14][64]
+    float* const A2 = hsm + JB * 14 * 64;     // [JB][16][64]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    for (int i = tid; i < JB * 14 * 64; i += 256) {
+        const int l = i & 63, kp = (i >> 6) % 14, jb = i / (14 * 64);
+        const int k = 2 * kp + (l >> 5), j = 32 * jb + (l & 31);
+        A1[i] = k < 27 ? w_in[j * 27 + k] : 0.0f;
+    }
+    for (int i = tid; i < JB * 16 * 64; i += 256) {
+        const int l = i & 63, r = (i >> 6) & 15, jb = i >> 10;
+        A2[i] = w_feat[(l & 31) * nmid + 32 * jb + 8 * (r >> 2) + 4 * (l >> 5) + (r & 3)];
+    }
+    __syncthreads();
+    const int n = blockIdx.y;
+    const size_t hw = (size_t)h * w;
+    const int tiles = (int)((hw + 31) / 32);
+    float s3[3], b3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s3[c] = sub_scale[c]; b3[c] = sub_bias[c]; }
+    float bf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bf[r] = b_feat[8 * (r >> 2) + 4 * kh + (r & 3)];
+    for (int tile = blockIdx.x * 4 + wv; tile < tiles; tile += gridDim.x * 4) {
+        const size_t p = (size_t)tile * 32 + col;
+        const bool p_ok = p < hw;
+        const int y = p_ok ? (int)(p / w) : 0, xx = p_ok ? (int)(p - (size_t)y * w) : 0;
+        float B1[14];
+#pragma unroll
+        for (int kp = 0; kp < 14; ++kp) {
+            // this lane's k = 2 kp + kh: (c, dy, dx); zero padding applies AFTER the mean shift
+            const int k0 = 2 * kp, k1 = 2 * kp + 1;
+            const int c0 = k0 / 9, dy0 = (k0 % 9) / 3, dx0 = k0 % 3, c1 = k1 / 9, dy1 = (k1 % 9) / 3, dx1 = k1 % 3;
+            const int c = kh ? c1 : c0, dy = kh ? dy1 : dy0, dx = kh ? dx1 : dx0;
+            const int yy = y + dy - 1, xc = xx + dx - 1;
+            const bool ok = p_ok && (k1 < 27 || !kh) && yy >= 0 && yy < h && xc >= 0 && xc < w;
+            const float v = ok ? x[((size_t)n * 3 + (c < 3 ? c : 0)) * hw + (size_t)yy * w + xc] : 0.0f;
+            B1[kp] = ok ? v * (c == 0 ? s3[0] : c == 1 ? s3[1] : s3[2]) + (c == 0 ? b3[0] : c == 1 ? b3[1] : b3[2]) : 0.0f;
+        }
+        f16v acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = bf[r];
+        for (int jb = 0; jb < JB; ++jb) {
+            f16v acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] = b_in[32 * jb + 8 * (r >> 2) + 4 * kh + (r & 3)];
+#pragma unroll
+            for (int kp = 0; kp < 14; ++kp) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[(jb * 14 + kp) * 64 + lane], B1[kp], acc1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[(jb * 16 + r) * 64 + lane], prelu(acc1[r], slope_in), acc2, 0, 0, 0);
+        }
+        if (p_ok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[((size_t)n * NF + 8 * (r >> 2) + 4 * kh + (r & 3)) * hw + p] = prelu(acc2[r], slope_feat);
+        }
+    }
+}
+
 }  // namespace
 
 namespace vsr {
@@ -447,6 +520,21 @@ void launch_conv1x1_f32_mfma(const float* in0, const float* w0, int ld0, const f
                              hipStream_t stream) {
     hipLaunchKernelGGL(k_conv1x1_mfma, dim3(vsr::cdiv(P, 256), N), dim3(256), 0, stream, in0, w0, ld0, in1, w1, ld1, in2, w2, ld2, bias, cmap,
                        slope, out, P);
+}
+
+bool launch_head_f32_mfma(const float* x, const float* sub_scale3, const float* sub_bias3, const float* w_in, const float* b_in, float slope_in, int nmid,
+                          const float* w_feat, const float* b_feat, float slope_feat, float* out, int N, int h, int w, hipStream_t stream) {
+    if ((nmid & 31) != 0 || nmid > 256) return false;
+    const size_t lds = (size_t)(nmid >> 5) * 30 * 64 * 4;
+    static unsigned long long attr_devs = 0;
+    if (lds > 48 * 1024 && !vsr::device_marked(attr_devs)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return false;
+        vsr::mark_device(attr_devs);
+    }
+    const long long tiles = ((long long)h * w + 31) / 32;
+    const unsigned gx = (unsigned)std::min<long long>((tiles + 3) / 4, 512);
+    hipLaunchKernelGGL(k_head_mfma, dim3(gx, N), dim3(256), lds, stream, x, sub_scale3, sub_bias3, w_in, b_in, slope_in, nmid, w_feat, b_feat, slope_feat, out, h, w);
+    return true;
 }
 
 bool launch_deconv_f32_mfma(const float* in, const float* wp, const float* bias, float slope, float* out, int N, int h, int w, int scale,
