@@ -153,6 +153,7 @@ int vsr_sr_conv_f32(const float* in, const float* weight_packed, const float* bi
                     int h, int w, int scale, vsr_stream_t stream);
 /* conv_out 3x3 (32->3, no activation) + bilinear skip of sub_mean(x) + add_mean (:136,:142-143), the skip's factor (=
  * upscale_factor, :136) a parameter: hr [N,32,S h,S w] (output of the `out` DeconvBlock), x [N,3,h,w] -> prefc [N,3,S h,S w].
+ * hr == NULL: conv_out (with its bias) has already been evaluated INTO prefc (vsr_conv2d_act_nchw_f32); only skip + add_mean, in place.
  * (float32 blocks on the matrix cores: v_mfma_f32_32x32x2_f32, the same fused multiply-adds in the same order as one pixel per
  * thread, csrc/sr_f32_mfma.hip; the stride-4 / stride-3 convolutions stay on csrc/sr_f32.hip's kernels, which are faster there.) */
 int vsr_sr_tail_scale_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,

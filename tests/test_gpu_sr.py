@@ -178,7 +178,11 @@ def test_f32_forward_fused_downtran_matches_separate_launches():
             m.fuse_dt_f32 = False
             b = m(x)
             m.fuse_dt_f32 = True
+            m.tail_conv_mfma_f32 = False     # conv_out on the one-pixel-per-thread k_tail instead of the 16x16x4 MFMA kernel
+            c = m(x)
+            m.tail_conv_mfma_f32 = True
         assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
+        assert (a - c).abs().max().item() <= 2e-6 * c.abs().max().item()
 
 
 @pytest.mark.parametrize("case", [(2, 1000, 1, False), (1, 4097, 2, True), (3, 70, 3, True), (1, 31, 1, True)])

@@ -217,6 +217,33 @@ __global__ void __launch_bounds__(kBlock) k_tail(const float* __restrict__ hr, c
     }
 }
 
+// ---- the same with conv_out already evaluated (bias included) into prefc by the float32 trunk convolution kernels (conv_f32_nchw.hip:
+//      k_conv_f32_sp16, 16x16x4 MFMA on an LDS-staged patch): only the bilinear skip + add_mean, in place
+__global__ void __launch_bounds__(kBlock) k_tail_skip(const float* __restrict__ x, const float* __restrict__ sub_scale, const float* __restrict__ sub_bias,
+                                                      const float* __restrict__ add_scale, const float* __restrict__ add_bias,
+                                                      float* __restrict__ prefc, int h, int w, int S) {
+    const int n = blockIdx.z, Y = blockIdx.y;
+    const int X = blockIdx.x * kBlock + threadIdx.x;
+    const int H = S * h, W = S * w;
+    if (X >= W) return;
+    const size_t hw = (size_t)h * w, HW = (size_t)H * W;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    const float inv = (float)(1.0 / (double)S);
+    bil(Y, h, inv, y0, y1, ly);
+    bil(X, w, inv, x0, x1, lx);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* xp = x + ((size_t)n * 3 + c) * hw;
+        const float s = sub_scale[c], b = sub_bias[c];
+        const float v00 = xp[(size_t)y0 * w + x0] * s + b, v01 = xp[(size_t)y0 * w + x1] * s + b;
+        const float v10 = xp[(size_t)y1 * w + x0] * s + b, v11 = xp[(size_t)y1 * w + x1] * s + b;
+        const float skip = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+        float* q = prefc + ((size_t)n * 3 + c) * HW + (size_t)Y * W + X;
+        *q = (skip + *q) * add_scale[c] + add_bias[c];
+    }
+}
+
 // ---- fusion MLP across the plane axis (SRProjectionModule.py:126-131,146)
 __global__ void __launch_bounds__(kBlock) k_fc_fuse(const float* __restrict__ prefc, const float* __restrict__ w1,
                                                     const float* __restrict__ b1, const float* __restrict__ w2,
@@ -328,10 +355,15 @@ int vsr_sr_conv_f32(const float* in, const float* weight_packed, const float* bi
 int vsr_sr_tail_scale_f32(const float* hr, const float* w_out, const float* b_out, const float* x, const float* sub_scale3,
                           const float* sub_bias3, const float* add_scale3, const float* add_bias3, float* prefc, int N, int h,
                           int w, int scale, vsr_stream_t stream) {
-    VSR_REQUIRE(hr && w_out && b_out && x && sub_scale3 && sub_bias3 && add_scale3 && add_bias3 && prefc,
-                "sr_tail: null pointer");
+    VSR_REQUIRE(x && sub_scale3 && sub_bias3 && add_scale3 && add_bias3 && prefc, "sr_tail: null pointer");
     VSR_REQUIRE(scale >= 2 && scale <= 4, "sr_tail: scale %d", scale);
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && (long long)scale * h <= 65535 && N <= 65535, "sr_tail: bad shape");
+    if (!hr) {   // conv_out (+ its bias) is already in prefc: skip + add_mean in place
+        hipLaunchKernelGGL(k_tail_skip, dim3(vsr::cdiv((long long)scale * w, kBlock), scale * h, N), dim3(kBlock), 0, vsr::S(stream), x, sub_scale3, sub_bias3,
+                           add_scale3, add_bias3, prefc, h, w, scale);
+        return vsr::launched("sr_tail_skip");
+    }
+    VSR_REQUIRE(w_out && b_out, "sr_tail: null pointer");
     hipLaunchKernelGGL(k_tail, dim3(vsr::cdiv((long long)scale * w, kBlock), scale * h, N), dim3(kBlock), 0, vsr::S(stream), hr, w_out,
                        b_out, x, sub_scale3, sub_bias3, add_scale3, add_bias3, prefc, h, w, scale);
     return vsr::launched("sr_tail");
