@@ -165,14 +165,29 @@ def accuracy_vs_oracle(model, scale, precision, dev, first=None, lr=64):
     with torch.no_grad():
         got, _ = model(data.to(dev), None, hf, None, train=False)
     got, ref = got.float().cpu().numpy().astype(np.float64), ref.numpy().astype(np.float64)
+    # the SR stack alone on IDENTICAL planes (no discrete guidance plane between this build and the oracle): what the arithmetic itself does
+    sr_only = None
+    try:
+        from oracle import vsr_oracle
+        rs = np.random.RandomState(1)
+        planes = torch.from_numpy(rs.randint(0, 256, (8, 3, 24, 32)).astype(np.float32))
+        Psr = {k[len("model."):]: v.detach().cpu() for k, v in model.state_dict().items() if k.startswith("model.")}
+        with torch.no_grad():
+            want = vsr_oracle.sr_forward(Psr, planes, upscale_factor=scale).numpy().astype(np.float64)
+            have = model.model(planes.to(dev)).float().cpu().numpy().astype(np.float64)
+        sr_only = float(f"{np.abs(have - want).max() / np.abs(want).max():.3e}")
+    except Exception as exc:   # noqa: BLE001  (an extra: must not cost the line)
+        sr_only = repr(exc)[:120]
     err = np.abs(got - ref)
     mse = float(np.mean(err ** 2))
     rng = np.abs(ref).max()
     return dict(psnr_vs_oracle_db=round(10 * np.log10(255.0 ** 2 / max(mse, 1e-30)), 2),
                 max_rel_err=float(f"{err.max() / rng:.3e}"), p99_rel_err=float(f"{np.percentile(err, 99) / rng:.3e}"),
+                sr_stack_max_rel_err_identical_planes=sr_only,
                 median_rel_err=float(f"{np.percentile(err, 50) / rng:.3e}"),
                 note="the guidance planes are DISCRETE (uint8 flow pictures, the 0/1 VOS mask): a rounding-level difference in a trunk flips "
-                     "a few plane pixels by a whole step, which is where the maximum comes from; the percentiles describe the frame",
+                     "a few plane pixels by a whole step, which is where the maximum comes from; the percentiles describe the frame; "
+                     "sr_stack_max_rel_err_identical_planes = the SR net alone (this build vs the oracle) on identical 8 x 3 x 24 x 32 planes: the arithmetic itself",
                 tile=f"one VSR.forward (estimated_image None) on LR {lr}x{lr} of the synthetic clip, x{scale}, {precision}: this build "
                      f"on the GPU vs the oracle on the CPU, same seeded weights; max_rel_err = max |diff| / max |oracle|",
                 oracle_range=[round(float(ref.min()), 3), round(float(ref.max()), 3)])

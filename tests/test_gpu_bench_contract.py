@@ -39,4 +39,5 @@ def test_bench_line_contract(extra):
     if "--accuracy" in extra:   # PSNR / max relative error of this build against the oracle, in the line itself
         # (the maximum sits on the few pixels where a DISCRETE guidance plane flipped by a whole step: tests/test_gpu_vsr.py)
         assert d["psnr_vs_oracle_db"] > 58.0 and 0 <= d["max_rel_err"] < 0.5 and d["accuracy"]["p99_rel_err"] < 1e-2, d["accuracy"]
+        assert 0 <= d["accuracy"]["sr_stack_max_rel_err_identical_planes"] < 1e-3, d["accuracy"]   # north_star: 1e-3 relative (fp16 storage: ~1e-4)
         assert "oracle" in d["accuracy"]["tile"]
