@@ -501,10 +501,13 @@ def main():
                 achieved = flop / (ms * 1e-3) / 1e12
                 traffic, traffic_source = None, None
                 pmc = os.path.join(ROOT, "profiles", "r04_c2_deconv_f32_hbm_pmc.json")
-                if name == "sr_deconv_f32" and planes == 8 and (h, w, scale) == (540, 960, 2) and os.path.exists(pmc):
+                if name == "sr_deconv_dt_f32":
+                    pmc = os.path.join(ROOT, "profiles", "r04_c2_deconv_dt_f32_hbm_pmc.json")
+                if name in ("sr_deconv_f32", "sr_deconv_dt_f32") and (h, w, scale) == (540, 960, 2) and os.path.exists(pmc):
                     with open(pmc) as f:
-                        traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"]
-                    traffic_source = "profiles/r04_c2_deconv_f32_hbm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate run of the 8-plane launch)"
+                        traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"] * planes / 8.0
+                    traffic_source = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate run of the 8-plane launch" + \
+                        (")" if planes == 8 else f", scaled to {planes} planes: the traffic is per plane)")
                 roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / FP32_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source, launches_timed=launches,
                             avg_ms=round(ms, 4), algorithmic_flop_per_launch=flop, planes_per_launch=planes)
