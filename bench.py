@@ -34,8 +34,8 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "2")
 # (abort() inside torch conv -> MIOpen, no message); the plain heuristic fallback has not
 os.environ.setdefault("MIOPEN_DEBUG_ENABLE_AI_IMMED_MODE_FALLBACK", "0")
 os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")
-# HIP's default of four hardware queues is the measured optimum for this forward's 4-6 streams (3 queues -0.6 %, 5 or more -20 %: LAB_NOTES R4.7);
-# pinned here so that an inherited setting cannot move the number
+# HIP's default of four hardware queues is the measured optimum for this forward's four streams (3 queues -0.6 %; a fifth ACTIVE queue cost
+# 20 % while the forward used five streams: LAB_NOTES R4.7); pinned here so that an inherited setting cannot move the number
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 import numpy as np  # noqa: E402

@@ -140,7 +140,9 @@ class VSR(nn.Module):
     def _side_streams(self, dev):
         key = (dev.type, dev.index)
         if getattr(self, "_streams_key", None) != key:
-            self._streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+            # [0]: depth trunk; [1]: VOS trunk (pass 2 only) AND the shared planes' SR maps (pass 1 only) -- they never overlap, and with the main
+            # stream and FlowNetSD's this makes four streams: HIP's four hardware queues (a fifth ACTIVE queue costs 20 %: LAB_NOTES R4.7)
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
             self._streams_key = key
         return self._streams
 
@@ -264,7 +266,7 @@ class VSR(nn.Module):
                 # float32 configuration: the same overlap; the SR module keeps the planes' pre-fusion maps in `shared`
                 main = torch.cuda.current_stream(d.device)
                 x_first = d.permute(0, 3, 1, 2).contiguous()
-                s_sr = self._side_streams(d.device)[2]
+                s_sr = self._side_streams(d.device)[1]
                 s_sr.wait_stream(main)
                 with torch.cuda.stream(s_sr):
                     self.model.precompute_shared(x_first, shared, None)
@@ -279,7 +281,7 @@ class VSR(nn.Module):
                     # ... and their pre-fusion planes (the tail's output) at full resolution: both passes' tails skip them
                     S = self.model.upscale_factor
                     live["prefc"] = torch.empty((n_planes, 3, S * h, S * w), dtype=torch.float32, device=d.device)
-                s_sr = self._side_streams(d.device)[2]
+                s_sr = self._side_streams(d.device)[1]
                 s_sr.wait_stream(main)
                 with torch.cuda.stream(s_sr):
                     self.model.precompute_shared(x_first, shared, live)
