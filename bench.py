@@ -37,6 +37,7 @@ os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")
 # HIP's default of four hardware queues is the measured optimum for this forward's four streams (3 queues -0.6 %; a fifth ACTIVE queue cost
 # 20 % while the forward used five streams: LAB_NOTES R4.7); pinned here so that an inherited setting cannot move the number
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # (this image's default behaviour; = 0 costs the ~600 launches of a frame 2 %)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
