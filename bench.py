@@ -24,6 +24,8 @@ import argparse
 import json
 import os
 import platform
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,9 +37,10 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "2")
 os.environ.setdefault("MIOPEN_DEBUG_ENABLE_AI_IMMED_MODE_FALLBACK", "0")
 os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")
 # HIP's default of four hardware queues is the measured optimum for this forward's four streams (3 queues -0.6 %; a fifth ACTIVE queue cost
-# 20 % while the forward used five streams: LAB_NOTES R4.7); pinned here so that an inherited setting cannot move the number
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # (this image's default behaviour; = 0 costs the ~600 launches of a frame 2 %)
+# 20 % while the forward used five streams: LAB_NOTES R4.7); assigned unconditionally so that an inherited setting cannot move the
+# number, and printed in the JSON line (`env`)
+os.environ["GPU_MAX_HW_QUEUES"] = "4"
+os.environ["HIP_FORCE_DEV_KERNARG"] = "1"   # (this image's default behaviour; = 0 costs the ~600 launches of a frame 2 %)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -134,11 +137,12 @@ def cpu_baseline(scale: int, sizes=(64, 96, 128), budget_s: float = 75.0):
             break
         data = torch.from_numpy(synthetic_clip(0, 3, lr, lr))
         t0 = time.time()
+        taps = {} if first is None else None   # (references to tensors the forward holds anyway: no extra work inside the timed call)
         with torch.no_grad():
-            out = vsr_oracle.vsr_forward(P, data, None, upscale_factor=scale)
+            out = vsr_oracle.vsr_forward(P, data, None, upscale_factor=scale, taps=taps)
         pts.append((lr * lr, time.time() - t0))
         if first is None:
-            first = (lr, data, out)    # kept: the GPU forward on the same tile gives the line's accuracy fields
+            first = (lr, data, out, taps)    # kept: the GPU forward on the same tile gives the line's accuracy fields
     px = np.array([p[0] for p in pts], dtype=np.float64)
     sec = np.array([p[1] for p in pts], dtype=np.float64)
     if len(pts) >= 2:
@@ -147,6 +151,45 @@ def cpu_baseline(scale: int, sizes=(64, 96, 128), budget_s: float = 75.0):
         b, a = sec[0] / px[0], 0.0
     return dict(points=[(int(p), round(float(s), 2)) for p, s in pts], slope_s_per_px=float(b), intercept_s=float(a),
                 cores=cores, cores_available=avail, cpu=cpu_model(), first=first)
+
+
+# LR receptive radius of the SR net: conv_in 3x3 (1) + 3 steps x 2 up/down pairs (x4, k8 s4 p2: 1 LR pixel per pair; x2 k6 s2 p2 and x3 k7 s3 p2: 2)
+# + out deconv, conv_out, bilinear skip (<= 3), rounded up
+SR_LR_RADIUS = {4: 10, 3: 18, 2: 18}
+
+
+def plane_flip_report(build_taps, ref_taps, got_hwc, ref_hwc, scale, radius=None):
+    """The DISCRETE guidance planes of the two SR passes -- the uint8 flow pictures (planes 3, 4; flow_utils.py:4-24 via
+    video_super_resolution.py:28-35,46-52) and the 0/1 VOS mask (:54,:58-60) -- compared pixel by pixel between two evaluations of one
+    forward (`*_taps`: pass1_input / pass2_input [8,3,h,w], vos_mask), and the frame error OUTSIDE the receptive fields of the flipped
+    pixels: pass-1 flips reach pass 2 through the decimated pass-1 frame, so the excluded set is dilate(flips2 | mask flips |
+    dilate(flips1)), each dilation by the SR net's LR receptive radius.  got / ref: [H,W,3] frames (numpy float64).  -> dict"""
+    import torch.nn.functional as F
+    radius = SR_LR_RADIUS[scale] if radius is None else radius
+    cpu = lambda t: t.detach().float().cpu()
+    b1, r1, b2, r2 = cpu(build_taps["pass1_input"]), cpu(ref_taps["pass1_input"]), cpu(build_taps["pass2_input"]), cpu(ref_taps["pass2_input"])
+    h, w = b1.shape[-2:]
+    flips = lambda a, b: ((a[3] != b[3]) | (a[4] != b[4])).any(dim=0)          # [h,w]: any channel of either flow picture differs
+    m2 = lambda t: (cpu(t).reshape(-1, h, w)[0] != 0)
+    f1, f2, fm = flips(b1, r1), flips(b2, r2), m2(build_taps["vos_mask"]) != m2(ref_taps["vos_mask"])
+    dil = lambda m: F.max_pool2d(m[None, None].float(), 2 * radius + 1, 1, radius)[0, 0] > 0
+    excl = dil(f2 | fm | dil(f1))
+    keep = (~excl).repeat_interleave(scale, 0).repeat_interleave(scale, 1).numpy()
+    err = np.abs(got_hwc - ref_hwc)
+    rng = np.abs(ref_hwc).max()
+    out = dict(plane_flip_rate=dict(pass1_flow_pictures=round(float(f1.float().mean()), 6), pass2_flow_pictures=round(float(f2.float().mean()), 6),
+                                    vos_mask=round(float(fm.float().mean()), 6)),
+               flipped_pixels=dict(pass1_flow_pictures=int(f1.sum()), pass2_flow_pictures=int(f2.sum()), vos_mask=int(fm.sum()), of=int(h * w)),
+               continuous_planes_max_rel_diff=dict(   # depth planes (5, 6) and the estimate plane (7) of pass 2: continuous, no flips
+                   depth=float(f"{(b2[5:7] - r2[5:7]).abs().max().item() / max(r2[5:7].abs().max().item(), 1e-30):.3e}")),
+               excluded_fraction=round(float(excl.float().mean()), 4), radius_lr_px=radius)
+    if keep.any():
+        e = err[keep]
+        out.update(max_rel_err_outside=float(f"{e.max() / rng:.3e}"), p99_rel_err_outside=float(f"{np.percentile(e, 99) / rng:.3e}"),
+                   psnr_outside_db=round(float(10 * np.log10(255.0 ** 2 / max(float(np.mean(e ** 2)), 1e-30))), 2))
+    else:
+        out.update(max_rel_err_outside=None, p99_rel_err_outside=None, psnr_outside_db=None)
+    return out
 
 
 def accuracy_vs_oracle(model, scale, precision, dev, first=None, lr=64):
@@ -162,13 +205,23 @@ def accuracy_vs_oracle(model, scale, precision, dev, first=None, lr=64):
         torch.set_flush_denormal(True)
         P = {k: v.detach() for k, v in fill_module_(VSR(upscale_factor=scale).eval(), seed=0).state_dict().items()}
         data = torch.from_numpy(synthetic_clip(0, 3, lr, lr))
+        otaps = {}
         with torch.no_grad():
-            first = (lr, data, vsr_oracle.vsr_forward(P, data, None, upscale_factor=scale))
-    lr, data, ref = first
+            first = (lr, data, vsr_oracle.vsr_forward(P, data, None, upscale_factor=scale, taps=otaps), otaps)
+    lr, data, ref, ref_taps = first
     hf = torch.zeros((3, scale * lr, scale * lr, 3), dtype=torch.float32, device=dev)
-    with torch.no_grad():
-        got, _ = model(data.to(dev), None, hf, None, train=False)
+    model.plane_taps = {}
+    try:
+        with torch.no_grad():
+            got, _ = model(data.to(dev), None, hf, None, train=False)
+        build_taps = model.plane_taps
+    finally:
+        model.plane_taps = None
     got, ref = got.float().cpu().numpy().astype(np.float64), ref.numpy().astype(np.float64)
+    try:   # which part of the error is the discrete guidance planes
+        flips = plane_flip_report(build_taps, ref_taps, got[0], ref[0], scale)
+    except Exception as exc:   # noqa: BLE001  (an extra: must not cost the line)
+        flips = dict(error=repr(exc)[:200])
     # the SR stack alone on IDENTICAL planes (no discrete guidance plane between this build and the oracle): what the arithmetic itself does
     sr_only = None
     try:
@@ -187,7 +240,7 @@ def accuracy_vs_oracle(model, scale, precision, dev, first=None, lr=64):
     rng = np.abs(ref).max()
     return dict(psnr_vs_oracle_db=round(10 * np.log10(255.0 ** 2 / max(mse, 1e-30)), 2),
                 max_rel_err=float(f"{err.max() / rng:.3e}"), p99_rel_err=float(f"{np.percentile(err, 99) / rng:.3e}"),
-                sr_stack_max_rel_err_identical_planes=sr_only,
+                sr_stack_max_rel_err_identical_planes=sr_only, guidance_plane_flips=flips,
                 median_rel_err=float(f"{np.percentile(err, 50) / rng:.3e}"),
                 note="the guidance planes are DISCRETE (uint8 flow pictures, the 0/1 VOS mask): a rounding-level difference in a trunk flips "
                      "a few plane pixels by a whole step, which is where the maximum comes from; the percentiles describe the frame; "
@@ -222,6 +275,23 @@ def other_configs(progress, names=("C3B", "C5", "C2"), steps=5, warmup=2, timeou
         except subprocess.TimeoutExpired:
             out[name] = dict(error=f"no line within {timeout_s} s")
     return out
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` as a CHILD process (never an exec;
+    nothing in this process has touched the GPU yet), let its ranks print to this process's stdout / stderr -- rank 0 prints the one
+    JSON line -- and return its exit code."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: RCCL across processes needs it on this image)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print(f"[bench] --gpus {n_gpus} without a launcher: starting {' '.join(cmd[1:8])} ... as a child process", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -259,9 +329,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher: become one (before anything touches the GPU), forward the ranks' output and exit code
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    n_vis = torch.cuda.device_count()   # (counting devices does not initialise the GPU on this image)
+    if args.gpus > n_vis:   # (every rank says so and leaves before any of them has touched a GPU or opened the process group)
+        raise SystemExit(f"[bench rank {rank}] --gpus {args.gpus} needs {args.gpus} visible GPUs (one process per GPU, RCCL over xGMI); this box has "
+                         f"{n_vis}")
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -539,6 +615,7 @@ def main():
                                 precision=precision, parallelism=f"clip-dp{world}", clips=n_clips, scale=scale),
                     roofline=roof)
         line.update(extras)
+        line["env"] = {k: os.environ.get(k) for k in ("GPU_MAX_HW_QUEUES", "HIP_FORCE_DEV_KERNARG", "MIOPEN_FIND_MODE")}   # effective values
         if world == 1 and not args.no_cpu_baseline:
             progress("timing the CPU oracle on LR 64x64 / 96x96 / 128x128 tiles (about a minute)")
             torch.cuda.synchronize()

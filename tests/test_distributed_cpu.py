@@ -148,3 +148,39 @@ def test_gather_root_given_as_global_rank_in_a_subgroup():
         assert p.exitcode == 0
     assert shapes == [(1, 2, 3), (2, 2, 3)] and firsts == [1.0, 2.0]
     assert clip_vals == [10.0, 20.0]
+
+
+def test_bench_gpus_n_launches_itself_as_a_child_process(monkeypatch):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: bench.py starts `python -m
+    torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process before anything touches the GPU and exits
+    with the child's code.  The spawn is replaced by a recorder here; under a launcher (RANK set) it must not spawn again."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = list(cmd), env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(bench.torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU touched before the spawn")))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2", "--clips", "32"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2", "--clips", "32"]
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    # under a launcher whose world disagrees with --gpus: a clear message, no second spawn
+    seen.clear()
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert not seen and "WORLD_SIZE=1" in str(e.value.code)

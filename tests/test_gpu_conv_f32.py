@@ -120,6 +120,34 @@ def test_conv2d_f32_spatial_kernels_match_float64(case):
         assert (rest == 7.0).all(), "channels outside the slice were written"
 
 
+def test_thin_layer_with_a_kernel_wider_than_16_leaves_the_thin_spatial_kernel(monkeypatch):
+    """k_conv_f32_sp16 stages one kernel row of kw x 4 x 16 weights with one float4 per thread (256 threads:
+    kw <= 16).  A <= 16-out-channel layer with kw = 17 must not be routed there (router and launcher), and is still served correctly."""
+    monkeypatch.setattr(trunk_f32, "MIN_TILES", 0)
+    monkeypatch.setattr(trunk_f32, "MIN_WGS", 0)
+    N, C, H, W, Co, k = 1, 32, 24, 70, 16, 17
+    assert trunk_f32._route(N, C, H, W, Co, k, k, 1, 8, 8) != trunk_f32.SPATIAL_K
+    assert trunk_f32._route(N, C, H, W, Co, 11, 11, 1, 5, 5) == trunk_f32.SPATIAL_K
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.randn(N, C, H, W).astype(np.float32))
+    w = torch.from_numpy((rs.randn(Co, C, k, k) / np.sqrt(C * k * k)).astype(np.float32))
+    b = torch.from_numpy(rs.randn(Co).astype(np.float32))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=8)
+    wp = trunk_f32._pack(w.cuda().contiguous())
+    from video_super_resolution_amd import _lib as L
+    with pytest.raises(L.VsrHipError):   # the launcher refuses the spatial route for it (it used to compute with uninitialised LDS)
+        trunk_f32.conv2d_fused(x.cuda(), wp, None, b.cuda(), False, 0.0, Co, k, k, 1, 8, 8, 2)
+    for route in (0, 1):
+        got = trunk_f32.conv2d_fused(x.cuda(), wp, None, b.cuda(), False, 0.0, Co, k, k, 1, 8, 8, route).cpu().double()
+        assert (got - ref).abs().max().item() <= TOL * ref.abs().max().item(), route
+    m = trunk_f32.Conv2dF32(C, Co, k, 1, 8).cuda()
+    with torch.no_grad():
+        m.weight.copy_(w)
+        m.bias.copy_(b)
+        got = m(x.cuda()).cpu().double()
+    assert (got - ref).abs().max().item() <= TOL * ref.abs().max().item()
+
+
 def test_fused_sequential_and_concat_match_the_separate_passes(monkeypatch):
     """FusedSequential / depth.ChannelConcat (Conv2d -> BatchNorm2d -> ReLU in one launch, branches written into the concat buffer in
     place) against the same modules evaluated child by child on the stock operators."""

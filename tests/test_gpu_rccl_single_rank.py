@@ -92,3 +92,30 @@ def test_bench_under_the_distributed_launcher_with_one_rank(extra):
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     assert len(d["ranks"]["frames_per_s"]) == 1 and len(d["gather"]["root_wait_ms_per_round"]) == d["gather"]["rounds"]
     assert d["gather"]["root_resident_bytes"] >= 2 * 256 * 384 * 3 * 2     # K = 2 fp16 frames of 256 x 384 x 3 per clip
+
+
+def test_bench_force_dist_through_the_plain_entry():
+    """`python bench.py --gpus 1 --force-dist` (no launcher): the same entry the driver uses for N = 1 opens a one-rank RCCL group."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--lr-h", "64", "--lr-w", "96",
+           "--no-cpu-baseline", "--no-extras", "--force-dist"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MASTER_PORT"] = str(_free_port())
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["process_group"]["backend"] == "nccl" and d["n_gpus"] == 1 and d["env"]["GPU_MAX_HW_QUEUES"] == "4"
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_starts_the_launcher_and_fails_with_the_ranks_message():
+    """`python bench.py --gpus 2` by itself (how the driver calls N = 1): bench.py becomes the launcher -- a child
+    `torch.distributed.run` with two ranks -- and on a box with fewer GPUs every rank leaves with a device-count message (not a usage
+    error of the parent), before any of them has touched the GPU; the parent forwards the exit code."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the launch would succeed")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--lr-h", "64", "--lr-w", "96",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert "torch.distributed.run" in p.stderr and "needs 2 visible GPUs" in p.stderr, p.stderr[-3000:]
+    assert "launch N>1 with" not in p.stderr

@@ -92,6 +92,28 @@ def test_hourglass_fused_front(gpu_vsr, shape):
     same(fused, three, "trunk prediction", bar=1e-2)
 
 
+def test_hourglass_level_streams_without_the_fused_front(gpu_vsr):
+    """with the hourglass's per-level side streams on (VSR_HOURGLASS_STREAMS=1, `concurrent`) and the fused front off, the
+    level-1 arm ends in a SegMap (dense 16-channel branch maps): `_fan_out` records it on the consumer's stream segment by segment.
+    Same launches in another stream order: identical prediction."""
+    netg = gpu_vsr.DepthModule.model.netG
+    fr = torch.from_numpy(np.random.RandomState(9).randint(0, 256, (2, 70, 90, 3)).astype(np.float32)).cuda()
+    ex = HourglassExec(netg)
+    with torch.no_grad():
+        ex.fused_front = False
+        try:
+            serial = ex(fr).clone()
+            ex.concurrent = True
+            try:
+                side = ex(fr).clone()
+            finally:
+                ex.concurrent = False
+        finally:
+            ex.fused_front = True
+    torch.cuda.synchronize()
+    assert torch.equal(serial, side)
+
+
 def test_flownet2_exec(gpu_vsr):
     net = gpu_vsr.FlowModule.net
     x = torch.from_numpy(np.random.RandomState(2).randint(0, 256, (2, 3, 2, 64, 128)).astype(np.float32)).cuda()

@@ -3,7 +3,8 @@
 The launchers choose kernels by layer size: at the sizes of test_gpu_trunk_exec.py (<= 135x240) the LDS-patch kernels
 (>= 8192 pixels), the 128-channel tiles, the hourglass stem kernel, the streaming 1x1 and the four-phase patch kernel of the
 thin transposed convolutions never run.  Here every trunk runs at the size the benchmark runs it, against its float32
-master module on stock convolutions (same weights, same inputs), at the bars of the small-size tests; the kernel every layer
+master module on STOCK operators (`stock_trunks()`: trunk_f32.ENABLED = False -- the master must not be built from this
+repository's own float32 kernels; same weights, same inputs), at the bars of the small-size tests; the kernel every layer
 was routed to is logged (`vsr_last_route`) and the size-dependent ones are asserted to be among them.  One `VSR.forward` at
 540x960 in the fp16 configuration is compared with the fp32 configuration (exact float32 SR kernels, stock float32 trunks):
 PSNR and the 99th percentile of the absolute difference ("What's weak" 3)."""
@@ -13,7 +14,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import contextlib  # noqa: E402
+
 from video_super_resolution_amd import _lib as L  # noqa: E402
+from video_super_resolution_amd import trunk_f32  # noqa: E402
 from video_super_resolution_amd.trunk_exec import FlowNet2Exec, HourglassExec, OSVOSExec  # noqa: E402
 
 H, W = 540, 960
@@ -27,6 +31,17 @@ def _smooth_frames(n, h, w, seed):
     base = gaussian_filter(rs.uniform(0, 255, size=(h + pad, w + 2 * pad, 3)).astype(np.float32), sigma=(3, 3, 0))
     base = (base - base.min()) / (base.max() - base.min()) * 255.0
     return np.stack([np.floor(base[k:k + h, 2 * k:2 * k + w]) for k in range(n)]).astype(np.float32)
+
+
+@contextlib.contextmanager
+def stock_trunks():
+    """Every Conv2dF32 / ConvTranspose2dF32 / FusedSequential / ChannelConcat of the master modules on the stock operators."""
+    old = trunk_f32.ENABLED
+    trunk_f32.ENABLED = False
+    try:
+        yield
+    finally:
+        trunk_f32.ENABLED = old
 
 
 def _rel(a, ref):
@@ -53,7 +68,8 @@ def test_hourglass_exec_at_4x540x960(gpu_vsr):
     with torch.no_grad():
         ex = HourglassExec(netg)
         got, hist = _logged(lambda: ex(fr))
-        ref = netg(fr.permute(0, 3, 1, 2))
+        with stock_trunks():
+            ref = netg(fr.permute(0, 3, 1, 2).contiguous())
     err = _rel(got, ref)
     print(f"[hourglass 4x{H}x{W} fp16 executor vs fp32 master] max {err:.3e} of range")
     assert got.shape == ref.shape == (4, 1, H, W)
@@ -69,7 +85,8 @@ def test_flownet2_exec_at_2_pairs_512x960(gpu_vsr):
     with torch.no_grad():
         ex = FlowNet2Exec(net)
         got, hist = _logged(lambda: ex(x))
-        ref = net(x)
+        with stock_trunks():
+            ref = net(x)
     mx, mean = _rel(got, ref), (got - ref).abs().mean().item() / ref.abs().max().item()
     print(f"[FlowNet2 2x512x{W} fp16 executor vs fp32 master] max {mx:.3e} mean {mean:.3e} of range")
     assert got.shape == ref.shape == (2, 2, 512, W)
@@ -85,7 +102,8 @@ def test_osvos_exec_at_2x540x960(gpu_vsr):
     with torch.no_grad():
         ex = OSVOSExec(net)
         got, hist = _logged(lambda: ex(x))
-        ref = net(x)
+        with stock_trunks():
+            ref = net(x)
     err = _rel(got, ref)
     print(f"[OSVOS 2x{H}x{W} fp16 executor vs fp32 master] max {err:.3e} of range")
     assert got.shape == ref.shape
@@ -135,7 +153,8 @@ def test_trunks_at_1080x1920(gpu_vsr):
         # hourglass, one frame
         netg = gpu_vsr.DepthModule.model.netG
         got, hist = _logged(lambda: HourglassExec(netg)(fr[:1]))
-        ref = netg(fr[:1].permute(0, 3, 1, 2))
+        with stock_trunks():
+            ref = netg(fr[:1].permute(0, 3, 1, 2).contiguous())
         e = _rel(got, ref)
         print(f"[hourglass 1x{H2}x{W2}] max {e:.3e} of range")
         assert e < 1e-2 and "hg_front" in hist
@@ -145,7 +164,8 @@ def test_trunks_at_1080x1920(gpu_vsr):
         net = gpu_vsr.VOSModule.net
         x = (fr[:2] - gpu_vsr.VOSModule.meanval.to("cuda")).permute(0, 3, 1, 2).contiguous()
         got, hist = _logged(lambda: OSVOSExec(net)(x))
-        ref = net(x)
+        with stock_trunks():
+            ref = net(x)
         e = _rel(got, ref)
         print(f"[OSVOS 2x{H2}x{W2}] max {e:.3e} of range")
         assert e < 1e-2
@@ -157,7 +177,8 @@ def test_trunks_at_1080x1920(gpu_vsr):
         fc = fr[:2, 28:28 + 1024]                                       # StaticCenterCrop to multiples of 64 (tools.py:8-14)
         xp = fc.permute(3, 0, 1, 2).unsqueeze(0).contiguous()           # [1,3,2,1024,1920]
         got, hist = _logged(lambda: FlowNet2Exec(fnet)(xp))
-        ref = fnet(xp)
+        with stock_trunks():
+            ref = fnet(xp)
         mx, mean = _rel(got, ref), (got - ref).abs().mean().item() / ref.abs().max().item()
         print(f"[FlowNet2 1x1024x{W2}] max {mx:.3e} mean {mean:.3e} of range")
         assert mx < 2e-2 and mean < 2e-3

@@ -103,10 +103,17 @@ class xcheck:
 Q_UTD_BLOB_BYTES, Q_UTD_STRIP_WIDTH, Q_UTD_S2_BLOB_BYTES, Q_UTD_S2_STRIP_WIDTH, Q_TAIL_S2_BLOB_BYTES = range(5)
 
 
-def check(rc: int, what: str = "") -> None:
+def check(rc: int, what: str = "", lib=None) -> None:
+    """`lib`: the library that made the call (each has its own error buffer); by default the text of every loaded library is
+    shown, the one `load()` returns first (a call site that went through `load_xcheck()` directly is then still reported)."""
     if rc != 0:
-        msg = load().vsr_last_error().decode("utf-8", "replace")
-        raise VsrHipError(f"{what or 'vsr'} failed ({rc}): {msg}")
+        libs = [lib] if lib is not None else [l for l in (load(), _lib, _xlib) if l is not None]
+        msgs = []
+        for l in libs:
+            m = l.vsr_last_error().decode("utf-8", "replace")
+            if m and m not in msgs:
+                msgs.append(m)
+        raise VsrHipError(f"{what or 'vsr'} failed ({rc}): {' | '.join(msgs)}")
 
 
 def dptr(t: torch.Tensor, dtype=torch.float32) -> ctypes.c_void_p:
@@ -219,6 +226,14 @@ class RouteLog:
     def note(self, label: str):
         if self.enabled:
             self.calls.append((label, load().vsr_last_route().decode()))
+
+    def note_as(self, label: str, route: str):
+        """A launch whose route the caller names itself (the stock operator; a suffix on `vsr_last_route`)."""
+        if self.enabled:
+            self.calls.append((label, route))
+
+    def last(self) -> str:
+        return load().vsr_last_route().decode()
 
     def histogram(self):
         h = {}

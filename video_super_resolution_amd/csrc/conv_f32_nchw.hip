@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) k_conv_f32_sp16(const CF32 p) {
     const int col = lane & 15, kq = lane >> 4;
     const int tx = blockIdx.x % p.tiles_x, t2 = blockIdx.x / p.tiles_x, ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
     const int x0 = tx * TW, y0 = ty * TH;
-    const int np = p.kw * 16;                                // float4 pieces of one kernel row's weight block (<= 256)
+    const int np = p.kw * 16;                                // float4 pieces of one kernel row's weight block (<= 256: the launcher keeps kw <= 16)
     f4v wreg = {0.0f, 0.0f, 0.0f, 0.0f};
     auto wload = [&](int c0, int ky) __attribute__((always_inline)) {
         if (tid < np) {
@@ -388,11 +388,13 @@ int vsr_conv2d_f32_pack(const float* weight, float* packed, int Co, int C, int k
 // (stride 1 only).  Returns VSR_E_UNSUPPORTED when route 2 cannot serve the layer.
 static int launch_conv_f32(CF32& p, int route, hipStream_t st) {
     const bool plain_out = p.oy_mul == 1 && p.ox_mul == 1 && p.oy_off == 0 && p.ox_off == 0 && p.outH == p.Ho && p.outW == p.Wo;
-    const bool sp_legal = p.stride == 1 && plain_out && p.kw <= 33;
+    // (the thin kernel stages one kernel row of kw x 4 x 16 weights with one float4 per thread: kw <= 16)
+    const bool sp_legal = p.stride == 1 && plain_out && p.kw <= (p.Co <= 16 ? 16 : 33);
     // predict_flow-shaped layers: the K-sharing head kernel (route 0 and 1; measured 0.46 -> see profiles/r04_c2_route_table_after_tuning.txt)
     if (route != 2 && p.stride == 1 && plain_out && p.Co <= 4 && p.kh * p.kw >= 9 && p.C >= 256 && (long long)p.N * p.Ho * p.Wo <= 131072) {
         const long long gx = ((long long)p.N * p.Ho * p.Wo + 15) / 16;
         hipLaunchKernelGGL(k_conv_f32_head, dim3((unsigned)gx), dim3(64 * HEAD_WAVES), 0, st, p);
+        vsr::route("f32 head");
         return vsr::launched("conv2d_nchw_f32 (head)");
     }
     if (route == 2 && !sp_legal) return vsr::fail(VSR_E_UNSUPPORTED, "conv2d_nchw_f32: the spatial-reuse kernel serves stride 1 into a plain output only");
@@ -421,6 +423,7 @@ static int launch_conv_f32(CF32& p, int route, hipStream_t st) {
             else if (MT == 2) hipLaunchKernelGGL((k_conv_f32_sp<2, 2, 4>), grid, dim3(256), lds, st, p);
             else if (KC == 8) hipLaunchKernelGGL((k_conv_f32_sp<1, 4, 8>), grid, dim3(256), lds, st, p);
             else hipLaunchKernelGGL((k_conv_f32_sp<1, 4, 4>), grid, dim3(256), lds, st, p);
+            if (thin) vsr::route("f32 sp16"); else vsr::route("f32 sp<%d,%d>", MT, KC);
             return vsr::launched("conv2d_nchw_f32 (spatial)");
         }
         if (route == 2) return vsr::fail(VSR_E_UNSUPPORTED, "conv2d_nchw_f32: kernel row of %d taps x %d out-channels exceeds the spatial kernel's weight block", p.kw, BM);
@@ -431,6 +434,7 @@ static int launch_conv_f32(CF32& p, int route, hipStream_t st) {
     if ((p.co_pad & 127) == 0) hipLaunchKernelGGL(k_conv_f32<4>, dim3((unsigned)gx, p.co_pad / 128), dim3(256), 0, st, p);
     else if ((p.co_pad & 63) == 0) hipLaunchKernelGGL(k_conv_f32<2>, dim3((unsigned)gx, p.co_pad / 64), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_conv_f32<1>, dim3((unsigned)gx, p.co_pad / 32), dim3(256), 0, st, p);
+    vsr::route("f32 flat<%d>", (p.co_pad & 127) == 0 ? 4 : (p.co_pad & 63) == 0 ? 2 : 1);
     return vsr::launched("conv2d_nchw_f32");
 }
 

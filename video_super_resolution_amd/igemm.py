@@ -330,6 +330,11 @@ class SegMap:
     def device(self):
         return self.segs[0][0].device
 
+    def record_stream(self, stream):
+        """torch.Tensor.record_stream for every segment (a SegMap produced on a side stream and read on another)."""
+        for t, _ in self.segs:
+            t.record_stream(stream)
+
 
 def _seg_args(t, coff, c):
     """(pointer array, ld array, coff array, nseg, keep-alive) of a plain tensor slice or a SegMap for vsr_resize_add_segs_nhwc_f16."""

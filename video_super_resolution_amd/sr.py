@@ -357,7 +357,7 @@ class SRProjectionModule(nn.Module):
             S = self.upscale_factor
             kept = torch.empty((n, 3, S * h, S * w), dtype=torch.float32, device=x.device)
             self._f32_planes(x, P, self._const_map(P, h, w, x.device), None, kept)
-            shared["prefc_f32"] = kept
+            shared["prefc_f32"], shared["key_f32"] = kept, (self._pack_key, h, w, self.fc[0].in_features, S, n)
             return
         if self.precision != "fp16" or self.block.num_groups != 6:
             raise ValueError("precompute_shared: the fp16 configuration with six groups only (or the float32 configuration)")
@@ -443,7 +443,9 @@ class SRProjectionModule(nn.Module):
         # the same values: identical frames (tests/test_gpu_sr.py::test_f32_shared_planes_bit_identical).
         S = self.upscale_factor
         n_sh = int(shared.get("n", 0)) if (shared is not None and taps is None) else 0
-        kept = shared.get("prefc_f32") if n_sh else None
+        # (the key: weights + geometry, as in _forward_f16; the caller guarantees the leading planes are the same)
+        skey32 = (self._pack_key, h, w, N, S, n_sh)
+        kept = shared.get("prefc_f32") if (n_sh and shared.get("key_f32") == skey32) else None
         reuse = kept is not None and 0 < n_sh < N and tuple(kept.shape) == (n_sh, 3, S * h, S * w) and kept.device == dev
         prefc = torch.empty((N, 3, S * h, S * w), dtype=torch.float32, device=dev)
         if reuse:
@@ -452,7 +454,7 @@ class SRProjectionModule(nn.Module):
         else:
             self._f32_planes(x, P, cmap, taps, prefc)
             if 0 < n_sh < N:
-                shared["prefc_f32"] = prefc[:n_sh]
+                shared["prefc_f32"], shared["key_f32"] = prefc[:n_sh].clone(), skey32   # (a copy: a view would keep all N planes alive)
         if taps is not None:
             taps[f"prefc{self.num_steps - 1}"] = prefc
         out = torch.empty((1, 3, S * h, S * w), dtype=torch.float32, device=dev)

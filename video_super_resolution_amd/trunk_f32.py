@@ -85,7 +85,7 @@ def _route(N, C, H, W, Co, kh, kw, stride, pad_y, pad_x) -> int:
     # spatial-reuse kernels: <= 16 out-channels from 3x3 up (112 vs 41 flat / 50 stock TFLOP/s on 4 x 540 x 960 64 -> 16 11x11), 32
     # out-channels from 5x5 up (83-111 vs 76-79 / 50-98), the RGB stems from 5x5 up (3 -> 128 7x7: 1.28 vs 3.83 / 2.59 ms); with 64+
     # out-channels the flat kernel's 128-pixel blocks win (61 vs 94)
-    if SPATIAL and stride == 1 and kh * kw >= 9 and kw <= 33 and (C > 4 or kh * kw >= 25) and \
+    if SPATIAL and stride == 1 and kh * kw >= 9 and kw <= (16 if Co <= 16 else 33) and (C > 4 or kh * kw >= 25) and \
             (Co <= 16 or ((co_pad == 32 or C <= 4) and kh * kw >= 25) or MIN_TILES == 0):
         thin = Co <= 16
         th = 16 if (thin or bm == 32) else 8
@@ -114,6 +114,9 @@ def conv2d_fused(x, wp, scale, shift, act, slope, co, kh, kw, stride, pad_y, pad
     assert out.is_contiguous() and out.shape[0] == N and out.shape[2:] == (Ho, Wo), (out.shape, (N, co, Ho, Wo))
     L.check(L.load().vsr_conv2d_act_nchw_f32(L.dptr(x), L.dptr(wp), L.optr(scale), L.optr(shift), int(act), L.cf(slope), L.dptr(out), out.shape[1], coff,
                                              N, C, H, W, co, kh, kw, stride, pad_y, pad_x, route, L.stream()), "conv2d_act_nchw_f32")
+    if L.ROUTES.enabled:   # (the full-size parity tests log which kernel every layer ran on)
+        L.ROUTES.note_as(f"conv N{N} {H}x{W} c{C}->{co} k{kh}x{kw} s{stride}",
+                         L.ROUTES.last() + (" +bn" if scale is not None else "") + (" ->slice" if out.shape[1] != co else ""))
     return out
 
 
@@ -156,6 +159,9 @@ def run_conv_group(conv, bn, act, x, out=None, coff=0):
     """Conv2dF32 [-> BatchNorm2d (eval)] [-> ReLU / LeakyReLU] in one launch; None when the layer is not served by the own kernels."""
     route = _conv_route(conv, x)
     if route == STOCK:
+        if L.ROUTES.enabled:
+            co, _, kh, kw = conv.weight.shape
+            L.ROUTES.note_as(f"conv N{x.shape[0]} {x.shape[2]}x{x.shape[3]} c{x.shape[1]}->{co} k{kh}x{kw} s{conv.stride[0]}", "stock")
         return None
     if bn is not None and (bn.training or bn.running_mean is None):
         return None

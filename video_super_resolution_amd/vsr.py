@@ -297,7 +297,8 @@ class VSR(nn.Module):
             # stack evaluates its tail and fusion MLP at exactly those (identical values, 1/16 of the tail work)
             # planes 0-2 (the LR frames) are the same in both SR calls (:40, :62): their FeedbackBlock maps are computed here
             # and kept for pass 2 (sr.py:_forward_f16 `shared`; identical values, 3/8 of pass 2's trunk not recomputed)
-            mid = self.model(self._assemble(d, pics, z, est), decimate=True, shared=shared)[0]  # [3,h,w] = F.interpolate(out1,(h,w))[0]
+            x1 = self._assemble(d, pics, z, est)
+            mid = self.model(x1, decimate=True, shared=shared)[0]  # [3,h,w] = F.interpolate(out1,(h,w))[0]
 
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
             mark()
@@ -305,6 +306,8 @@ class VSR(nn.Module):
             pics2, z2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3))
             mark()
             x8 = self._assemble(d, pics2, z2, mid.contiguous(), mask.contiguous())   # plane 7: mid, zero where mask != 0 (:58-60)
+            if getattr(self, "plane_taps", None) is not None:   # (measurement hook: the SR inputs of both passes and the mask, bench.py / tests)
+                self.plane_taps.update(pass1_input=x1.clone(), pass2_input=x8.clone(), vos_mask=mask.clone(), pass1_decimated=mid.clone())
         # ---- pass 2 SR (:62-64): the reference's only call outside no_grad.  Under the caller's no_grad or in eval mode it
         # runs the kernels; in training mode with autograd on it is differentiable (SRProjectionModule.forward)
         out = self.model(x8, shared=shared).permute(0, 2, 3, 1)
