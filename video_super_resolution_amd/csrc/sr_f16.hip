@@ -1307,7 +1307,7 @@ k_fc_planes_skip4(const float* __restrict__ raw, const float* __restrict__ x, co
 
 namespace vsr {
 int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
-                int diag, hipStream_t stream);
+                int diag, hipStream_t stream, void* out2 = nullptr);
 int utd3_set_stamps(void* buf);
 int tail3_set_stamps(void* buf, int totals_only);
 size_t utd_s2_blob_bytes();
@@ -1394,6 +1394,17 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
                        (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
     return vsr::launched("sr_utd");
 #endif
+}
+
+int vsr_sr_utd_post_f16(const void* in, const void* blob, void* out, void* out_post, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                        vsr_stream_t stream) {
+    VSR_REQUIRE(in && blob && out && out_post, "sr_utd_post: null pointer");
+    VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg != 0 && rows_per_seg >= -65535 && N <= 65535, "sr_utd_post: bad shape");
+    VSR_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_post) & 15) == 0,
+                "sr_utd_post: pointers must be 16-byte aligned");
+    VSR_REQUIRE(out_post != out && out_post != in, "sr_utd_post: out_post must be a tensor of its own");
+    return vsr::launch_utd3(in, blob, out, N, h, w, rows_per_seg, slopes_le_one, 0, vsr::S(stream), out_post);
 }
 
 int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* in1, const float* w1, int ldw1,

@@ -33,13 +33,21 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 constexpr int UTD3_LR_PAD = 2 * LR_SLOT + 16 * (256 - LR_COLS * 4);   // where the lanes without an LR piece store (slot offset + lane)
 constexpr int UTD3_LDS = PART_BYTES + LR_BYTES + UTD3_LR_PAD;   // no HR ring: the x4 map never leaves the registers
 
-template <bool ALLMAX, int DIAG>
+constexpr int OROW = 32 * 64;   // POST: one finished output row (32 pixels x 32 fp16 channels, lr_off swizzle), double buffered by row parity
+
+// POST = 1: the NEXT group's uptran 1x1 + PReLU (SRProjectionModule.py:55-61 under zero fill: lr[j+3] -> the slice of uptranBlocks[j+3] that
+// reads it) applied to every finished output row and written to `out2` as well -- the launch of k_chain1x1_s<1,1,false> between the two
+// stages of a step, folded into this kernel: the reduce threads leave the row (fp16, as stored) in LDS too, and one step later each wave
+// multiplies one (out-channel tile, pixel tile) quadrant of it: 1 MFMA + 6 VALU + 1 store per wave and row, in the gaps of phase A.
+// Same operands, same MFMA, same activation as the chain kernel: bit-identical `out2`.
+template <bool ALLMAX, int DIAG, int POST>
 __global__ void __launch_bounds__(256)
 k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _Float16* __restrict__ out, int h, int w,
-       int rows_per_seg, int flat_n) {
+       int rows_per_seg, int flat_n, _Float16* __restrict__ out2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const part = smem;                 // 2 x 4 fp32 partial tiles
     unsigned char* const lrr = smem + PART_BYTES;     // 3 LR rows
+    unsigned char* const orow = smem + UTD3_LDS;      // POST: 2 finished output rows
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -105,6 +113,19 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     const float a_up = fpar[96], a_dt = fpar[97], a_dn = fpar[98];
     const h2 a_up2 = {(_Float16)a_up, (_Float16)a_up}, a_dt2 = {(_Float16)a_dt, (_Float16)a_dt};
     const bool up_max = ALLMAX || a_up <= 1.0f, dt_max = ALLMAX || a_dt <= 1.0f;
+    // POST: this wave's quadrant of the 1x1 = out-channel tile wv >> 1, pixel tile wv & 1
+    const int pmt = wv >> 1, pnt = wv & 1;
+    h8 Apost;
+    f4 bpost = {0.0f, 0.0f, 0.0f, 0.0f};
+    h2 a_post2 = {(_Float16)1.0f, (_Float16)1.0f};
+    bool post_max = true;
+    if (POST) {
+        Apost = *reinterpret_cast<const h8*>(blob + BLOB_CO + (pmt * 64 + lane) * 16);
+        const float* cpar = reinterpret_cast<const float*>(blob + BLOB_CO + 4096);
+        bpost = *reinterpret_cast<const f4*>(cpar + 16 * pmt + 4 * g);
+        a_post2 = h2{(_Float16)cpar[32], (_Float16)cpar[32]};
+        post_max = ALLMAX || cpar[32] <= 1.0f;
+    }
     for (;;) {   // one march per trip (grid mode: one trip)
     int x0, n, r0, r1;
     if (flat_n) {
@@ -260,6 +281,7 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
             asm volatile("" : "+v"(a));
             const unsigned off = red_ok ? a : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_buffer_store_b64(u2{u.lo, u.hi}, out_rsrc, off, 0, 0);
+            if (POST) *reinterpret_cast<u2*>(orow + (i & 1) * OROW + lr_off(rj, rc4 >> 1) + 8 * (rc4 & 1)) = u2{u.lo, u.hi};
         }
         if (j < 20 || (j >= 24 && j < 28)) asm volatile("" : "+v"(u.s[e]));   // pin the stage where it is written (and keep
         else if (j < 24) asm volatile("" : "+v"(u.t[e]));                      // the SLP vectorizer from re-packing it)
@@ -273,6 +295,39 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
         for (int k = 0; k < 4; ++k) pr[k] = *reinterpret_cast<const f4*>(pbase + part_rd + k * PART_W_PITCH);
 #pragma unroll
         for (int j = 0; j < 31; ++j) red_stage(j, i, pr, u);
+    };
+    // POST: the 1x1 on finished row i (its fp16 values lie in orow[i & 1] since the barrier that followed its reduce): this wave's quadrant.
+    // Single-instruction stages like the reduce's, placed by the step schedule: 0 operand from LDS, 1 MFMA, 2-3 convert, 4-5 slope
+    // multiply, 6-7 max / min, 8 store (rows outside [r0, r1) and pixels outside the strip / image: out-of-range offset, dropped)
+    const __amdgpu_buffer_rsrc_t out2_rsrc = __builtin_amdgcn_make_buffer_rsrc(POST ? out2 : out, 0, (int)((size_t)n_planes * h * w * NF * 2), 0x00020000);
+    struct PostU {
+        h8 b;
+        f4 acc;
+        h2 c[2], m[2], r[2];
+    };
+    const int ppx = 16 * pnt + l15;
+    const bool post_px_ok = ppx < TX && x0 + ppx < w;
+    auto post_stage = [&](int j, int i, PostU& u) __attribute__((always_inline)) {
+        if (j == 0) u.b = *reinterpret_cast<const h8*>(orow + (i & 1) * OROW + lr_off(ppx, g));
+        else if (j == 1) u.acc = mfma16(Apost, u.b, bpost);
+        else if (j < 4) { u.c[j - 2] = __builtin_convertvector(f2v{u.acc[2 * (j - 2)], u.acc[2 * (j - 2) + 1]}, h2); asm volatile("" : : "v"(u.c[j - 2])); }
+        else if (j < 6) { u.m[j - 4] = u.c[j - 4] * a_post2; asm volatile("" : : "v"(u.m[j - 4])); }
+        else if (j < 8) {
+            u.r[j - 6] = post_max ? __builtin_elementwise_max(u.c[j - 6], u.m[j - 6]) : __builtin_elementwise_min(u.c[j - 6], u.m[j - 6]);
+            asm volatile("" : : "v"(u.r[j - 6]));
+        } else {
+            unsigned a = (unsigned)(((((size_t)n * h + i) * w + x0 + ppx) * NF + 16 * pmt + 4 * g) * 2);
+            asm volatile("" : "+v"(a));
+            const unsigned off = (post_px_ok && i >= r0 && i < r1) ? a : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_buffer_store_b64(u2{__builtin_bit_cast(unsigned, u.r[0]), __builtin_bit_cast(unsigned, u.r[1])}, out2_rsrc, off, 0, 0);
+        }
+    };
+    auto post_row = [&](int i) __attribute__((always_inline)) {
+        if (POST) {
+            PostU u;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) post_stage(j, i, u);
+        }
     };
     // whole deconv -> PReLU -> 1x1 -> PReLU of one HR row (prologue / first and last steps): unit by unit, fenced, so
     // that this cold path does not set the kernel's register peak
@@ -371,13 +426,20 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
         ShU sh[4];
         f4 pr[4], accA[2][2][2], accB[2][2][2], a2A[2][2][2], a2B[2][2][2];
         RedU ru;
+        PostU pu;
         ActU uA[4], uB[4], fA[4], fB[4];
         VSR_FENCE();
-        // ---- A: partial tiles of row i-3 requested in the first gaps, reduced one VALU per gap from slot 6 on
+        // ---- A: partial tiles of row i-3 requested in the first gaps, reduced one VALU per gap from slot 6 on; POST: the 1x1 on row
+        //      i-4 (reduced in the step before, in LDS since that step's barrier): operand in slot 4, MFMA in slot 9, 6 VALU + the store behind
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             dmf(0, s, Bf, accA);
             if (s < 4) pr[s] = *reinterpret_cast<const f4*>(part_prev + part_rd + s * PART_W_PITCH);
+            if (POST) {
+                if (s == 4) post_stage(0, i - 4, pu);
+                else if (s == 9) post_stage(1, i - 4, pu);
+                else if (s >= 14 && s < 28 && ((s - 14) & 1) == 0) post_stage(2 + (s - 14) / 2, i - 4, pu);
+            }
             if (s >= 6) {
 #pragma unroll
                 for (int v = ((s - 6) * 31) / 26; v < ((s - 5) * 31) / 26; ++v) red_stage(v, i - 3, pr, ru);
@@ -478,6 +540,7 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
         f4 accd[2][2];
         if (i - 3 >= r0) reduce_store(i - 3, part_prev);
         __syncthreads();
+        if (i - 3 >= r0) post_row(i - 3);
         h8 obN[4][2];
         if (row_ok) p1_plain(Bf, obN, edgec);
         else zero_row(obN);
@@ -499,6 +562,7 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
         int i = r0;
         for (; i < i_st; ++i) step_plain(i, obP, edgec);
         for (; i < i_en; ++i) step_steady(i, obP, edgec);
+        if (POST && i_en > i_st) post_row(i_en - 4);   // (a steady step leaves the 1x1 of the row it reduced to the next one)
         for (; i < r1; ++i) step_plain(i, obP, edgec);
     };
     if (edge_strip) march(BoolC<true>{}); else march(BoolC<false>{});
@@ -512,6 +576,7 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     // last step), r1-1 (group G(r1-1) in obP, not yet convolved)
     if (r1 - 3 >= r0) reduce_store(r1 - 3, part + (part_cur ^ PART_BUF));
     __syncthreads();
+    if (r1 - 3 >= r0) post_row(r1 - 3);
     {
         f4 accd[2][2];
         down_plain(obP, accd);
@@ -519,7 +584,12 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     }
     if (r1 - 2 >= r0) reduce_store(r1 - 2, part + part_cur);
     __syncthreads();
+    if (r1 - 2 >= r0) post_row(r1 - 2);
     reduce_store(r1 - 1, part + (part_cur ^ PART_BUF));
+    if (POST) {
+        __syncthreads();
+        post_row(r1 - 1);
+    }
     if (!flat_n) break;
     f0 += r1 - r0;
     if (f0 >= f_end) break;
@@ -536,34 +606,40 @@ int utd3_set_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stam
 #endif
 
 // launch of the fused stage on k_utd3 (called by vsr_sr_utd_f16, which has validated the arguments)
+// out2 != nullptr: the POST = 1 build (the next group's uptran 1x1 on every output row, written to out2)
 int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
-                int diag, hipStream_t stream) {
-    typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int, int);
+                int diag, hipStream_t stream, void* out2) {
+    typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int, int, _Float16*);
 #if VSR_X
-    static const kern_t kerns[4] = {k_utd3<false, 0>, k_utd3<true, 0>, k_utd3<true, 1>, k_utd3<true, 2>};
+    static const kern_t kerns[6] = {k_utd3<false, 0, 0>, k_utd3<true, 0, 0>, k_utd3<true, 1, 0>, k_utd3<true, 2, 0>, k_utd3<false, 0, 1>, k_utd3<true, 0, 1>};
+    constexpr int NK = 6, POST0 = 4;
+    if (out2) diag = 0;
 #else
-    static const kern_t kerns[2] = {k_utd3<false, 0>, k_utd3<true, 0>};
+    static const kern_t kerns[4] = {k_utd3<false, 0, 0>, k_utd3<true, 0, 0>, k_utd3<false, 0, 1>, k_utd3<true, 0, 1>};
+    constexpr int NK = 4, POST0 = 2;
     diag = 0;
 #endif
+    constexpr int LDS_POST = UTD3_LDS + 2 * OROW;
+    const int lds = out2 ? LDS_POST : UTD3_LDS;
     static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
     if (!vsr::device_marked(attr_devs)) {
-        for (kern_t k : kerns)
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, UTD3_LDS) != hipSuccess)
-                return vsr::fail(VSR_E_LAUNCH, "sr_utd3: cannot reserve %d bytes of LDS", UTD3_LDS);
+        for (int q = 0; q < NK; ++q)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[q]), hipFuncAttributeMaxDynamicSharedMemorySize, q >= POST0 ? LDS_POST : UTD3_LDS) != hipSuccess)
+                return vsr::fail(VSR_E_LAUNCH, "sr_utd3: cannot reserve %d bytes of LDS", LDS_POST);
         vsr::mark_device(attr_devs);
     }
     if ((size_t)N * h * w * NF * 2 >= (1ull << 31)) return vsr::fail(VSR_E_UNSUPPORTED, "sr_utd3: tensors beyond 2 GiB");
-    const kern_t k = diag ? kerns[1 + diag] : kerns[slopes_le_one ? 1 : 0];
+    const kern_t k = out2 ? kerns[POST0 + (slopes_le_one ? 1 : 0)] : (diag ? kerns[1 + diag] : kerns[slopes_le_one ? 1 : 0]);
     if (rows_per_seg < 0) {   // flat mode: -rows_per_seg workgroups share the N * strips * h rows evenly
         const long long total = (long long)N * vsr::cdiv(w, TX) * h;
         const unsigned nwg = (unsigned)(total < -rows_per_seg ? total : -rows_per_seg);
-        hipLaunchKernelGGL(k, dim3(nwg, 1, 1), dim3(256), UTD3_LDS, stream, (const _Float16*)in, (const unsigned char*)blob,
-                           (_Float16*)out, h, w, 0, N);
+        hipLaunchKernelGGL(k, dim3(nwg, 1, 1), dim3(256), lds, stream, (const _Float16*)in, (const unsigned char*)blob,
+                           (_Float16*)out, h, w, 0, N, (_Float16*)out2);
         return vsr::launched("sr_utd3");
     }
     const unsigned strips = vsr::cdiv(w, TX), segs = vsr::cdiv(h, rows_per_seg);
-    hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(256), UTD3_LDS, stream, (const _Float16*)in, (const unsigned char*)blob,
-                       (_Float16*)out, h, w, rows_per_seg, 0);
+    hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(256), lds, stream, (const _Float16*)in, (const unsigned char*)blob,
+                       (_Float16*)out, h, w, rows_per_seg, 0, (_Float16*)out2);
     return vsr::launched("sr_utd3");
 }
 
