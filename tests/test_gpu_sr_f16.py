@@ -91,6 +91,52 @@ def test_stage_row_segments_agree(gpu_vsr_f16):
             assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 7), (1, 9, 40), (3, 20, 70), (1, 2, 2), (1, 1, 31), (1, 33, 31), (2, 37, 95), (5, 48, 64)])
+@pytest.mark.parametrize("rps", [0, 6, 1, -3, -7, -64, -1000])
+def test_stage_with_fused_uptran_bit_identical(gpu_vsr_f16, shape, rps):
+    """vsr_sr_utd_post_f16 (k_utd3<.., POST = 1>: the next group's uptran 1x1 + PReLU applied to every finished output row inside the
+    stage's launch) against the two launches it replaces -- vsr_sr_utd_f16, then vsr_sr_chain1x1_f16 on its output: both tensors bit
+    for bit, over whole marches, row segments (recomputed halo, 1-row segments) and the flat split (shares spanning strips / planes)."""
+    from video_super_resolution_amd import _lib as L
+    m = gpu_vsr_f16.model
+    N, h, w = shape
+    P = m._packed()
+    assert 0 in P["utd_post"] and 3 not in P["utd_post"]      # six groups: stage 0 is followed by another stage, stage 3 is not
+    a = torch.from_numpy((np.random.RandomState(h * 100 + w + N).randn(N, h, w, 32) * 20).astype(np.float16)).cuda()
+    lib = L.load()
+    ref = torch.empty((N, h, w, 32), dtype=torch.float16, device="cuda")
+    L.check(lib.vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(P["utd"][0], torch.uint8), L.dptr(ref, torch.float16), N, h, w, rps or h, 0, 1, L.stream()))
+    ref_post = m._chain([dict(ins=[(ref.view(N, h * w, 32), P["ut_w"][3], 32 * 4)], prev=None, bias=P["ut_b"][3], slope=P["ut_a"][3])], N, h * w, keep=[True])[0]
+    out = torch.full((N, h, w, 32), float("nan"), dtype=torch.float16, device="cuda")
+    post = torch.full((N, h, w, 32), float("nan"), dtype=torch.float16, device="cuda")
+    L.check(lib.vsr_sr_utd_post_f16(L.dptr(a, torch.float16), L.dptr(P["utd_post"][0], torch.uint8), L.dptr(out, torch.float16), L.dptr(post, torch.float16),
+                                    N, h, w, rps or h, 1, L.stream()))
+    assert torch.isfinite(post.float()).all()
+    assert torch.equal(out, ref)
+    assert torch.equal(post.view(N, h * w, 32), ref_post)
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (9, 40), (37, 95)])
+def test_forward_with_fused_uptran_bit_identical(gpu_vsr_f16, shape):
+    """The whole SR forward with the uptran slice fused into the first stage of every step (default) and as its own launch."""
+    import copy
+    m = copy.deepcopy(gpu_vsr_f16.model)
+    h, w = shape
+    x = torch.from_numpy(np.random.RandomState(h * 7 + w).randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    assert m.fuse_uptran
+    with torch.no_grad():
+        fused = m(x).clone()
+        m.fuse_uptran = False
+        apart = m(x).clone()
+        # ... and with a slope > 1 in the fused 1x1 (the select build k_utd3<false, .., 1>)
+        m.block.uptranBlocks[3][1].weight.fill_(1.5)
+        apart2 = m(x).clone()
+        m.fuse_uptran = True
+        fused2 = m(x).clone()
+    assert torch.equal(fused, apart)
+    assert not m._packed()["post_slopes_le_one"] and torch.equal(fused2, apart2) and not torch.equal(fused2, fused)
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 7), (1, 9, 40), (1, 17, 64)])
 def test_deconv_only_mode(gpu_vsr_f16, shape):
     m = gpu_vsr_f16.model

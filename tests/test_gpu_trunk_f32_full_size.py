@@ -185,8 +185,10 @@ def test_frame_error_at_540x960_is_attributable_to_flipped_guidance_pixels(gpu_v
                 # measured (frame 0): 298 + 1642 of 518,400 flow-picture pixels flipped, no mask pixel; whole frame 8.5e-2 of range, and
                 # 2.1e-7 on the 24 % of the frame outside the flipped pixels' receptive fields: the float32 configuration's error IS the
                 # flips (uint8(floor(255 col)) of flow_utils.py:24 is discontinuous at every grey level; the trunks differ by 4e-6 of range)
-                assert max(fr.values()) < 2e-2, rep
-                assert rep["excluded_fraction"] < 0.97 and rep["max_rel_err_outside"] is not None, rep
+                # (frame 1 is recurrent -- its estimate plane and, through pass 1, everything behind it start from frame 0's flips: 9,511
+                # flow-picture pixels and 2 mask pixels flipped, 98 % of the frame inside a receptive field, 3.1e-7 on the rest)
+                assert max(fr.values()) < (2e-2 if t == 0 else 5e-2), rep
+                assert rep["excluded_fraction"] < (0.9 if t == 0 else 0.995) and rep["max_rel_err_outside"] is not None, rep
                 assert rep["max_rel_err_outside"] < 1e-5, rep          # north star: 1e-3 relative fp32
             else:
                 # fp16 trunks differ by ~1e-3 of range: a sizeable share of the uint8 flow pictures moves by one grey level, so (almost)

@@ -48,6 +48,8 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     unsigned char* const part = smem;                 // 2 x 4 fp32 partial tiles
     unsigned char* const lrr = smem + PART_BYTES;     // 3 LR rows
     unsigned char* const orow = smem + UTD3_LDS;      // POST: 2 finished output rows
+    unsigned char* const postw = orow + 2 * OROW;     // POST: the 1x1's two weight fragments [mt][lane] + bias[32] (read at the point of use:
+                                                      // as loop-invariant registers they were spilled and reloaded inside the steady loop)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,16 +117,15 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     const bool up_max = ALLMAX || a_up <= 1.0f, dt_max = ALLMAX || a_dt <= 1.0f;
     // POST: this wave's quadrant of the 1x1 = out-channel tile wv >> 1, pixel tile wv & 1
     const int pmt = wv >> 1, pnt = wv & 1;
-    h8 Apost;
-    f4 bpost = {0.0f, 0.0f, 0.0f, 0.0f};
     h2 a_post2 = {(_Float16)1.0f, (_Float16)1.0f};
     bool post_max = true;
     if (POST) {
-        Apost = *reinterpret_cast<const h8*>(blob + BLOB_CO + (pmt * 64 + lane) * 16);
         const float* cpar = reinterpret_cast<const float*>(blob + BLOB_CO + 4096);
-        bpost = *reinterpret_cast<const f4*>(cpar + 16 * pmt + 4 * g);
+        if (tid < 128) *reinterpret_cast<h8*>(postw + tid * 16) = *reinterpret_cast<const h8*>(blob + BLOB_CO + tid * 16);
+        else if (tid < 160) *reinterpret_cast<float*>(postw + 2048 + (tid - 128) * 4) = cpar[tid - 128];
         a_post2 = h2{(_Float16)cpar[32], (_Float16)cpar[32]};
         post_max = ALLMAX || cpar[32] <= 1.0f;
+        // (visible to every wave after the prologue's first barrier)
     }
     for (;;) {   // one march per trip (grid mode: one trip)
     int x0, n, r0, r1;
@@ -301,15 +302,18 @@ k_utd3(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     // multiply, 6-7 max / min, 8 store (rows outside [r0, r1) and pixels outside the strip / image: out-of-range offset, dropped)
     const __amdgpu_buffer_rsrc_t out2_rsrc = __builtin_amdgcn_make_buffer_rsrc(POST ? out2 : out, 0, (int)((size_t)n_planes * h * w * NF * 2), 0x00020000);
     struct PostU {
-        h8 b;
+        h8 a, b;
         f4 acc;
         h2 c[2], m[2], r[2];
     };
     const int ppx = 16 * pnt + l15;
     const bool post_px_ok = ppx < TX && x0 + ppx < w;
     auto post_stage = [&](int j, int i, PostU& u) __attribute__((always_inline)) {
-        if (j == 0) u.b = *reinterpret_cast<const h8*>(orow + (i & 1) * OROW + lr_off(ppx, g));
-        else if (j == 1) u.acc = mfma16(Apost, u.b, bpost);
+        if (j == 0) {
+            u.b = *reinterpret_cast<const h8*>(orow + (i & 1) * OROW + lr_off(ppx, g));
+            u.a = *reinterpret_cast<const h8*>(postw + (pmt * 64 + lane) * 16);
+            u.acc = *reinterpret_cast<const f4*>(postw + 2048 + (16 * pmt + 4 * g) * 4);
+        } else if (j == 1) u.acc = mfma16(u.a, u.b, u.acc);
         else if (j < 4) { u.c[j - 2] = __builtin_convertvector(f2v{u.acc[2 * (j - 2)], u.acc[2 * (j - 2) + 1]}, h2); asm volatile("" : : "v"(u.c[j - 2])); }
         else if (j < 6) { u.m[j - 4] = u.c[j - 4] * a_post2; asm volatile("" : : "v"(u.m[j - 4])); }
         else if (j < 8) {
@@ -619,7 +623,7 @@ int launch_utd3(const void* in, const void* blob, void* out, int N, int h, int w
     constexpr int NK = 4, POST0 = 2;
     diag = 0;
 #endif
-    constexpr int LDS_POST = UTD3_LDS + 2 * OROW;
+    constexpr int LDS_POST = UTD3_LDS + 2 * OROW + 2048 + 128;
     const int lds = out2 ? LDS_POST : UTD3_LDS;
     static unsigned long long attr_devs = 0;   // one bit per device: the attribute is per device
     if (!vsr::device_marked(attr_devs)) {

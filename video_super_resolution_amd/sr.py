@@ -208,12 +208,15 @@ class SRProjectionModule(nn.Module):
             self._const_nhwc.clear()
             return P
         # ---- MFMA path: one packed blob per live chain  lr[j] -> hr[j+1] -> lr[j+3]  and one for the tail deconv
-        P["utd"], P["utd2"] = {}, {}
+        P["utd"], P["utd2"], P["utd_post"] = {}, {}, {}
         for j in range(0, G - 2, 3):
             args = (b.upBlocks[j + 1][0].weight, b.upBlocks[j + 1][0].bias, P["up_a"][j + 1], P["dt_w"][j + 1], _NF * (j + 2),
                     P["dt_b"][j + 1], P["dt_a"][j + 1], b.downBlocks[j + 2][0].weight, b.downBlocks[j + 2][0].bias, P["dn_a"][j + 2])
             P["utd"][j] = pack_utd_blob(*args)             # k_utd (every wave both phases)
             P["utd2"][j] = pack_utd_blob(*args, layout=2)  # k_utd2 (producer / consumer waves)
+            if j + 6 <= G:   # another stage follows: its input = the uptran slice of this stage's output, applied inside this launch
+                P["utd_post"][j] = pack_utd_blob(*args, post=(P["ut_w"][j + 3], _NF * (j + 4), P["ut_b"][j + 3], P["ut_a"][j + 3]))
+        P["post_slopes_le_one"] = P["slopes_le_one"] and all(a <= 1.0 for a in P["ut_a"])
         P["utd_out"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0)
         if G == 6:   # compress_out reads exactly two live maps (lr3, lr6): folded into the tail's LR path
             P["utd_out_fold"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0,
@@ -613,6 +616,21 @@ class SRProjectionModule(nn.Module):
     fused_s2 = True    # scale 2: the stage on k_utd_s2 (csrc/sr_utd_s2.hip); False: the unfused launches (cross-check).
                        # (read when the weights are packed: change it before the first forward or bump a parameter)
 
+    fuse_uptran = os.environ.get("VSR_UTD_POST", "1") != "0"   # the uptran 1x1 between the two stages of a step inside the first stage's launch
+                                                                # (vsr_sr_utd_post_f16; False: its own chain launch -- the cross-check, bit-identical)
+
+    def _utd_post(self, a, blob, N, h, w, out=None):
+        """The fused stage + the next group's uptran slice on its output rows -> (out, out_post), both [N,h,w,32] fp16."""
+        if out is None:
+            out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
+        out_post = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
+        tok = L.TIMER.start("sr_utd_f16" if N == 8 else f"sr_utd_f16_p{N}")
+        L.check(L.load().vsr_sr_utd_post_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), L.dptr(out_post, torch.float16),
+                                             N, h, w, self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256), flat_ok=getattr(self, "utd_flat_split", True)),
+                                             int(self._pack["post_slopes_le_one"]), L.stream()), "sr_utd_post_f16")
+        L.TIMER.stop(tok)
+        return out, out_post
+
     def _utd(self, a, blob, N, h, w, deconv_only=False, out=None):
         if out is None:
             out = torch.empty((N, 4 * h, 4 * w, _NF) if deconv_only else (N, h, w, _NF), dtype=torch.float16, device=a.device)
@@ -688,15 +706,21 @@ class SRProjectionModule(nn.Module):
             live = {0: outs[-2]} if want_lr0 else {}
             a = outs[-1]
             j = 0
+            a_next = None
             while j + 3 <= G:
                 if j > 0:
-                    a = self._chain([ut(j, live[j])], N, hp, keep=[True])[0]
+                    a = a_next if a_next is not None else self._chain([ut(j, live[j])], N, hp, keep=[True])[0]
+                    a_next = None
                 # (the last step of a call that shares planes writes beside the kept maps of the first call)
                 dst = shared["live"][j + 3][n0:].view(N, h, w, _NF) if (n0 and step == self.num_steps - 1) else None
                 if precompute is not None and step == self.num_steps - 1:
                     dst = precompute[j + 3][:N].view(N, h, w, _NF)
-                live[j + 3] = (self._utd(a, P["utd"][j], N, h, w, out=dst) if self.upscale_factor == 4 else
-                               P["stage"][j](a.view(N, h, w, _NF), self._chain, out=dst)).view(N, hp, _NF)
+                if self.upscale_factor == 4 and self.fuse_uptran and j in P.get("utd_post", {}) and not L._use_x:
+                    o, a_next = self._utd_post(a, P["utd_post"][j], N, h, w, out=dst)
+                    live[j + 3], a_next = o.view(N, hp, _NF), a_next.view(N, hp, _NF)
+                else:
+                    live[j + 3] = (self._utd(a, P["utd"][j], N, h, w, out=dst) if self.upscale_factor == 4 else
+                                   P["stage"][j](a.view(N, h, w, _NF), self._chain, out=dst)).view(N, hp, _NF)
                 j += 3
             if taps is not None and step == self.num_steps - 1:
                 for k, v in live.items():
@@ -1055,7 +1079,7 @@ def _chunk_channel_order(device):
     return torch.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4))  # [4,8]
 
 
-def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a, layout: int = 1, fold_co=None) -> torch.Tensor:
+def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a, layout: int = 1, fold_co=None, post=None) -> torch.Tensor:
     """Weights of one fused up->tran->down stage in the per-wave MFMA fragment order of csrc/sr_f16.hip.
 
     up_w [32(in),32(out),8,8] ConvTranspose2d weight; tr_w [32,ld] 1x1 weight whose live slice starts at column
@@ -1063,6 +1087,8 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a,
     fold_co = (co_w [32,ld], (col0_a, col0_b), co_b [32], co_a): the 1x1 + PReLU over two LR maps (+ constant map) that
     produces the deconv's input, applied by k_tail3<.., FOLD> on the rows' way into LDS; the deconv fragments then take
     their K index in the accumulator's channel order (vsr_sr_tail3_fold_f16).
+    post = (w [32,ld], col0, b [32], a): the 1x1 + PReLU that vsr_sr_utd_post_f16 applies to every finished output row (the next
+    group's uptran slice); its two fragments, bias and slope take the first half of the compress_out region (natural channel order).
     """
     dev = up_w.device
     nbytes = int(L.load().vsr_sr_query(L.Q_UTD_BLOB_BYTES))
@@ -1142,6 +1168,19 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a,
         cpar = torch.zeros(64, dtype=torch.float32, device=dev)
         cpar[0:32] = co_b.detach().float()
         cpar[32] = float(co_a)
+        blob[off_co + 4096:off_co + 4096 + 256] = cpar.view(torch.uint8)
+    if post is not None:
+        assert fold_co is None
+        pw, pcol, pb, pa = post
+        off_co = off_f + 512
+        MT = torch.arange(2, device=dev).view(2, 1, 1)
+        co = 16 * MT + col_l.view(1, 64, 1)
+        ci = pcol + 8 * g.view(1, 64, 1) + j8.view(1, 1, 8)
+        co, ci = torch.broadcast_tensors(co, ci)
+        blob[off_co:off_co + 2048] = pw.detach().float()[co, ci].to(torch.float16).contiguous().view(torch.uint8).reshape(-1)
+        cpar = torch.zeros(64, dtype=torch.float32, device=dev)
+        cpar[0:32] = pb.detach().float()
+        cpar[32] = float(pa)
         blob[off_co + 4096:off_co + 4096 + 256] = cpar.view(torch.uint8)
     return blob
 
