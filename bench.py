@@ -375,7 +375,9 @@ def main():
     # the dominant kernel's launches, timed under one name per plane count so that a launch is always priced by the planes it
     # processed: both SR passes launch it on the 5 planes they do not share (the 3 LR-frame planes run once per forward, on a
     # side stream beside the guidance trunks: VSR.overlap_shared); 8-plane launches only with plane sharing switched off
-    dom_names = {"sr_utd_f16", "sr_utd_f16_p5", "sr_utd_f16_p3"} if (precision == "fp16" and scale == 4) else \
+    # (x4: with VSR.early_planes the passes run on 4 planes, plane 7 of each pass on a side stream: `_side` marks launches that share the chip
+    # with the guidance trunks)
+    dom_names = ({"sr_utd_f16"} | {f"sr_utd_f16_p{n}{sd}" for n in range(1, 8) for sd in ("", "_side")}) if (precision == "fp16" and scale == 4) else \
         ({"sr_utd_s2_f16", "sr_utd_s2_f16_p5", "sr_utd_s2_f16_p3", "sr_stage_up", "sr_stage_dt", "sr_stage_dn"} if precision == "fp16" else
          {f"{k}{p}" for k in ("sr_conv8s4_f32", "sr_deconv8s4_f32", "sr_conv_f32", "sr_deconv_f32", "sr_deconv_dt_f32") for p in ("", "_p5", "_p3")})
     with torch.no_grad():
@@ -504,13 +506,20 @@ def main():
         ms_per_frame = 1e3 * elapsed / calls_per_rank
         # ---- roofline of the dominant kernel, timed with HIP events inside the timed region
         timers = _lib.TIMER.summary()
-        part = timers.pop("sr_utd_f16_p5", None) or timers.pop("sr_utd_s2_f16_p5", None)   # the 5-plane launches of the two SR passes
-        part3 = timers.pop("sr_utd_f16_p3", None) or timers.pop("sr_utd_s2_f16_p3", None)  # the LR-frame planes, beside the guidance trunks
-        planes_dom = 8
-        if part is not None and not any(k in timers for k in ("sr_utd_f16", "sr_utd_s2_f16")):
-            # no 8-plane launch in the forward: the 5-plane launches are the dominant kernel's launches
-            timers["sr_utd_f16" if scale == 4 else "sr_utd_s2_f16"] = part
-            part, planes_dom = None, 5
+        # the fused stage's launches by plane count: main-stream launches (the two SR passes: 5 planes, 4 with VSR.early_planes) and
+        # side-stream ones (`_side`; x2: the 3-plane launches), which run BESIDE the guidance trunks
+        utd_base = "sr_utd_f16" if scale == 4 else "sr_utd_s2_f16"
+        mains, sides = {}, {}
+        for k in [k for k in timers if k == utd_base or k.startswith(utd_base + "_p")]:
+            v = timers.pop(k)
+            kk = k[:-5] if k.endswith("_side") else k
+            pl = int(kk.rsplit("_p", 1)[1]) if kk != utd_base else 8
+            (sides if (k.endswith("_side") or (scale != 4 and pl == 3)) else mains)[pl] = v
+        part, part3, planes_dom = None, None, 8
+        if mains:   # the dominant kernel's launches = the main-stream group with the most time
+            planes_dom, v = max(mains.items(), key=lambda kv: kv[1][0] * kv[1][1])
+            timers[utd_base] = v
+            part3 = sides.get(3)
         dom = max(timers.items(), key=lambda kv: kv[1][0] * kv[1][1]) if timers else None
         roof = None
         if dom is not None:
@@ -555,11 +564,10 @@ def main():
                                                         achieved=round(f3 / (part3[1] * 1e-3) / 1e12, 3),
                                                         note="the LR-frame planes, once per forward on a side stream BESIDE the guidance trunks "
                                                              "(they share the chip: not a clean kernel time)")
-                if part is not None:
-                    f5 = 5 * h * w * STAGE_FLOP_PER_PX[scale]
-                    roof["five_plane_launches"] = dict(launches_timed=part[0], avg_ms=round(part[1], 4), algorithmic_flop_per_launch=f5,
-                                                       achieved=round(f5 / (part[1] * 1e-3) / 1e12, 3),
-                                                       frac=round(f5 / (part[1] * 1e-3) / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4))
+                others = [(pl, v, False) for pl, v in sorted(mains.items()) if pl != planes_dom] + [(pl, v, True) for pl, v in sorted(sides.items()) if pl != 3]
+                if others:
+                    roof["other_launches"] = [dict(planes=pl, side_stream=sd, launches_timed=v[0], avg_ms=round(v[1], 4),
+                                                   achieved=round(pl * h * w * STAGE_FLOP_PER_PX[scale] / (v[1] * 1e-3) / 1e12, 3)) for pl, v, sd in others]
             elif name.startswith("sr_stage_"):
                 # unfused x2 stage (scale extension): each of its three launches is an HBM pass over the HR map.
                 # algorithmic bytes per LR pixel and plane (fp16, 32 ch = 64 B per pixel): up 64 in + 64 s^2 out;

@@ -383,6 +383,42 @@ def test_precomputed_planes_bit_identical(shape, scale):
         m.precompute_shared(a[:2].contiguous(), {"n": 3}, live)
 
 
+@pytest.mark.parametrize("shape", [(16, 16), (9, 40), (37, 33)])
+def test_precomputed_rows_bit_identical(shape):
+    """SRProjectionModule.precompute_rows + shared["done_last"]: the maps of the LAST plane evaluated ahead of the call (VSR.forward: the
+    estimate plane beside the guidance trunks), those of the first three by precompute_shared; the call itself runs planes 3-6 only."""
+    from video_super_resolution_amd import SRProjectionModule
+    from video_super_resolution_amd.weights import fill_module_
+    m = fill_module_(SRProjectionModule().eval(), seed=0, prefix="model.").cuda()
+    h, w = shape
+    rs = np.random.RandomState(h * 29 + w)
+    a = torch.from_numpy(rs.randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    b = a.clone()
+    b[3:] = torch.from_numpy(rs.randint(0, 256, (5, 3, h, w)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        ref_a, ref_b = m(a, decimate=True), m(b)
+        shared = {"n": 3}
+        live = {k: torch.full((8, h * w, 32), float("nan"), dtype=torch.float16, device="cuda") for k in (3, 6)}
+        live["prefc"] = torch.full((8, 3, 4 * h, 4 * w), float("nan"), dtype=torch.float32, device="cuda")
+        m.precompute_shared(a[:3].contiguous(), shared, live)
+        m.precompute_rows(a[7:8], live, 7)
+        shared["done_last"] = 1
+        assert torch.equal(m(a, decimate=True, shared=shared), ref_a)
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            m.precompute_rows(b[6:8], live, 6)      # two trailing planes, on another stream
+        torch.cuda.current_stream().wait_stream(st)
+        shared["done_last"] = 2
+        assert torch.equal(m(b, shared=shared), ref_b)
+        # every plane but the shared ones evaluated ahead: the call is tail + fusion only
+        m.precompute_rows(a[3:8], live, 3)
+        shared["done_last"] = 5
+        assert torch.equal(m(a, decimate=True, shared=shared), ref_a)
+    with pytest.raises(ValueError):
+        m.precompute_rows(a[6:8], live, 7)
+
+
 def test_shared_planes_scale2():
     from video_super_resolution_amd import SRProjectionModule
     from video_super_resolution_amd.weights import fill_module_

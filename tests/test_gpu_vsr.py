@@ -214,6 +214,32 @@ def test_lr_frame_planes_beside_the_guidance_trunks(gpu_vsr_f16):
         assert torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_early_planes_beside_the_guidance_trunks(gpu_vsr_f16):
+    """VSR.early_planes (default on, fp16 configuration, x4): plane 7 of pass 1 (the resized previous output) joins the LR-frame planes on
+    the side stream beside the pass-1 trunks, plane 7 of pass 2 (the masked pass-1 frame) runs behind OSVOS on its stream beside
+    FlowNet2; both SR calls then evaluate head + FeedbackBlock on planes 3-6 only.  Same kernels on the same values: the recurrent
+    frames must equal those of the order without it, bit for bit (first call: plane 7 = frame 0; later calls: the estimate)."""
+    import copy
+    m = copy.deepcopy(gpu_vsr_f16)
+    assert m.early_planes and m.overlap_shared and m.share_planes
+    clip = torch.from_numpy(np.random.RandomState(19).randint(0, 256, (5, 66, 70, 3)).astype(np.float32)).cuda()
+
+    def run(early):
+        m.early_planes = early
+        est, outs = None, []
+        for t in range(3):
+            est, _ = m(clip[t:t + 3], None, None, est, train=False)
+            outs.append(est.clone())
+        torch.cuda.synchronize()
+        return outs
+    try:
+        ref, got = run(False), run(True)
+    finally:
+        m.early_planes = True
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
 def test_streaming_mode_matches_per_window_evaluation(gpu_vsr_f16):
     """VSR.temporal_cache (opt-in): depth predictions / flow pictures of the two frames consecutive windows share are kept
     across calls.  Same networks on the same frames, but the trunks then run on batches of 1-2 instead of 2-4 frames and the

@@ -372,11 +372,32 @@ class SRProjectionModule(nn.Module):
         P = self._packed()
         cmap = self._const_map(P, h, w, x.device)
         # (segmented for `precompute_cus` CUs, not the whole chip: the launches share it with the trunks they run beside)
-        self._utd_cus = int(getattr(self, "precompute_cus", 256))
+        self._utd_cus, self._utd_side = int(getattr(self, "precompute_cus", 256)), True
         try:
             self._forward_f16(x, P, cmap, None, False, shared, precompute=live)
         finally:
-            self._utd_cus = 256
+            self._utd_cus, self._utd_side = 256, False
+
+    @L.on_device
+    @torch.no_grad()
+    def precompute_rows(self, x_rows: torch.Tensor, live: dict, row0: int) -> None:
+        """The FeedbackBlock maps of planes [row0, row0 + n) of a later `forward(x, shared=...)` call, computed ahead of it (fp16
+        configuration, six groups): `x_rows` [n,3,h,w] are those planes, `live` = {3: buf, 6: buf} the [planes,h*w,32] half buffers
+        `precompute_shared` was given; the later call is told with shared["done_last"] (trailing planes).  The planes are independent up
+        to the fusion MLP: same kernels on the same values (tests/test_gpu_sr_f16.py::test_precomputed_rows_bit_identical)."""
+        if self.precision != "fp16" or self.block.num_groups != 6:
+            raise ValueError("precompute_rows: the fp16 configuration with six groups only")
+        n, _, h, w = x_rows.shape
+        if not (0 <= row0 and row0 + n <= live[3].shape[0]):
+            raise ValueError(f"precompute_rows: rows [{row0}, {row0 + n}) outside the {live[3].shape[0]} planes of the buffers")
+        x = x_rows.detach().float().contiguous()
+        P = self._packed()
+        cmap = self._const_map(P, h, w, x.device)
+        self._utd_cus, self._utd_side = int(getattr(self, "precompute_cus", 256)), True
+        try:
+            self._forward_f16(x, P, cmap, None, False, {}, precompute={k: live[k][row0:row0 + n] for k in (3, 6)})
+        finally:
+            self._utd_cus, self._utd_side = 256, False
 
     def _forward_autograd(self, x: torch.Tensor) -> torch.Tensor:
         """CROSS-CHECK ONLY (tests): the same graph on stock differentiable operators -- `forward` never calls it; the train
@@ -619,12 +640,17 @@ class SRProjectionModule(nn.Module):
     fuse_uptran = os.environ.get("VSR_UTD_POST", "1") != "0"   # the uptran 1x1 between the two stages of a step inside the first stage's launch
                                                                 # (vsr_sr_utd_post_f16; False: its own chain launch -- the cross-check, bit-identical)
 
+    def _utd_timer_name(self, N):
+        # (timer names carry the plane count when it is not the full 8 -- the roofline leg prices a launch by its planes -- and `_side` for
+        # the launches of precompute_shared / precompute_rows, which share the chip with the guidance trunks)
+        return ("sr_utd_f16" if N == 8 else f"sr_utd_f16_p{N}") + ("_side" if getattr(self, "_utd_side", False) else "")
+
     def _utd_post(self, a, blob, N, h, w, out=None):
         """The fused stage + the next group's uptran slice on its output rows -> (out, out_post), both [N,h,w,32] fp16."""
         if out is None:
             out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
         out_post = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
-        tok = L.TIMER.start("sr_utd_f16" if N == 8 else f"sr_utd_f16_p{N}")
+        tok = L.TIMER.start(self._utd_timer_name(N))
         L.check(L.load().vsr_sr_utd_post_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), L.dptr(out_post, torch.float16),
                                              N, h, w, self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256), flat_ok=getattr(self, "utd_flat_split", True)),
                                              int(self._pack["post_slopes_le_one"]), L.stream()), "sr_utd_post_f16")
@@ -635,7 +661,7 @@ class SRProjectionModule(nn.Module):
         if out is None:
             out = torch.empty((N, 4 * h, 4 * w, _NF) if deconv_only else (N, h, w, _NF), dtype=torch.float16, device=a.device)
         # (timer names carry the plane count when it is not the full 8: the roofline leg prices a launch by its planes)
-        tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else ("sr_utd_f16" if N == 8 else f"sr_utd_f16_p{N}"))
+        tok = L.TIMER.start("sr_utd_f16_deconv" if deconv_only else self._utd_timer_name(N))
         # (the deconv-only mode is served by the two-waves-per-SIMD build k_utd: cross-check library only)
         L.check((L.load_xcheck() if deconv_only else L.load()).vsr_sr_utd_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), N, h, w,
                                         self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256), flat_ok=not deconv_only and getattr(self, "utd_flat_split", True)),
@@ -664,19 +690,25 @@ class SRProjectionModule(nn.Module):
         else:
             share_ok = shared is not None and taps is None and G == 6 and 0 < int(shared.get("n", 0)) < N_all
             skey = (self._pack_key, h, w, N_all, self.upscale_factor)
+        m_done = 0
         if share_ok and shared.get("live") is not None and shared.get("key") == skey:
             n0 = int(shared["n"])
-        x_all, x = x, (x[n0:] if n0 else x)
-        N = N_all - n0
+            # `done_last` = m: the FeedbackBlock maps of the LAST m planes of this call are in shared["live"] too (`precompute_rows`,
+            # evaluated ahead on a side stream): this call runs head + FeedbackBlock on planes [n0, N - m) only
+            m_done = max(0, min(int(shared.get("done_last", 0)), N_all - n0))
+        x_all, x = x, (x[n0:N_all - m_done] if (n0 or m_done) else x)
+        N = N_all - n0 - m_done
         if (h, w) not in self._const_nhwc:
             self._const_nhwc[(h, w)] = cmap.t().contiguous()  # [h*w, 32] fp32, added before the activation
         cmap_nhwc = self._const_nhwc[(h, w)]
         feat = torch.empty((N, hp, _NF), dtype=torch.float16, device=dev)
-        tok = L.TIMER.start("sr_head_f16") if L.TIMER.enabled else None
-        L.check(lib.vsr_sr_head_f16(L.dptr(x), L.dptr(P["sub_s"]), L.dptr(P["sub_b"]), L.dptr(P["w_in"]), L.dptr(P["b_in"]),
-                                    L.cf(P["a_in"]), P["w_in"].shape[0], L.dptr(P["w_feat"]), L.dptr(P["b_feat"]),
-                                    L.cf(P["a_feat"]), L.dptr(feat, torch.float16), N, h, w, L.stream()), "sr_head_f16")
-        L.TIMER.stop(tok)
+        if N:
+            x = x.contiguous()
+            tok = L.TIMER.start("sr_head_f16") if L.TIMER.enabled else None
+            L.check(lib.vsr_sr_head_f16(L.dptr(x), L.dptr(P["sub_s"]), L.dptr(P["sub_b"]), L.dptr(P["w_in"]), L.dptr(P["b_in"]),
+                                        L.cf(P["a_in"]), P["w_in"].shape[0], L.dptr(P["w_feat"]), L.dptr(P["b_feat"]),
+                                        L.cf(P["a_feat"]), L.dptr(feat, torch.float16), N, h, w, L.stream()), "sr_head_f16")
+            L.TIMER.stop(tok)
         nchw = lambda t: t.view(N, h, w, _NF).permute(0, 3, 1, 2).float()
         if taps is not None:
             taps["feat_in"] = nchw(feat)
@@ -691,7 +723,7 @@ class SRProjectionModule(nn.Module):
                                cmap=cmap_nhwc)
         live = {}
         hid = None
-        for step in range(self.num_steps):
+        for step in range(self.num_steps if N else 0):
             # one launch: (compress_out of the previous step ->) compress_in -> uptran slice of group 1
             if step > 0 and len(co(live)["ins"]) > 2:   # more than 6 groups: compress_out on its own (three inputs)
                 hid = self._c1h(co(live)["ins"], P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
@@ -712,7 +744,7 @@ class SRProjectionModule(nn.Module):
                     a = a_next if a_next is not None else self._chain([ut(j, live[j])], N, hp, keep=[True])[0]
                     a_next = None
                 # (the last step of a call that shares planes writes beside the kept maps of the first call)
-                dst = shared["live"][j + 3][n0:].view(N, h, w, _NF) if (n0 and step == self.num_steps - 1) else None
+                dst = shared["live"][j + 3][n0:n0 + N].view(N, h, w, _NF) if (n0 and step == self.num_steps - 1) else None
                 if precompute is not None and step == self.num_steps - 1:
                     dst = precompute[j + 3][:N].view(N, h, w, _NF)
                 if self.upscale_factor == 4 and self.fuse_uptran and j in P.get("utd_post", {}) and not L._use_x:

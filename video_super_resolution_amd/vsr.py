@@ -73,6 +73,10 @@ class VSR(nn.Module):
         self.share_tail = os.environ.get("VSR_SHARE_TAIL", "1") != "0"   # ... their tail (pre-fusion planes) too (A/B switch)
         self.f32_streams = os.environ.get("VSR_F32_STREAMS", "1") != "0"   # float32 configuration: the trunks (and the shared planes' SR maps) on separate streams too (A/B switch; +7.6 % same box)
         self.overlap_shared = True  # ... and do so on a side stream beside the guidance trunks of pass 1 (fp16 configuration)
+        # ... and the planes of a pass that are known BEFORE its guidance trunks finish: plane 7 of pass 1 (the resized previous output,
+        # :37-38) beside the pass-1 trunks, plane 7 of pass 2 (the masked pass-1 frame, :58-60) behind OSVOS on its stream, beside FlowNet2
+        # (SRProjectionModule.precompute_rows; same kernels on the same values: bit-identical frames)
+        self.early_planes = os.environ.get("VSR_EARLY_PLANES", "1") != "0"
         # Opt-in streaming mode (OFF by default; the headline benchmark leaves it off): consecutive windows of a clip share
         # two of their three LR frames (utils/video_utils.py:25), so the depth prediction of a frame and the flow picture of a
         # frame pair computed for window t are what window t+1 computes again.  With temporal_cache = True they are kept
@@ -147,7 +151,7 @@ class VSR(nn.Module):
         return self._streams
 
     @torch.no_grad()
-    def _guidance(self, trip, depth_cache, extra_depth=(), with_vos=None, cacheable=False):
+    def _guidance(self, trip, depth_cache, extra_depth=(), with_vos=None, cacheable=False, after_vos=None):
         """trip: three [h,w,3] frames -> (flow pictures [2,h',w',3], the three single-frame depth predictions [1,1,h,w]
         [, VOS mask [h,w]]): what `_assemble` turns into planes 3-6 (and the masked plane 7) of the SR input.
 
@@ -188,6 +192,8 @@ class VSR(nn.Module):
             with torch.cuda.stream(s_vos):
                 mask = self.VOSModule(with_vos[0], with_vos[1], self._vos_exec.get() if fast else None)  # [h,w] in {0,1}
                 mask.record_stream(main)
+                if after_vos is not None:
+                    after_vos(mask)   # (more work for this stream, behind the mask)
         # both frame pairs as one FlowNet2 batch of two (on the main stream)
         pairs = [(trip[0], trip[1]), (trip[1], trip[2])]
         net = self._flow_exec.get() if fast else None
@@ -283,9 +289,15 @@ class VSR(nn.Module):
                     live["prefc"] = torch.empty((n_planes, 3, S * h, S * w), dtype=torch.float32, device=d.device)
                 s_sr = self._side_streams(d.device)[1]
                 s_sr.wait_stream(main)
+                early = self.early_planes and self.model.upscale_factor == 4
                 with torch.cuda.stream(s_sr):
                     self.model.precompute_shared(x_first, shared, live)
+                    if early:   # plane 7 of pass 1: the previous output at h x w (:37), frame 0 on the first call (:38)
+                        self.model.precompute_rows((est if est is not None else x_first[0]).unsqueeze(0), live, n_planes - 1)
+                        shared["done_last"] = 1
                 x_first.record_stream(s_sr)
+                if est is not None:
+                    est.record_stream(s_sr)
                 for t in live.values():
                     t.record_stream(s_sr)
             # (the estimate's depth is only used in pass 2 but is already known: batched with the three frames)
@@ -303,7 +315,17 @@ class VSR(nn.Module):
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
             mark()
             mid_hw3 = mid.permute(1, 2, 0).contiguous()
-            pics2, z2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3))
+            after_vos = None
+            if shared is not None and shared.get("done_last"):
+                s_vos = self._side_streams(d.device)[1]
+
+                def after_vos(m):   # plane 7 of pass 2 = the pass-1 frame, zero under the mask (:58-60; as k_assemble_planes writes it)
+                    x7 = torch.where(m != 0, torch.zeros_like(mid), mid).unsqueeze(0)
+                    self.model.precompute_rows(x7, shared["live"], self.model.fc[0].in_features - 1)
+                mid.record_stream(s_vos)
+                for t in shared["live"].values():
+                    t.record_stream(s_vos)
+            pics2, z2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3), after_vos=after_vos)
             mark()
             x8 = self._assemble(d, pics2, z2, mid.contiguous(), mask.contiguous())   # plane 7: mid, zero where mask != 0 (:58-60)
             if getattr(self, "plane_taps", None) is not None:   # (measurement hook: the SR inputs of both passes and the mask, bench.py / tests)
