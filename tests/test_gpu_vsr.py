@@ -232,12 +232,15 @@ def test_early_planes_beside_the_guidance_trunks(gpu_vsr_f16):
             outs.append(est.clone())
         torch.cuda.synchronize()
         return outs
+    default = m.early_planes
     try:
-        ref, got = run(False), run(True)
+        ref = run(0)
+        # level 1: plane 7 of both passes; 2: + the depth planes of pass 2 behind the hourglass; 3: + the flow-picture planes of pass 1 behind FlowNet2
+        for level in (1, 2, 3):
+            for a, b in zip(run(level), ref):
+                assert torch.equal(a, b), level
     finally:
-        m.early_planes = True
-    for a, b in zip(got, ref):
-        assert torch.equal(a, b)
+        m.early_planes = default
 
 
 def test_streaming_mode_matches_per_window_evaluation(gpu_vsr_f16):

@@ -682,7 +682,7 @@ class SRProjectionModule(nn.Module):
         dev = x.device
         G = self.block.num_groups
         hp = h * w
-        n0 = 0
+        n0 = n_sh = 0   # n_sh: the shared planes [0, n_sh) (their maps -- and tails, with `prefc_all` -- are kept); n0: first plane this call evaluates
         if precompute is not None:   # `x` = the first planes only; their maps go to rows 0.. of the caller's buffers (precompute_shared)
             N_tot = precompute[3].shape[0]
             share_ok = False
@@ -692,10 +692,15 @@ class SRProjectionModule(nn.Module):
             skey = (self._pack_key, h, w, N_all, self.upscale_factor)
         m_done = 0
         if share_ok and shared.get("live") is not None and shared.get("key") == skey:
-            n0 = int(shared["n"])
-            # `done_last` = m: the FeedbackBlock maps of the LAST m planes of this call are in shared["live"] too (`precompute_rows`,
-            # evaluated ahead on a side stream): this call runs head + FeedbackBlock on planes [n0, N - m) only
+            n0 = n_sh = int(shared["n"])
+            # `todo` = (a, b): the FeedbackBlock maps of every other plane of this call are in shared["live"] already (`precompute_rows`,
+            # evaluated ahead on side streams): this call runs head + FeedbackBlock on planes [a, b) only.  (`done_last` = m: b = N - m.)
             m_done = max(0, min(int(shared.get("done_last", 0)), N_all - n0))
+            if shared.get("todo") is not None:
+                a_, b_ = shared["todo"]
+                if not (n0 <= a_ <= b_ <= N_all):
+                    raise ValueError(f"shared['todo'] = {shared['todo']} outside the unshared planes [{n0}, {N_all})")
+                n0, m_done = int(a_), N_all - int(b_)
         x_all, x = x, (x[n0:N_all - m_done] if (n0 or m_done) else x)
         N = N_all - n0 - m_done
         if (h, w) not in self._const_nhwc:
@@ -780,9 +785,10 @@ class SRProjectionModule(nn.Module):
                 self._tail_raw(hid.view(N, h, w, _NF), P, False, pre[:N], cus=2 * getattr(self, "_utd_cus", 256))
                 shared["prefc_all"] = pre
             return None
-        if n0:
+        if n_sh:
             live = {k: shared["live"][k] for k in (3, 6)}
             N, x = N_all, x_all
+            n0 = n_sh
         elif share_ok:
             shared.update(live={k: live[k] for k in (3, 6)}, key=skey)
         S = self.upscale_factor

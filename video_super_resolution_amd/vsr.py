@@ -76,7 +76,9 @@ class VSR(nn.Module):
         # ... and the planes of a pass that are known BEFORE its guidance trunks finish: plane 7 of pass 1 (the resized previous output,
         # :37-38) beside the pass-1 trunks, plane 7 of pass 2 (the masked pass-1 frame, :58-60) behind OSVOS on its stream, beside FlowNet2
         # (SRProjectionModule.precompute_rows; same kernels on the same values: bit-identical frames)
-        self.early_planes = os.environ.get("VSR_EARLY_PLANES", "1") != "0"
+        # level 2: also the two depth planes of pass 2 behind the hourglass on its stream (beside FlowNet2, the long pole of pass 2's guidance);
+        # level 3: also the two flow-picture planes of pass 1 on the main stream behind FlowNet2 (beside the hourglass, pass 1's long pole)
+        self.early_planes = int(os.environ.get("VSR_EARLY_PLANES", "1"))
         # Opt-in streaming mode (OFF by default; the headline benchmark leaves it off): consecutive windows of a clip share
         # two of their three LR frames (utils/video_utils.py:25), so the depth prediction of a frame and the flow picture of a
         # frame pair computed for window t are what window t+1 computes again.  With temporal_cache = True they are kept
@@ -151,7 +153,7 @@ class VSR(nn.Module):
         return self._streams
 
     @torch.no_grad()
-    def _guidance(self, trip, depth_cache, extra_depth=(), with_vos=None, cacheable=False, after_vos=None):
+    def _guidance(self, trip, depth_cache, extra_depth=(), with_vos=None, cacheable=False, after_vos=None, after_depth=None, after_flow=None):
         """trip: three [h,w,3] frames -> (flow pictures [2,h',w',3], the three single-frame depth predictions [1,1,h,w]
         [, VOS mask [h,w]]): what `_assemble` turns into planes 3-6 (and the masked plane 7) of the SR input.
 
@@ -187,6 +189,9 @@ class VSR(nn.Module):
                 z.record_stream(main)
             for i, f in enumerate(new):
                 depth_cache[f.data_ptr()] = (f, z[i:i + 1])  # keep f alive so the pointer stays unique
+        if after_depth is not None:
+            with torch.cuda.stream(s_depth):
+                after_depth([depth_cache[f.data_ptr()][1] for f in trip])   # (more work for this stream, behind the predictions)
         mask = None
         if with_vos is not None:
             with torch.cuda.stream(s_vos):
@@ -209,6 +214,8 @@ class VSR(nn.Module):
             tc["flow"] = {k: (a, b, p) for k, (a, b), p in zip(keys, pairs, pics_l)}
         else:
             pics = self.FlowModule.forward_pairs(pairs, net)
+        if after_flow is not None:
+            after_flow(pics)   # (more work for the main stream, behind the flow pictures, while the other trunks finish)
         if par:
             main.wait_stream(s_depth)
             main.wait_stream(s_vos)
@@ -289,19 +296,25 @@ class VSR(nn.Module):
                     live["prefc"] = torch.empty((n_planes, 3, S * h, S * w), dtype=torch.float32, device=d.device)
                 s_sr = self._side_streams(d.device)[1]
                 s_sr.wait_stream(main)
-                early = self.early_planes and self.model.upscale_factor == 4
+                early = self.early_planes if self.model.upscale_factor == 4 else 0
                 with torch.cuda.stream(s_sr):
                     self.model.precompute_shared(x_first, shared, live)
                     if early:   # plane 7 of pass 1: the previous output at h x w (:37), frame 0 on the first call (:38)
                         self.model.precompute_rows((est if est is not None else x_first[0]).unsqueeze(0), live, n_planes - 1)
-                        shared["done_last"] = 1
+                        shared["todo"] = (3, n_planes - 1)
                 x_first.record_stream(s_sr)
                 if est is not None:
                     est.record_stream(s_sr)
                 for t in live.values():
                     t.record_stream(s_sr)
             # (the estimate's depth is only used in pass 2 but is already known: batched with the three frames)
-            pics, z, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,), cacheable=True)
+            after_flow = None
+            if shared is not None and shared.get("todo") is not None and self.early_planes >= 3:
+                def after_flow(p):   # planes 3, 4 of pass 1: the flow pictures at h x w (:35), as k_assemble_planes writes them
+                    zd = torch.zeros((1, 1, h, w), dtype=torch.float32, device=d.device)
+                    self.model.precompute_rows(self._assemble(d, p, [zd, zd, zd], est)[3:5], shared["live"], 3)
+                    shared["todo"] = (5, shared["todo"][1])
+            pics, z, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,), cacheable=True, after_flow=after_flow)
             if s_sr is not None:
                 torch.cuda.current_stream(d.device).wait_stream(s_sr)
             mark()
@@ -315,9 +328,19 @@ class VSR(nn.Module):
             # ---- pass 2 guidance on (estimate, x4-decimated pass-1 output, frame 2) (:43-54)
             mark()
             mid_hw3 = mid.permute(1, 2, 0).contiguous()
-            after_vos = None
-            if shared is not None and shared.get("done_last"):
-                s_vos = self._side_streams(d.device)[1]
+            after_vos = after_depth = None
+            if shared is not None and shared.get("todo") is not None:
+                s_depth, s_vos = self._side_streams(d.device)[:2]
+                n_pl = self.model.fc[0].in_features
+                shared["todo"] = (3, n_pl - 1)
+                if self.early_planes >= 2:
+                    def after_depth(z3):   # planes 5, 6 of pass 2: the depth planes (:49-50), as k_assemble_planes writes them
+                        self.model.precompute_rows(self._assemble(d, pics, z3, mid)[5:7], shared["live"], 5)
+                    shared["todo"] = (3, 5)
+                    pics.record_stream(s_depth)
+                    mid.record_stream(s_depth)
+                    for t in shared["live"].values():
+                        t.record_stream(s_depth)
 
                 def after_vos(m):   # plane 7 of pass 2 = the pass-1 frame, zero under the mask (:58-60; as k_assemble_planes writes it)
                     x7 = torch.where(m != 0, torch.zeros_like(mid), mid).unsqueeze(0)
@@ -325,7 +348,7 @@ class VSR(nn.Module):
                 mid.record_stream(s_vos)
                 for t in shared["live"].values():
                     t.record_stream(s_vos)
-            pics2, z2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3), after_vos=after_vos)
+            pics2, z2, mask = self._guidance((est_hw3, mid_hw3, f2), depth_cache, with_vos=(est_hw3, mid_hw3), after_vos=after_vos, after_depth=after_depth)
             mark()
             x8 = self._assemble(d, pics2, z2, mid.contiguous(), mask.contiguous())   # plane 7: mid, zero where mask != 0 (:58-60)
             if getattr(self, "plane_taps", None) is not None:   # (measurement hook: the SR inputs of both passes and the mask, bench.py / tests)
