@@ -378,7 +378,7 @@ def main():
     # (x4: with VSR.early_planes the passes run on 4 planes, plane 7 of each pass on a side stream: `_side` marks launches that share the chip
     # with the guidance trunks)
     dom_names = ({"sr_utd_f16"} | {f"sr_utd_f16_p{n}{sd}" for n in range(1, 8) for sd in ("", "_side")}) if (precision == "fp16" and scale == 4) else \
-        ({"sr_utd_s2_f16", "sr_utd_s2_f16_p5", "sr_utd_s2_f16_p3", "sr_stage_up", "sr_stage_dt", "sr_stage_dn"} if precision == "fp16" else
+        (({"sr_utd_s2_f16", "sr_stage_up", "sr_stage_dt", "sr_stage_dn"} | {f"sr_utd_s2_f16_p{n}{sd}" for n in range(1, 8) for sd in ("", "_side")}) if precision == "fp16" else
          {f"{k}{p}" for k in ("sr_conv8s4_f32", "sr_deconv8s4_f32", "sr_conv_f32", "sr_deconv_f32", "sr_deconv_dt_f32") for p in ("", "_p5", "_p3")})
     with torch.no_grad():
         # initialisation, not a step: both entry paths of forward (no estimate yet / recurrent estimate) run once so that
@@ -514,7 +514,7 @@ def main():
             v = timers.pop(k)
             kk = k[:-5] if k.endswith("_side") else k
             pl = int(kk.rsplit("_p", 1)[1]) if kk != utd_base else 8
-            (sides if (k.endswith("_side") or (scale != 4 and pl == 3)) else mains)[pl] = v
+            (sides if k.endswith("_side") else mains)[pl] = v
         part, part3, planes_dom = None, None, 8
         if mains:   # the dominant kernel's launches = the main-stream group with the most time
             planes_dom, v = max(mains.items(), key=lambda kv: kv[1][0] * kv[1][1])

@@ -757,7 +757,7 @@ class SRProjectionModule(nn.Module):
                     live[j + 3], a_next = o.view(N, hp, _NF), a_next.view(N, hp, _NF)
                 else:
                     live[j + 3] = (self._utd(a, P["utd"][j], N, h, w, out=dst) if self.upscale_factor == 4 else
-                                   P["stage"][j](a.view(N, h, w, _NF), self._chain, out=dst)).view(N, hp, _NF)
+                                   P["stage"][j](a.view(N, h, w, _NF), self._chain, out=dst, side=getattr(self, "_utd_side", False))).view(N, hp, _NF)
                 j += 3
             if taps is not None and step == self.num_steps - 1:
                 for k, v in live.items():
@@ -1047,14 +1047,14 @@ class _FusedStageS2:
         self.slopes_le_one = bool(slopes_le_one)
         self.rows_fn = rows_fn
 
-    def __call__(self, a, chain, out=None):
+    def __call__(self, a, chain, out=None, side=False):
         N, h, w, _ = a.shape
         if out is None:
             out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
         nb = max(1, min(N, ((1 << 32) - 32) // (h * w * _NF * 2)))   # planes per launch: the kernel's 32-bit byte offsets
         for n0 in range(0, N, nb):
             n = min(nb, N - n0)
-            tok = L.TIMER.start("sr_utd_s2_f16" if n == 8 else f"sr_utd_s2_f16_p{n}")
+            tok = L.TIMER.start(("sr_utd_s2_f16" if n == 8 else f"sr_utd_s2_f16_p{n}") + ("_side" if side else ""))
             # two workgroups share a CU (256 registers per wave): twice the slots of the x4 kernel per round
             rows = self.rows_fn(n, h, w, cus=512, strip=int(L.load().vsr_sr_query(L.Q_UTD_S2_STRIP_WIDTH)))
             L.check(L.load().vsr_sr_utd_s2_f16(L.dptr(a[n0:n0 + n], torch.float16), L.dptr(self.blob, torch.uint8),
@@ -1077,7 +1077,7 @@ class _UnfusedStage:
         self.dn = HConv(dn[0].weight, dn[0].bias, stride=S, pad=2, act=ACT_LEAKY, slope=float(dn[1].weight.detach()))
         assert K == S + 4
 
-    def __call__(self, a, chain, out=None):
+    def __call__(self, a, chain, out=None, side=False):
         N, h, w, _ = a.shape
         S = self.S
         if out is None:

@@ -79,6 +79,7 @@ class VSR(nn.Module):
         # level 2: also the two depth planes of pass 2 behind the hourglass on its stream (beside FlowNet2, the long pole of pass 2's guidance);
         # level 3: also the two flow-picture planes of pass 1 on the main stream behind FlowNet2 (beside the hourglass, pass 1's long pole)
         self.early_planes = int(os.environ.get("VSR_EARLY_PLANES", "1"))
+        self.early_scales = (4,)   # x2 (C3-B): measured level with the plain order (14.15 / 14.26 vs 14.17 / 14.16 frames/s, same box): off there
         # Opt-in streaming mode (OFF by default; the headline benchmark leaves it off): consecutive windows of a clip share
         # two of their three LR frames (utils/video_utils.py:25), so the depth prediction of a frame and the flow picture of a
         # frame pair computed for window t are what window t+1 computes again.  With temporal_cache = True they are kept
@@ -296,7 +297,7 @@ class VSR(nn.Module):
                     live["prefc"] = torch.empty((n_planes, 3, S * h, S * w), dtype=torch.float32, device=d.device)
                 s_sr = self._side_streams(d.device)[1]
                 s_sr.wait_stream(main)
-                early = self.early_planes if self.model.upscale_factor == 4 else 0
+                early = self.early_planes if self.model.upscale_factor in self.early_scales else 0
                 with torch.cuda.stream(s_sr):
                     self.model.precompute_shared(x_first, shared, live)
                     if early:   # plane 7 of pass 1: the previous output at h x w (:37), frame 0 on the first call (:38)
