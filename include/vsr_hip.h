@@ -372,6 +372,13 @@ int vsr_flow_head_f16(const void* in, int in_ld, int in_coff, int cin, const voi
                       int f_coff, const float* up_w, const float* up_b, void* up, int u_ld, int u_coff, int N, int H, int W,
                       vsr_stream_t stream);
 
+/* The batch the convolution launchers (vsr_conv2d_nhwc_f16 / _sx_, vsr_deconv4s2_nhwc_f16, vsr_conv2d_stem_f16, vsr_flow_head_f16) DECIDE
+ * by -- which kernel, tile width and split-K count -- when it is not the batch they are launched on: n > 0 makes every following launch of
+ * the calling thread choose as if it held n images (the launch itself covers the real batch); 0 (default) = decide by the real batch.
+ * A frame's result then does not depend on the batch it travelled in (VSR.temporal_cache: trunks evaluated on the frames a window
+ * does not share with the previous one run the kernels of the full batch -> bit-identical to the per-window evaluation). */
+int vsr_conv2d_route_batch(int n);
+
 /* ConvTranspose2d(k=4, s=2, p=1) (+bias +activation) as its four 2x2-tap phase convolutions in ONE launch (grid.z walks
  * phase and split-K slice).  w_packed4[py*2+px]: the phase's taps packed like vsr_conv2d_nhwc_sx_f16 weights (kernel rows
  * (3,1) for py = 0, (2,0) for py = 1; same along x).  in [N,H,W,in_ld] -> out [N,2H,2W,out_ld], slice [out_coff,+cout). */

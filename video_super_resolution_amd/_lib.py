@@ -181,6 +181,24 @@ class Chain1x1(ctypes.Structure):
     _fields_ = [("nstages", ctypes.c_int), ("stage", _ChainStage * 3)]
 
 
+class route_batch:
+    """`with _lib.route_batch(n):` -- the convolution launchers inside choose kernel / tile width / split-K as if the batch held n images
+    (vsr_conv2d_route_batch): a trunk evaluated on a part of its usual batch runs the usual kernels.  n <= 0: no-op."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+
+    def __enter__(self):
+        if self.n > 0:
+            check(load().vsr_conv2d_route_batch(self.n), "conv2d_route_batch")
+        return self
+
+    def __exit__(self, *exc):
+        if self.n > 0:
+            load().vsr_conv2d_route_batch(0)
+        return False
+
+
 class EventTimer:
     """HIP-event timing of selected kernel launches on the current stream (used by bench.py for the roofline
     leg).  Disabled (no events, no overhead) unless `enabled` is set."""

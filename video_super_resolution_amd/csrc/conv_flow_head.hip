@@ -189,7 +189,7 @@ extern "C" int vsr_flow_head_f16(const void* in, int in_ld, int in_coff, int cin
     p.N = N; p.H = H; p.W = W; p.tiles_x = p.tiles_y = 0;
     hipStream_t st = vsr::S(stream);
     // small maps: 4 x 4 tiles (more workgroups than CUs only from 32 x 60 x 2 up); else 8 x 8
-    const bool small = (long long)N * H * W < 16384;
+    const bool small = (long long)vsr::route_batch(N) * H * W < 16384;
     vsr::route(up_w ? (small ? "flow_head<4,4,2>" : "flow_head<8,8,2>") : (small ? "flow_head<4,4,1>" : "flow_head<8,8,1>"));
     if (up_w) return small ? launch_head<4, 4, 2>(p, st) : launch_head<8, 8, 2>(p, st);
     return small ? launch_head<4, 4, 1>(p, st) : launch_head<8, 8, 1>(p, st);

@@ -1631,12 +1631,13 @@ static int pf_choice(const ConvP& p, int N) {
     return 0;
 }
 
-static int run_tile(ConvP& p, long long M, int nk_all, int nph, void* splitk_ws, size_t splitk_ws_bytes, hipStream_t st, const char* what) {
+// Mr: the pixel count the DECISIONS are taken by (vsr::route_batch: = M unless a route batch is set); M: the pixels launched
+static int run_tile(ConvP& p, long long M, long long Mr, int nk_all, int nph, void* splitk_ws, size_t splitk_ws_bytes, hipStream_t st, const char* what) {
     const bool can128 = (p.cout_pad & 127) == 0;
     int splits = 1;
-    int bn = tile_choice(p, M, nk_all, nph, &splits);
+    int bn = tile_choice(p, Mr, nk_all, nph, &splits);
     if (bn == 0) {   // (mode 3 / experiments: a layer the heuristic leaves to the other kernels)
-        const long long nwg = vsr::cdiv(M, BM) * (long long)(p.cout_pad / (can128 ? 128 : 64)) * nph;
+        const long long nwg = vsr::cdiv(Mr, BM) * (long long)(p.cout_pad / (can128 ? 128 : 64)) * nph;
         bn = can128 ? 128 : 64;
         if (nwg < 200) splits = (int)((320 + nwg - 1) / nwg);
     }
@@ -1645,7 +1646,7 @@ static int run_tile(ConvP& p, long long M, int nk_all, int nph, void* splitk_ws,
     if (splits > nk_all / 4) splits = nk_all / 4;
     if (splits > 32) splits = 32;
     if (!splitk_ws) splits = 1;
-    while (splits > 1 && (size_t)splits * nph * M * p.cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
+    while (splits > 1 && (size_t)splits * nph * (M > Mr ? M : Mr) * p.cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
     if (splits < 1) splits = 1;
     p.ws = splits > 1 ? (float*)splitk_ws : nullptr;
     p.splits = splits;
@@ -1758,6 +1759,12 @@ int vsr_flownetc_corr_nhwc_f16(const void* feat_a, const void* feat_b, void* out
     return vsr::launched("flownetc_corr");
 }
 
+int vsr_conv2d_route_batch(int n) {
+    VSR_REQUIRE(n >= 0 && n <= 65535, "conv2d_route_batch: %d", n);
+    vsr::route_batch_ref() = n;
+    return VSR_OK;
+}
+
 int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* const* w_packed4, const float* bias, void* out,
                            int out_ld, int out_coff, int N, int H, int W, int cin, int cout, int cout_pad, int act, float slope,
                            void* splitk_ws, size_t splitk_ws_bytes, vsr_stream_t stream) {
@@ -1796,7 +1803,7 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
         p.pad_y_ph[ph] = py == 0 ? 1 : 0; p.pad_x_ph[ph] = px == 0 ? 1 : 0;
         p.oy_off_ph[ph] = py; p.ox_off_ph[ph] = px;
     }
-    const long long M = (long long)N * H * W;
+    const long long M = (long long)N * H * W, Mr = (long long)vsr::route_batch(N) * H * W;
     VSR_REQUIRE(M < (1ll << 31), "deconv4s2: %lld output pixels per phase exceed the kernel's 32-bit pixel index", M);
     // few out-channels on many pixels: all four phases from one staged input patch (k_deconv4s2_patch)
     if (g_patch_mode != 1 && g_patch_mode != 8 && cout_pad <= 32 && (long long)H * W >= 8192 && H >= 4 && W >= 16 && N <= 65535 &&
@@ -1809,18 +1816,18 @@ int vsr_deconv4s2_nhwc_f16(const void* in, int in_ld, int in_coff, const void* c
     }
     int ts_ = 1;
     if (g_tile_mode >= 1 && g_patch_mode != 8 && g_patch_mode != 1 && (cout_pad & 63) == 0 &&
-        (g_tile_mode >= 3 || tile_choice(p, M, (4 * (cin >> 5) + 1) >> 1, 4, &ts_) != 0))
-        return run_tile(p, M, (4 * (cin >> 5) + 1) >> 1, 4, splitk_ws, splitk_ws_bytes, vsr::S(stream), "deconv4s2_nhwc_f16/tile");
-    const unsigned gx = vsr::cdiv(M, BM);
+        (g_tile_mode >= 3 || tile_choice(p, Mr, (4 * (cin >> 5) + 1) >> 1, 4, &ts_) != 0))
+        return run_tile(p, M, Mr, (4 * (cin >> 5) + 1) >> 1, 4, splitk_ws, splitk_ws_bytes, vsr::S(stream), "deconv4s2_nhwc_f16/tile");
+    const unsigned gx = vsr::cdiv(M, BM), gxr = vsr::cdiv(Mr, BM);   // (gxr: the workgroups the decisions count)
     const int bn = (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const unsigned gy = cout_pad / bn;
     const int nk_all = (4 * (cin >> 5) + 1) >> 1;
     int splits = 1;
-    if (splitk_ws && (long long)gx * gy * 4 < 128 && nk_all >= 8) {
-        splits = (int)(256 / ((long long)gx * gy * 4));
+    if (splitk_ws && (long long)gxr * gy * 4 < 128 && nk_all >= 8) {
+        splits = (int)(256 / ((long long)gxr * gy * 4));
         if (splits > nk_all / 4) splits = nk_all / 4;
         if (splits > 32) splits = 32;
-        while (splits > 1 && (size_t)splits * 4 * M * cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
+        while (splits > 1 && (size_t)splits * 4 * (M > Mr ? M : Mr) * cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
         if (splits < 1) splits = 1;
     }
     p.ws = splits > 1 ? (float*)splitk_ws : nullptr;
@@ -1863,11 +1870,11 @@ int vsr_conv2d_stem_f16(const void* in4, const void* w_packed, const float* bias
     p.kh = kh; p.kw = kw; p.stride = stride; p.stride_x = stride_x > 0 ? stride_x : stride; p.pad_y = pad_y; p.pad_x = pad_x;
     p.outH = Ho; p.outW = Wo; p.oy_mul = 1; p.oy_off = 0; p.ox_mul = 1; p.ox_off = 0;
     p.act = act; p.slope = slope; p.ws = nullptr; p.splits = 1; p.nphase = 0;
-    const long long M = (long long)N * Ho * Wo;
+    const long long M = (long long)N * Ho * Wo, Mr = (long long)vsr::route_batch(N) * Ho * Wo;
     VSR_REQUIRE(M < (1ll << 31), "conv2d_stem: %lld output pixels exceed the kernels' 32-bit pixel index", M);
     // the hourglass stem's shape: persistent row-walking kernel with register-resident weights and full-line stores
     if (g_patch_mode != 1 && kh == 7 && kw == 7 && stride == 1 && pad_y == 3 && pad_x == 3 && cout == 128 && cout_pad == 128 && Ho == H &&
-        Wo == W && (out_ld & 7) == 0 && (out_coff & 7) == 0 && (unsigned long long)N * H * W * 8 < (1ull << 31) && M >= 65536) {
+        Wo == W && (out_ld & 7) == 0 && (out_coff & 7) == 0 && (unsigned long long)N * H * W * 8 < (1ull << 31) && Mr >= 65536) {
         const int tiles_x = (int)vsr::cdiv(Wo, ST_C), tiles_y = (int)vsr::cdiv(Ho, ST_R);
         const long long ntiles = (long long)N * tiles_x * tiles_y;
         if (ntiles < (1ll << 30)) {
@@ -1933,7 +1940,8 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     p.kh = kh; p.kw = kw; p.stride = stride; p.stride_x = stride_x > 0 ? stride_x : stride; p.pad_y = pad_y; p.pad_x = pad_x;
     p.outH = outH; p.outW = outW; p.oy_mul = oy_mul; p.oy_off = oy_off; p.ox_mul = ox_mul; p.ox_off = ox_off;
     p.act = act; p.slope = slope; p.nphase = 0;
-    const long long M = (long long)N * Ho * Wo;
+    const int Nr = vsr::route_batch(N);   // the batch the kernel / tile / split-K decisions below count (= N unless vsr_conv2d_route_batch is set)
+    const long long M = (long long)N * Ho * Wo, Mr = (long long)Nr * Ho * Wo;
     VSR_REQUIRE(M < (1ll << 31), "conv2d: %lld output pixels exceed the kernels' 32-bit pixel index", M);
     // stride-1 layers with a real spatial kernel and enough pixels: the 2-D LDS patch kernel (stages the input once per
     // 32-channel chunk instead of gathering it kh*kw times from L2).  Measured on MI355X (tools/conv_microbench.py).
@@ -1947,9 +1955,9 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     int ts_ = 1;
     const int nk_all_ = (kh * kw * (cin >> 5) + 1) >> 1;
     const bool tile_can = g_tile_mode >= 1 && g_patch_mode != 8 && g_patch_mode != 1 && (cout_pad & 63) == 0;
-    const bool tile_ok = tile_can && (g_tile_mode >= 3 || (tile_choice(p, M, nk_all_, 1, &ts_) != 0 && !(kh == 1 && kw == 1 && M >= 65536)));
+    const bool tile_ok = tile_can && (g_tile_mode >= 3 || (tile_choice(p, Mr, nk_all_, 1, &ts_) != 0 && !(kh == 1 && kw == 1 && Mr >= 65536)));
     if (tile_can && g_tile_mode >= 3 && !force)
-        return run_tile(p, M, nk_all_, 1, splitk_ws, splitk_ws_bytes, vsr::S(stream), "conv2d_nhwc_f16/tile");
+        return run_tile(p, M, Mr, nk_all_, 1, splitk_ws, splitk_ws_bytes, vsr::S(stream), "conv2d_nhwc_f16/tile");
     if (patch_legal && g_patch_mode != 1 && (patch_pays || force)) {
         p.ws = nullptr;
         p.splits = 1;
@@ -1963,7 +1971,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
             hipStream_t st = vsr::S(stream);
             // the persistent, prefetching build (conv_patch_pf.hip): see pf_choice
             if (g_pf_mode >= 1 && kh == kw && g_patch_mode != 5) {
-                const int pf_mt = pf_choice(p, N);
+                const int pf_mt = pf_choice(p, Nr);
                 if (pf_mt) {
                     vsr::route("patch_pf<%d,%d>", kh, pf_mt);
                     const int rc = vsrc::launch_conv_patch_pf(p, pf_mt, st);
@@ -1979,7 +1987,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
             // g_lw_mode: 0 never, 1 this heuristic, 2 wherever a build exists (tests / A-B).
             if (g_lw_mode >= 1 && kh == kw && g_patch_mode != 5) {
                 const int lw_mt = (kh == 3 && (cout_pad & 63) == 0) ? 4 : ((cout_pad & 31) == 0 && (kh == 3 || kh == 5 || kh == 7) ? 2 : 0);
-                const long long lw_wgs = lw_mt ? (long long)vsr::cdiv(Ho, P8_H) * vsr::cdiv(Wo, P8_W) * N * (cout_pad / (16 * lw_mt)) : 0;
+                const long long lw_wgs = lw_mt ? (long long)vsr::cdiv(Ho, P8_H) * vsr::cdiv(Wo, P8_W) * Nr * (cout_pad / (16 * lw_mt)) : 0;
                 const bool lw_pays = g_lw_mode >= 2 || (kh == 3 && lw_wgs >= 500 && (lw_mt == 4 || (cin >> 5) >= 2));
                 if (lw_mt && lw_pays) {
                     vsr::route("patch_lw<%d,%d>", kh, lw_mt);
@@ -2018,7 +2026,7 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
     // 1x1 over many pixels with more than one 64-channel block of outputs: the streaming kernel (input read once)
     const size_t w_lds = (size_t)(cin >> 5) * cout_pad * 64;
     if (kh == 1 && kw == 1 && stride == 1 && (stride_x <= 0 || stride_x == 1) && pad_y == 0 && pad_x == 0 && oy_mul == 1 && ox_mul == 1 && oy_off == 0 && ox_off == 0 &&
-        outH == Ho && outW == Wo && (cin >> 5) <= C1_MAX_CHUNKS && w_lds <= 128 * 1024 && cout_pad > 64 && M >= 65536 &&
+        outH == Ho && outW == Wo && (cin >> 5) <= C1_MAX_CHUNKS && w_lds <= 128 * 1024 && cout_pad > 64 && Mr >= 65536 &&
         g_patch_mode != 1) {
         p.ws = nullptr;
         p.splits = 1;
@@ -2055,23 +2063,23 @@ int vsr_conv2d_nhwc_sx_f16(const void* in, int in_ld, int in_coff, const void* w
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), k_lds, vsr::S(stream), p);
         return vsr::launched("conv2d_nhwc_f16/1x1");
     }
-    if (tile_ok) return run_tile(p, M, nk_all_, 1, splitk_ws, splitk_ws_bytes, vsr::S(stream), "conv2d_nhwc_f16/tile");
-    const unsigned gx = vsr::cdiv(M, BM);
+    if (tile_ok) return run_tile(p, M, Mr, nk_all_, 1, splitk_ws, splitk_ws_bytes, vsr::S(stream), "conv2d_nhwc_f16/tile");
+    const unsigned gx = vsr::cdiv(M, BM), gxr = vsr::cdiv(Mr, BM);   // (gxr: the workgroups the decisions count)
     // widest tile the padded count fills; 128 out-channels per workgroup (half the pixel-operand traffic per FLOP: these
     // layers run at the L2's bandwidth, 43 FLOP per byte with the 128 x 64 tile) when that still leaves 128 workgroups
     // before split-K (measured per layer, tools/probe_layers.py with VSR_TUNING=10 / 11)
     const bool wide = (cout_pad & 127) == 0 && g_patch_mode != 8 && g_patch_mode != 11 &&
-                      (g_patch_mode == 10 || (long long)gx * (cout_pad / 128) >= 128);
+                      (g_patch_mode == 10 || (long long)gxr * (cout_pad / 128) >= 128);
     const int bn = wide ? 128 : (cout_pad & 63) == 0 ? 64 : ((cout_pad & 31) == 0 ? 32 : 16);
     const unsigned gy = cout_pad / bn;
     // split-K when the launch cannot fill the chip and K is long
     const int nk_all = (kh * kw * (cin >> 5) + 1) >> 1;
     int splits = 1;
-    if (splitk_ws && (long long)gx * gy < g_splitk_fill && nk_all >= 8) {
-        splits = (int)((g_splitk_fill * 2 + (long long)gx * gy - 1) / ((long long)gx * gy));
+    if (splitk_ws && (long long)gxr * gy < g_splitk_fill && nk_all >= 8) {
+        splits = (int)((g_splitk_fill * 2 + (long long)gxr * gy - 1) / ((long long)gxr * gy));
         if (splits > nk_all / 4) splits = nk_all / 4;
         if (splits > 32) splits = 32;
-        while (splits > 1 && (size_t)splits * M * cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
+        while (splits > 1 && (size_t)splits * (M > Mr ? M : Mr) * cout_pad * sizeof(float) > splitk_ws_bytes) --splits;
         if (splits < 1) splits = 1;
     }
     p.ws = splits > 1 ? (float*)splitk_ws : nullptr;

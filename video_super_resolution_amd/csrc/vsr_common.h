@@ -33,6 +33,16 @@ inline void route(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Batch the convolution launchers DECIDE by (kernel, tile width, split-K) when it is not the batch they run: vsr_conv2d_route_batch(n), n > 0,
+// makes every following launch of this thread choose as if it held n images -- a trunk evaluated on fewer frames than usual (VSR's
+// streaming mode: the frames a window shares with the previous one are cached) then runs the kernels of the full batch, and a frame's
+// result does not depend on the batch it travelled in.  0 (default): decide by the actual batch.
+inline int& route_batch_ref() {
+    static thread_local int n = 0;
+    return n;
+}
+inline int route_batch(int N) { return route_batch_ref() > 0 ? route_batch_ref() : N; }
+
 // Called right after a kernel launch: reports launch-configuration errors without synchronising.
 inline int launched(const char* what) {
     hipError_t e = hipGetLastError();

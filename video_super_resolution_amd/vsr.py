@@ -182,7 +182,11 @@ class VSR(nn.Module):
             if f.data_ptr() not in depth_cache and all(f.data_ptr() != g.data_ptr() for g in new):
                 new.append(f)
         if new:
-            with torch.cuda.stream(s_depth):
+            # streaming mode: the cached frames' share of the batch is missing -- the launchers still choose the kernels of the whole
+            # window's batch, so a frame's prediction is the one the per-window evaluation computes, bit for bit
+            n_window = len({f.data_ptr() for f in list(trip) + list(extra_depth)}) if tc is not None else 0
+            from . import _lib as L
+            with torch.cuda.stream(s_depth), L.route_batch(n_window if n_window > len(new) else 0):
                 if fast:
                     z = self._depth_exec.get()(torch.stack(new))  # [k,1,h,w] float32
                 else:
@@ -208,7 +212,9 @@ class VSR(nn.Module):
             have = [tc["flow"].get(k) for k in keys]
             have = [hv[2] if hv is not None else None for hv in have]
             todo = [p for p, hv in zip(pairs, have) if hv is None]
-            fresh = iter(self.FlowModule.forward_pairs(todo, net)) if todo else iter(())
+            from . import _lib as L
+            with L.route_batch(len(pairs) if 0 < len(todo) < len(pairs) else 0):   # (a cached pair is missing from the batch: see above)
+                fresh = iter(self.FlowModule.forward_pairs(todo, net)) if todo else iter(())
             pics_l = [hv if hv is not None else next(fresh) for hv in have]
             pics = torch.stack(pics_l)
             # keep this window's two pictures only -- WITH their frames, so the keyed addresses stay taken
