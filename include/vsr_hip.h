@@ -373,11 +373,12 @@ int vsr_flow_head_f16(const void* in, int in_ld, int in_coff, int cin, const voi
                       vsr_stream_t stream);
 
 /* The batch the convolution launchers (vsr_conv2d_nhwc_f16 / _sx_, vsr_deconv4s2_nhwc_f16, vsr_conv2d_stem_f16, vsr_flow_head_f16) DECIDE
- * by -- which kernel, tile width and split-K count -- when it is not the batch they are launched on: n > 0 makes every following launch of
- * the calling thread choose as if it held n images (the launch itself covers the real batch); 0 (default) = decide by the real batch.
- * A frame's result then does not depend on the batch it travelled in (VSR.temporal_cache: trunks evaluated on the frames a window
- * does not share with the previous one run the kernels of the full batch -> bit-identical to the per-window evaluation). */
-int vsr_conv2d_route_batch(int n);
+ * by -- which kernel, tile width and split-K count -- when it is not the batch they are launched on: num, den > 0 make every following
+ * launch of the calling thread choose as if its batch N were N * num / den (the launch itself covers the real batch); den = 0 (default):
+ * decide by the real batch.  A frame's result then does not depend on the batch it travelled in (VSR.temporal_cache: trunks evaluated
+ * on the frames a window does not share with the previous one run the kernels of the full batch -> bit-identical to the per-window
+ * evaluation). */
+int vsr_conv2d_route_batch(int num, int den);
 
 /* ConvTranspose2d(k=4, s=2, p=1) (+bias +activation) as its four 2x2-tap phase convolutions in ONE launch (grid.z walks
  * phase and split-K slice).  w_packed4[py*2+px]: the phase's taps packed like vsr_conv2d_nhwc_sx_f16 weights (kernel rows

@@ -182,20 +182,22 @@ class Chain1x1(ctypes.Structure):
 
 
 class route_batch:
-    """`with _lib.route_batch(n):` -- the convolution launchers inside choose kernel / tile width / split-K as if the batch held n images
-    (vsr_conv2d_route_batch): a trunk evaluated on a part of its usual batch runs the usual kernels.  n <= 0: no-op."""
+    """`with _lib.route_batch(num, den):` -- the convolution launchers inside choose kernel / tile width / split-K as if their batch N
+    were N * num / den (vsr_conv2d_route_batch): a trunk evaluated on a part of its usual batch runs the usual kernels.  num == den or
+    den <= 0: no-op."""
 
-    def __init__(self, n: int):
-        self.n = int(n)
+    def __init__(self, num: int, den: int):
+        self.num, self.den = int(num), int(den)
+        self.on = self.den > 0 and self.num > 0 and self.num != self.den
 
     def __enter__(self):
-        if self.n > 0:
-            check(load().vsr_conv2d_route_batch(self.n), "conv2d_route_batch")
+        if self.on:
+            check(load().vsr_conv2d_route_batch(self.num, self.den), "conv2d_route_batch")
         return self
 
     def __exit__(self, *exc):
-        if self.n > 0:
-            load().vsr_conv2d_route_batch(0)
+        if self.on:
+            load().vsr_conv2d_route_batch(0, 0)
         return False
 
 

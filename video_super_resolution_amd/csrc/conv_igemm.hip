@@ -1759,9 +1759,9 @@ int vsr_flownetc_corr_nhwc_f16(const void* feat_a, const void* feat_b, void* out
     return vsr::launched("flownetc_corr");
 }
 
-int vsr_conv2d_route_batch(int n) {
-    VSR_REQUIRE(n >= 0 && n <= 65535, "conv2d_route_batch: %d", n);
-    vsr::route_batch_ref() = n;
+int vsr_conv2d_route_batch(int num, int den) {
+    VSR_REQUIRE(num >= 0 && den >= 0 && num <= 65535 && den <= 65535, "conv2d_route_batch: %d / %d", num, den);
+    vsr::route_scale_ref() = vsr::RouteScale{num, den};
     return VSR_OK;
 }
 

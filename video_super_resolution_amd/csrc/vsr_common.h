@@ -33,15 +33,24 @@ inline void route(const char* fmt, ...) {
     va_end(ap);
 }
 
-// Batch the convolution launchers DECIDE by (kernel, tile width, split-K) when it is not the batch they run: vsr_conv2d_route_batch(n), n > 0,
-// makes every following launch of this thread choose as if it held n images -- a trunk evaluated on fewer frames than usual (VSR's
-// streaming mode: the frames a window shares with the previous one are cached) then runs the kernels of the full batch, and a frame's
-// result does not depend on the batch it travelled in.  0 (default): decide by the actual batch.
-inline int& route_batch_ref() {
-    static thread_local int n = 0;
-    return n;
+// The batch the convolution launchers DECIDE by (kernel, tile width, split-K) when it is not the batch they run:
+// vsr_conv2d_route_batch(num, den), both > 0, makes every following launch of this thread choose as if its batch N were N * num / den -- a
+// trunk evaluated on a part of its usual batch (VSR's streaming mode: the frames a window shares with the previous one are cached; the
+// hourglass then sees 2 of 4 frames, FlowNet2 1 of 2 pairs -- its per-frame layers 2 of 4 frames) runs the kernels of the full batch, and
+// a frame's result does not depend on the batch it travelled in.  den = 0 (default): decide by the actual batch.
+struct RouteScale {
+    int num, den;
+};
+inline RouteScale& route_scale_ref() {
+    static thread_local RouteScale r = {0, 0};
+    return r;
 }
-inline int route_batch(int N) { return route_batch_ref() > 0 ? route_batch_ref() : N; }
+inline int route_batch(int N) {
+    const RouteScale& r = route_scale_ref();
+    if (r.den <= 0 || r.num <= 0) return N;
+    const long long v = ((long long)N * r.num + r.den - 1) / r.den;
+    return v > 65535 ? 65535 : (v < 1 ? 1 : (int)v);
+}
 
 // Called right after a kernel launch: reports launch-configuration errors without synchronising.
 inline int launched(const char* what) {

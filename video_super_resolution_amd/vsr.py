@@ -79,6 +79,9 @@ class VSR(nn.Module):
         # level 2: also the two depth planes of pass 2 behind the hourglass on its stream (beside FlowNet2, the long pole of pass 2's guidance);
         # level 3: also the two flow-picture planes of pass 1 on the main stream behind FlowNet2 (beside the hourglass, pass 1's long pole)
         self.early_planes = int(os.environ.get("VSR_EARLY_PLANES", "1"))
+        # the hourglass on the estimate (only pass 2 reads its depth): True = with pass 2's guidance, as a batch of two with the pass-1 frame,
+        # in the shadow of FlowNet2 (pass 2's long pole); False = batched with the three LR frames in pass 1 (where the hourglass IS the long pole)
+        self.depth_est_late = os.environ.get("VSR_DEPTH_EST_LATE", "0") != "0"   # (measured level: guidance 1 -1.0 ms, guidance 2 +0.9 ms, profiles/r05_early_planes_stages.txt: off)
         self.early_scales = (4,)   # x2 (C3-B): measured level with the plain order (14.15 / 14.26 vs 14.17 / 14.16 frames/s, same box): off there
         # Opt-in streaming mode (OFF by default; the headline benchmark leaves it off): consecutive windows of a clip share
         # two of their three LR frames (utils/video_utils.py:25), so the depth prediction of a frame and the flow picture of a
@@ -186,7 +189,7 @@ class VSR(nn.Module):
             # window's batch, so a frame's prediction is the one the per-window evaluation computes, bit for bit
             n_window = len({f.data_ptr() for f in list(trip) + list(extra_depth)}) if tc is not None else 0
             from . import _lib as L
-            with torch.cuda.stream(s_depth), L.route_batch(n_window if n_window > len(new) else 0):
+            with torch.cuda.stream(s_depth), L.route_batch(n_window, len(new) if n_window > len(new) else 0):
                 if fast:
                     z = self._depth_exec.get()(torch.stack(new))  # [k,1,h,w] float32
                 else:
@@ -213,7 +216,7 @@ class VSR(nn.Module):
             have = [hv[2] if hv is not None else None for hv in have]
             todo = [p for p, hv in zip(pairs, have) if hv is None]
             from . import _lib as L
-            with L.route_batch(len(pairs) if 0 < len(todo) < len(pairs) else 0):   # (a cached pair is missing from the batch: see above)
+            with L.route_batch(len(pairs), len(todo) if 0 < len(todo) < len(pairs) else 0):   # (a cached pair is missing from the batch: see above)
                 fresh = iter(self.FlowModule.forward_pairs(todo, net)) if todo else iter(())
             pics_l = [hv if hv is not None else next(fresh) for hv in have]
             pics = torch.stack(pics_l)
@@ -321,7 +324,8 @@ class VSR(nn.Module):
                     zd = torch.zeros((1, 1, h, w), dtype=torch.float32, device=d.device)
                     self.model.precompute_rows(self._assemble(d, p, [zd, zd, zd], est)[3:5], shared["live"], 3)
                     shared["todo"] = (5, shared["todo"][1])
-            pics, z, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=(est_hw3,), cacheable=True, after_flow=after_flow)
+            pics, z, _ = self._guidance((f0, f1, f2), depth_cache, extra_depth=() if (self.depth_est_late and self._fast()) else (est_hw3,), cacheable=True,
+                                        after_flow=after_flow)
             if s_sr is not None:
                 torch.cuda.current_stream(d.device).wait_stream(s_sr)
             mark()
