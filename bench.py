@@ -532,7 +532,7 @@ def main():
                 # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
                 # gfx950 correction applied) -- a committed measurement of the same launch geometry, not taken in this run
                 # (file, planes of the profiled launch): the 5-plane flat-split launch has its own passes (round 3)
-                pmcs = {(540, 960, 4): (("r03_k_utd3_pmc.json", 5), ("r02_k_utd3_pmc.json", 8), ("r01_k_utd3_pmc.json", 8)),
+                pmcs = {(540, 960, 4): (("r05_k_utd3_pmc_4planes.json", 4), ("r05_k_utd3_pmc_5planes.json", 5), ("r03_k_utd3_pmc.json", 5), ("r02_k_utd3_pmc.json", 8)),
                         (1080, 1920, 2): (("r02_k_utd_s2_pmc.json", 8),),
                         (2160, 3840, 2): (("r04_c5_k_utd_s2_hbm_pmc.json", 5),)}
                 cands = sorted(pmcs.get((h, w, scale), ()), key=lambda fp: fp[1] != planes_dom)   # the launch's own geometry first
@@ -549,13 +549,13 @@ def main():
                             launches_timed=launches, avg_ms=round(ms, 4), algorithmic_flop_per_launch=flop, planes_per_launch=planes_dom)
                 # what an fp16 MFMA loop of this kernel's instruction shape SUSTAINS on this chip (power-governed clock): a committed
                 # same-device measurement (tools/power_roofline.py), reported beside the spec peak -- `frac` stays achieved / spec peak
-                pr_path = os.path.join(ROOT, "profiles", "r04_power_roofline.json")
+                pr_path = os.path.join(ROOT, "profiles", "r05_power_roofline.json")
                 if scale == 4 and os.path.exists(pr_path):
                     with open(pr_path) as f:
                         pr = json.load(f)
                     roof["practical_peak"] = dict(
                         value=pr["mix_loop_tflops"], unit="TFLOP/s", frac_of_practical=round(achieved / pr["mix_loop_tflops"], 4),
-                        bare_mfma_loop_tflops=pr["bare_mfma_tflops"], source="profiles/r04_power_roofline.json (tools/power_roofline.py: 144 "
+                        bare_mfma_loop_tflops=pr["bare_mfma_tflops"], source="profiles/r05_power_roofline.json (tools/power_roofline.py: 144 "
                         "v_mfma_f32_16x16x32_f16 + k_utd3's 304 VALU + 17 LDS per trip, no global memory, random operands, one wave per SIMD, "
                         ">= 2.5 s back to back with k_utd3 on one device; measured on another box than this run)")
                 if part3 is not None:

@@ -11,7 +11,8 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 m = fill_module_(SRProjectionModule().eval(), 0, "model.").cuda()
 P = m._packed()
 a = (torch.randn(N, h, w, 32, device="cuda") * 20).half()
-variants = {"k_utd2 (roles)": lambda: m._utd2(a, P["utd2"][0], N, h, w), "k_utd (uniform)": lambda: m._utd(a, P["utd"][0], N, h, w)}
+variants = {"k_utd2 (roles)": lambda: m._utd2(a, P["utd2"][0], N, h, w), "k_utd (uniform)": lambda: m._utd(a, P["utd"][0], N, h, w),
+            "k_utd3 post (fused uptran)": lambda: m._utd_post(a, P["utd_post"][0], N, h, w)}
 if len(sys.argv) > 4:
     variants = {k: v for k, v in variants.items() if sys.argv[4] in k}
 for fn in variants.values():
