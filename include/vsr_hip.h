@@ -204,6 +204,13 @@ int vsr_sr_utd_f16(const void* in, const void* blob, void* out, int N, int h, in
  * and the slope (fp32) travel in the blob's compress_out region (sr.py:pack_utd_blob(post=...)); slopes_le_one covers that slope too. */
 int vsr_sr_utd_post_f16(const void* in, const void* blob, void* out, void* out_post, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                         vsr_stream_t stream);
+/* The same fused stage on v_mfma_f32_32x32x16_f16 (k_utd4, csrc/sr_utd4.hip: 72 matrix instructions per LR row instead of 144 -- one
+ * wave per SIMD pays ~8 cycles of issue per MFMA whatever its shape, and k_utd3's row was issue-bound; the default build of the
+ * stage).  Arguments as vsr_sr_utd_f16 / vsr_sr_utd_post_f16 (out_post_or_null = NULL: no uptran slice); blob packed by
+ * sr.py:pack_utd_blob(layout=4) -- same regions and sizes, fragments in the 32 x 32 operand layout, K index in the accumulator's
+ * channel order.  Same values as vsr_sr_utd_f16 up to the fp32 summation order of the K dimension (not bit-identical). */
+int vsr_sr_utd4_f16(const void* in, const void* blob, void* out, void* out_post_or_null, int N, int h, int w, int rows_per_seg,
+                    int slopes_le_one, vsr_stream_t stream);
 
 /* vsr_sr_conv1x1_f32 for NHWC fp16 tensors [N,P,32]; weights/bias fp32, cmap_nhwc fp32 [P,32] or NULL. */
 int vsr_sr_conv1x1_f16(const void* in0, const float* w0, int ldw0, const void* in1, const float* w1, int ldw1,

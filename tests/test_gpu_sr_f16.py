@@ -116,6 +116,47 @@ def test_stage_with_fused_uptran_bit_identical(gpu_vsr_f16, shape, rps):
     assert torch.equal(post.view(N, h * w, 32), ref_post)
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 7), (1, 9, 40), (3, 20, 70), (1, 2, 2), (1, 1, 31), (1, 33, 31), (2, 37, 95), (5, 48, 64), (8, 12, 32)])
+@pytest.mark.parametrize("chain", [0, 3])
+def test_stage_on_the_32x32x16_mfma(gpu_vsr_f16, shape, chain):
+    """k_utd4 (csrc/sr_utd4.hip: the fused stage on v_mfma_f32_32x32x16_f16, the default build) against the fp32 stock-operator
+    evaluation of the stage (the bar of k_utd3's test) and against k_utd3 (same products, K summed in another order: fp16 rounding
+    of nearly equal fp32 sums -- a last-place difference on a few values); its own launch geometries (whole marches, row segments,
+    the flat split) agree bit for bit; the fused uptran output is bit for bit what the chain kernel makes of the stage's output."""
+    from video_super_resolution_amd import _lib as L
+    m = gpu_vsr_f16.model
+    N, h, w = shape
+    P = m._packed()
+    rs = np.random.RandomState(N * 1000 + h * 10 + w + chain)
+    a = torch.from_numpy((rs.randn(N, h, w, 32) * 20).astype(np.float16)).cuda()
+    lib = L.load()
+
+    def run(rps, post):
+        out = torch.full((N, h, w, 32), float("nan"), dtype=torch.float16, device="cuda")
+        op = torch.full((N, h, w, 32), float("nan"), dtype=torch.float16, device="cuda") if post else None
+        L.check(lib.vsr_sr_utd4_f16(L.dptr(a, torch.float16), L.dptr(P["utd4"][chain], torch.uint8), L.dptr(out, torch.float16), L.optr(op, torch.float16),
+                                    N, h, w, rps, 1, L.stream()), "sr_utd4_f16")
+        return out, op
+    with torch.no_grad():
+        ref, _ = _stage_reference(m, chain, a.float().permute(0, 3, 1, 2))
+        got, _ = run(h, False)
+        old = m._utd(a, P["utd"][chain], N, h, w)
+    assert torch.isfinite(got.float()).all()
+    err = (got.float().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= 3e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+    d = (got.float() - old.float()).abs()
+    assert d.max().item() <= 2e-3 * old.float().abs().max().item() and (d > 0).float().mean().item() < 0.2, (d.max().item(), (d > 0).float().mean().item())
+    for rps in (6, 1, -3, -7, -64, -1000):
+        o, _ = run(rps, False)
+        assert torch.equal(o, got), rps
+    if chain == 0:   # the blob of stage 0 carries the next group's uptran slice
+        for rps in (h, 6, -7, -64):
+            o, op = run(rps, True)
+            assert torch.equal(o, got), rps
+            want = m._chain([dict(ins=[(got.view(N, h * w, 32), P["ut_w"][3], 32 * 4)], prev=None, bias=P["ut_b"][3], slope=P["ut_a"][3])], N, h * w, keep=[True])[0]
+            assert torch.equal(op.view(N, h * w, 32), want), rps
+
+
 @pytest.mark.parametrize("shape", [(16, 16), (9, 40), (37, 95)])
 def test_forward_with_fused_uptran_bit_identical(gpu_vsr_f16, shape):
     """The whole SR forward with the uptran slice fused into the first stage of every step (default) and as its own launch."""

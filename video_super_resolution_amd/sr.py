@@ -208,14 +208,17 @@ class SRProjectionModule(nn.Module):
             self._const_nhwc.clear()
             return P
         # ---- MFMA path: one packed blob per live chain  lr[j] -> hr[j+1] -> lr[j+3]  and one for the tail deconv
-        P["utd"], P["utd2"], P["utd_post"] = {}, {}, {}
+        P["utd"], P["utd2"], P["utd_post"], P["utd4"] = {}, {}, {}, {}
         for j in range(0, G - 2, 3):
             args = (b.upBlocks[j + 1][0].weight, b.upBlocks[j + 1][0].bias, P["up_a"][j + 1], P["dt_w"][j + 1], _NF * (j + 2),
                     P["dt_b"][j + 1], P["dt_a"][j + 1], b.downBlocks[j + 2][0].weight, b.downBlocks[j + 2][0].bias, P["dn_a"][j + 2])
             P["utd"][j] = pack_utd_blob(*args)             # k_utd (every wave both phases)
             P["utd2"][j] = pack_utd_blob(*args, layout=2)  # k_utd2 (producer / consumer waves)
+            # k_utd4 (v_mfma_f32_32x32x16_f16; the default build of the stage); with the next group's uptran slice when another stage follows
+            post = (P["ut_w"][j + 3], _NF * (j + 4), P["ut_b"][j + 3], P["ut_a"][j + 3]) if j + 6 <= G else None
+            P["utd4"][j] = pack_utd_blob(*args, layout=4, post=post)
             if j + 6 <= G:   # another stage follows: its input = the uptran slice of this stage's output, applied inside this launch
-                P["utd_post"][j] = pack_utd_blob(*args, post=(P["ut_w"][j + 3], _NF * (j + 4), P["ut_b"][j + 3], P["ut_a"][j + 3]))
+                P["utd_post"][j] = pack_utd_blob(*args, post=post)
         P["post_slopes_le_one"] = P["slopes_le_one"] and all(a <= 1.0 for a in P["ut_a"])
         P["utd_out"] = pack_utd_blob(self.out[0].weight, self.out[0].bias, P["out_a"], None, 0, None, 1.0, None, None, 1.0)
         if G == 6:   # compress_out reads exactly two live maps (lr3, lr6): folded into the tail's LR path
@@ -645,6 +648,22 @@ class SRProjectionModule(nn.Module):
         # the launches of precompute_shared / precompute_rows, which share the chip with the guidance trunks)
         return ("sr_utd_f16" if N == 8 else f"sr_utd_f16_p{N}") + ("_side" if getattr(self, "_utd_side", False) else "")
 
+    # the build of the fused stage: 4 = k_utd4 (v_mfma_f32_32x32x16_f16: 72 MFMAs per row), 3 = k_utd3 (v_mfma_f32_16x16x32_f16: 144; the
+    # bit-identity reference of the older builds).  Equal to rounding, not bit for bit (the K dimension is summed in another order).
+    utd_build = int(os.environ.get("VSR_UTD_BUILD", "4"))
+
+    def _utd4(self, a, blob, N, h, w, out=None, post=False):
+        """The fused stage on k_utd4 -> out [N,h,w,32] fp16 (and, post=True, the next group's uptran slice of it)."""
+        if out is None:
+            out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
+        out_post = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device) if post else None
+        tok = L.TIMER.start(self._utd_timer_name(N))
+        L.check(L.load().vsr_sr_utd4_f16(L.dptr(a, torch.float16), L.dptr(blob, torch.uint8), L.dptr(out, torch.float16), L.optr(out_post, torch.float16),
+                                         N, h, w, self._rows_per_segment(N, h, w, cus=getattr(self, "_utd_cus", 256), flat_ok=getattr(self, "utd_flat_split", True)),
+                                         int(self._pack["post_slopes_le_one"] if post else self._pack["slopes_le_one"]), L.stream()), "sr_utd4_f16")
+        L.TIMER.stop(tok)
+        return (out, out_post) if post else out
+
     def _utd_post(self, a, blob, N, h, w, out=None):
         """The fused stage + the next group's uptran slice on its output rows -> (out, out_post), both [N,h,w,32] fp16."""
         if out is None:
@@ -752,7 +771,13 @@ class SRProjectionModule(nn.Module):
                 dst = shared["live"][j + 3][n0:n0 + N].view(N, h, w, _NF) if (n0 and step == self.num_steps - 1) else None
                 if precompute is not None and step == self.num_steps - 1:
                     dst = precompute[j + 3][:N].view(N, h, w, _NF)
-                if self.upscale_factor == 4 and self.fuse_uptran and j in P.get("utd_post", {}) and not L._use_x:
+                if self.upscale_factor == 4 and self.utd_build == 4 and not L._use_x:
+                    if self.fuse_uptran and j + 6 <= G:
+                        o, a_next = self._utd4(a, P["utd4"][j], N, h, w, out=dst, post=True)
+                        live[j + 3], a_next = o.view(N, hp, _NF), a_next.view(N, hp, _NF)
+                    else:
+                        live[j + 3] = self._utd4(a, P["utd4"][j], N, h, w, out=dst).view(N, hp, _NF)
+                elif self.upscale_factor == 4 and self.fuse_uptran and j in P.get("utd_post", {}) and not L._use_x:
                     o, a_next = self._utd_post(a, P["utd_post"][j], N, h, w, out=dst)
                     live[j + 3], a_next = o.view(N, hp, _NF), a_next.view(N, hp, _NF)
                 else:
@@ -1156,6 +1181,15 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a,
     off_dn = 8 * 16 * 1024
     off_dt = off_dn + 8 * 16 * 1024
     off_f = off_dt + 2 * 1024
+    if layout == 4:
+        # k_utd4 (csrc/sr_utd4.hip, v_mfma_f32_32x32x16_f16): [wave 4][column phase 4][tap (dy, dx) 4][K block 2][lane 64][8]:
+        # A[co = lane % 32][k = (kh = lane / 32, e)] = W[ci = 16 kb + 8 kh + e][co][ky = wave + 4 dy][kx = phase + 4 dx]
+        WV = torch.arange(4, device=dev).view(4, 1, 1, 1, 1, 1)
+        PX = torch.arange(4, device=dev).view(1, 4, 1, 1, 1, 1)
+        T4 = torch.arange(4, device=dev).view(1, 1, 4, 1, 1, 1)
+        KB = torch.arange(2, device=dev).view(1, 1, 1, 2, 1, 1)
+        ci4, co4, ky4, kx4 = torch.broadcast_tensors(16 * KB + 8 * (LN >> 5) + J, LN & 31, WV + 4 * (T4 >> 1), PX + 4 * (T4 & 1))
+        up_frag = up_w.detach().float()[ci4, co4, ky4, kx4].to(torch.float16).contiguous()
     blob[0:off_dn] = up_frag.view(torch.uint8).reshape(-1)
     fpar = torch.zeros(128, dtype=torch.float32, device=dev)
     fpar[0:32] = up_b.detach().float()
@@ -1180,13 +1214,30 @@ def pack_utd_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a,
             KX = KX6
         co, ci, ky, kx = torch.broadcast_tensors(co, ci, ky, KX)
         dn_frag = dn_w.detach().float()[co, ci, ky, kx].to(torch.float16).contiguous()
-        blob[off_dn:off_dt] = dn_frag.view(torch.uint8).reshape(-1)
         # ---- 1x1 fragments [mt 2][lane 64][j 8]
         MT = torch.arange(2, device=dev).view(2, 1, 1)
         co = 16 * MT + col_l.view(1, 64, 1)
         ci = tr_col0 + perm[g].view(1, 64, 8)
         co, ci = torch.broadcast_tensors(co, ci)
         dt_frag = tr_w.detach().float()[co, ci].to(torch.float16).contiguous()
+        if layout == 4:
+            # k_utd4: K index (kb, kh, e) <-> channel 16 kb + 8 (e / 4) + 4 kh + e % 4 (the 32 x 32 accumulator's channel order);
+            # down [wave 4][0: kernel row wave (next output row), 1: wave + 4 (current)][kx 8][K block 2][lane 64][8]; 1x1 [K block 2][lane 64][8]
+            WV = torch.arange(4, device=dev).view(4, 1, 1, 1, 1, 1)
+            HL = torch.arange(2, device=dev).view(1, 2, 1, 1, 1, 1)
+            KX8 = torch.arange(8, device=dev).view(1, 1, 8, 1, 1, 1)
+            KB = torch.arange(2, device=dev).view(1, 1, 1, 2, 1, 1)
+            LN6 = lane.view(1, 1, 1, 1, 64, 1)
+            E6 = j8.view(1, 1, 1, 1, 1, 8)
+            ch6 = 16 * KB + 8 * (E6 >> 2) + 4 * (LN6 >> 5) + (E6 & 3)
+            co6, ci6, ky6, kx6 = torch.broadcast_tensors(LN6 & 31, ch6, WV + 4 * HL, KX8)
+            dn_frag = dn_w.detach().float()[co6, ci6, ky6, kx6].to(torch.float16).contiguous()
+            KB3 = torch.arange(2, device=dev).view(2, 1, 1)
+            LN3 = lane.view(1, 64, 1)
+            E3 = j8.view(1, 1, 8)
+            co3, ci3 = torch.broadcast_tensors(LN3 & 31, tr_col0 + 16 * KB3 + 8 * (E3 >> 2) + 4 * (LN3 >> 5) + (E3 & 3))
+            dt_frag = tr_w.detach().float()[co3, ci3].to(torch.float16).contiguous()
+        blob[off_dn:off_dt] = dn_frag.view(torch.uint8).reshape(-1)
         blob[off_dt:off_f] = dt_frag.view(torch.uint8).reshape(-1)
         fpar[32:64] = tr_b.detach().float()
         fpar[64:96] = dn_b.detach().float()

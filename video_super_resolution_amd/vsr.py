@@ -185,11 +185,12 @@ class VSR(nn.Module):
             if f.data_ptr() not in depth_cache and all(f.data_ptr() != g.data_ptr() for g in new):
                 new.append(f)
         if new:
-            # streaming mode: the cached frames' share of the batch is missing -- the launchers still choose the kernels of the whole
-            # window's batch, so a frame's prediction is the one the per-window evaluation computes, bit for bit
-            n_window = len({f.data_ptr() for f in list(trip) + list(extra_depth)}) if tc is not None else 0
+            # pass 1's hourglass batch is "the window's frames + the estimate" (4); fewer run when the estimate IS frame 0 (first call) or,
+            # in streaming mode, when predictions of shared frames are cached -- the launchers still choose the kernels of the batch of
+            # 4, so a frame's prediction does not depend on the batch it travelled in (streaming == per-window evaluation, bit for bit)
+            n_window = (len(trip) + len(extra_depth)) if cacheable else 0
             from . import _lib as L
-            with torch.cuda.stream(s_depth), L.route_batch(n_window, len(new) if n_window > len(new) else 0):
+            with torch.cuda.stream(s_depth), L.route_batch(n_window, len(new) if n_window != len(new) else 0):
                 if fast:
                     z = self._depth_exec.get()(torch.stack(new))  # [k,1,h,w] float32
                 else:
