@@ -12,7 +12,8 @@ m = fill_module_(SRProjectionModule().eval(), 0, "model.").cuda()
 P = m._packed()
 a = (torch.randn(N, h, w, 32, device="cuda") * 20).half()
 variants = {"k_utd2 (roles)": lambda: m._utd2(a, P["utd2"][0], N, h, w), "k_utd (uniform)": lambda: m._utd(a, P["utd"][0], N, h, w),
-            "k_utd3 post (fused uptran)": lambda: m._utd_post(a, P["utd_post"][0], N, h, w)}
+            "k_utd3 post (fused uptran)": lambda: m._utd_post(a, P["utd_post"][0], N, h, w),
+            "k_utd4 (32x32x16)": lambda: m._utd4(a, P["utd4"][0], N, h, w), "k_utd4 post": lambda: m._utd4(a, P["utd4"][0], N, h, w, post=True)}
 if len(sys.argv) > 4:
     variants = {k: v for k, v in variants.items() if sys.argv[4] in k}
 for fn in variants.values():

@@ -33,33 +33,71 @@ constexpr int U4_LDS_POST = U4_LDS + 2 * U4_OROW + 2048 + 128;
 
 __device__ __forceinline__ f16v mfma32(h8 a, h8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-// 16 accumulator values of a lane -> PReLU -> 8 packed fp16 pairs = the two K-block operands of the next product
-struct Op2 {
-    h8 k[2];
+// One column phase's operand of the next product: the lane's 16 channels of one pixel as 8 packed fp16 pairs; dwords 4 kb .. 4 kb + 3 are
+// the B operand of K block kb.  (Kept as dwords: the hand-placed activation stages finish them one at a time, in place.)
+struct Ob {
+    h2 d[8];
 };
-__device__ __forceinline__ Op2 act16(const f16v& a, h2 slope, bool use_max) {
-    h2 r[8];
+__device__ __forceinline__ h8 opk(const Ob& o, int kb) {
+    return h8{o.d[4 * kb][0], o.d[4 * kb][1], o.d[4 * kb + 1][0], o.d[4 * kb + 1][1], o.d[4 * kb + 2][0], o.d[4 * kb + 2][1], o.d[4 * kb + 3][0], o.d[4 * kb + 3][1]};
+}
+// 16 accumulator values of a lane -> PReLU -> 8 packed fp16 pairs (plain form: cold rows)
+__device__ __forceinline__ Ob act16(const f16v& a, h2 slope, bool use_max) {
+    Ob o;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         const h2 c = __builtin_convertvector(f2v4{a[2 * d], a[2 * d + 1]}, h2);
         const h2 m = c * slope;
-        r[d] = use_max ? __builtin_elementwise_max(c, m) : __builtin_elementwise_min(c, m);
+        o.d[d] = use_max ? __builtin_elementwise_max(c, m) : __builtin_elementwise_min(c, m);
     }
-    Op2 o;
-    o.k[0] = h8{r[0][0], r[0][1], r[1][0], r[1][1], r[2][0], r[2][1], r[3][0], r[3][1]};
-    o.k[1] = h8{r[4][0], r[4][1], r[5][0], r[5][1], r[6][0], r[6][1], r[7][0], r[7][1]};
     return o;
+}
+// The same as 24 single instructions the step schedule places one by one ("program positions" 0..23): convert 0, convert 1, then per
+// dword pair p = 0..2: multiply 2p, multiply 2p+1, convert 2p+2, max 2p, max 2p+1, convert 2p+3; then multiply 6, 7, max 6, 7.
+// Chunks of the program that end behind a convert -- [0,2) [2,5) [5,8) [8,11) [11,14) [14,17) [17,20) [20,24) -- keep a packed-math
+// instruction (v_pk_mul / v_pk_max) from being the last one in front of the next MFMA: that costs an s_nop every time (seen in the ISA:
+// none behind v_cvt_pk_f16_f32, v_add_f32, DPP moves).  Each result is pinned to the gap it is written in.
+struct ActT {
+    h2 c[8], m[8];
+};
+__device__ __forceinline__ constexpr int act_chunk_begin(int c) { return c == 0 ? 0 : (c >= 8 ? 24 : 3 * c - 1); }
+template <bool ZERO>
+__device__ __forceinline__ void act_st(int j, const f16v& a, ActT& t, Ob& o, h2 slope, bool use_max, bool keep) {
+    // position -> (operation 0 convert / 1 multiply / 2 max, dword)
+    int op, d;
+    if (j < 2) { op = 0; d = j; }
+    else if (j < 20) {
+        const int p = (j - 2) / 6, k = (j - 2) % 6;
+        op = (k == 2 || k == 5) ? 0 : (k < 2 ? 1 : 2);
+        d = k == 2 ? 2 * p + 2 : k == 5 ? 2 * p + 3 : ((k == 0 || k == 3) ? 2 * p : 2 * p + 1);
+    } else { op = j < 22 ? 1 : 2; d = 6 + (j & 1); }
+    if (op == 0) {
+        t.c[d] = __builtin_convertvector(f2v4{a[2 * d], a[2 * d + 1]}, h2);
+        asm volatile("" : : "v"(t.c[d]));
+    } else if (op == 1) {
+        t.m[d] = t.c[d] * slope;
+        asm volatile("" : : "v"(t.m[d]));
+    } else {
+        h2 r = use_max ? __builtin_elementwise_max(t.c[d], t.m[d]) : __builtin_elementwise_min(t.c[d], t.m[d]);
+        if (ZERO) r = keep ? r : h2{(_Float16)0.0f, (_Float16)0.0f};   // (columns outside the image: the conv's zero padding)
+        o.d[d] = r;
+        asm volatile("" : : "v"(o.d[d]));
+    }
 }
 
 // the tile moved down one pixel: lane j takes lane j + 1 (whole-wave shift; lane 31 / 63 -- position 32, which only the discarded 32nd
 // output reads -- take whatever the neighbour holds)
-__device__ __forceinline__ h8 shift1(h8 v) {
-    const u4w s = __builtin_bit_cast(u4w, v);
-    u4w d;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) d[q] = (unsigned)__builtin_amdgcn_mov_dpp((int)s[q], 0x130, 0xF, 0xF, true);   // wave_shl:1
-    return __builtin_bit_cast(h8, d);
+__device__ __forceinline__ h2 shift1d(h2 v) {
+    return __builtin_bit_cast(h2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));   // wave_shl:1
 }
+__device__ __forceinline__ Ob shift1(const Ob& v) {
+    Ob o;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o.d[d] = shift1d(v.d[d]);
+    return o;
+}
+
+#define VSR_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <bool ALLMAX, int POST>
 __global__ void __launch_bounds__(256)
@@ -194,47 +232,49 @@ k_utd4(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     };
     const bool edge_strip = (x0 == 0) || (4 * (x0 + 32) - 2 >= 4 * w);
     // whole deconv -> PReLU -> 1x1 -> PReLU of this wave's HR row: column phase px -> operand pair of the down conv
-    auto p1 = [&](const h8 (&Bf)[4][2], Op2 (&ob)[4]) __attribute__((always_inline)) {
+    // columns of this lane's position outside the image, per column phase (the conv's zero padding; only edge strips have any)
+    bool col_ok[4];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+        const int c_hr = 4 * (x0 + j32) + px - 2;
+        col_ok[px] = (c_hr >= 0) && (c_hr < 4 * w);
+    }
+    auto p1 = [&](const h8 (&Bf)[4][2], Ob (&ob)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             f16v acc;
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc = mfma32(Aup[px][k >> 1][k & 1], Bf[k >> 1][k & 1], k == 0 ? bup : acc);
-            const Op2 u = act16(acc, a_up2, up_max);
-            f16v a2 = mfma32(adt[0], u.k[0], bdt);
-            a2 = mfma32(adt[1], u.k[1], a2);
-            Op2 o = act16(a2, a_dt2, dt_max);
-            if (edge_strip) {   // columns outside the image are the conv's zero padding
-                const int c_hr = 4 * (x0 + j32) + px - 2;
-                const bool col_ok = (c_hr >= 0) && (c_hr < 4 * w);
-                h8 z;
+            const Ob u = act16(acc, a_up2, up_max);
+            f16v a2 = mfma32(adt[0], opk(u, 0), bdt);
+            a2 = mfma32(adt[1], opk(u, 1), a2);
+            Ob o = act16(a2, a_dt2, dt_max);
+            if (edge_strip) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
-                o.k[0] = col_ok ? o.k[0] : z;
-                o.k[1] = col_ok ? o.k[1] : z;
+                for (int d = 0; d < 8; ++d) o.d[d] = col_ok[px] ? o.d[d] : h2{(_Float16)0.0f, (_Float16)0.0f};
             }
             ob[px] = o;
         }
     };
-    auto zero_row = [&](Op2 (&ob)[4]) __attribute__((always_inline)) {
-        h8 z;
+    auto zero_row = [&](Ob (&ob)[4]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.0f;
+        for (int px = 0; px < 4; ++px)
 #pragma unroll
-        for (int px = 0; px < 4; ++px) ob[px].k[0] = ob[px].k[1] = z;
+            for (int d = 0; d < 8; ++d) ob[px].d[d] = h2{(_Float16)0.0f, (_Float16)0.0f};
     };
     // down conv over this wave's HR row of the previous group: finishes the current output row (kernel row wv + 4, on top of the
     // carried sum) and starts the next (kernel row wv).  Tap order 0,4,1,5,..: both uses of a column phase's tile are adjacent.
-    auto down = [&](const Op2 (&obP)[4], f16v& accd) __attribute__((always_inline)) {
+    auto down = [&](const Ob (&obP)[4], f16v& accd) __attribute__((always_inline)) {
         f16v nxt;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
 #pragma unroll
             for (int sft = 0; sft < 2; ++sft) {
                 const int kx = px + 4 * sft;
+                const Ob src = sft ? shift1(obP[px]) : obP[px];
                 h8 b[2];
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) b[kb] = sft ? shift1(obP[px].k[kb]) : obP[px].k[kb];
+                for (int kb = 0; kb < 2; ++kb) b[kb] = opk(src, kb);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     const bool first = (px == 0 && sft == 0 && kb == 0);
@@ -263,47 +303,74 @@ k_utd4(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     };
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)n_planes * h * w * NF * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t out2_rsrc = __builtin_amdgcn_make_buffer_rsrc(POST ? out2 : out, 0, (int)((size_t)n_planes * h * w * NF * 2), 0x00020000);
-    // reduce of LR row i: the 4 partial tiles summed in a fixed order, bias, PReLU, fp16 (k_utd3's arithmetic)
+    // reduce of LR row i: the 4 partial tiles summed in a fixed order, bias, PReLU, fp16 (k_utd3's arithmetic and its 31 single-instruction
+    // stages: 4 x (0 + p0 + p1 + p2 + p3 + bias), slope multiply, max / select, 2 converts, store); lanes without an output pixel store to
+    // an out-of-range buffer offset
+    struct RedU {
+        float s[4], t[4];
+        unsigned lo, hi;
+    };
+    auto red_stage = [&](int j, int i, const f4 (&pr)[4], RedU& u) __attribute__((always_inline)) {
+        const int e = j & 3;
+        if (j < 4) u.s[e] = 0.0f + pr[0][e];
+        else if (j < 16) u.s[e] += pr[j >> 2][e];
+        else if (j < 20) u.s[e] += bdn[e];
+        else if (j < 24) u.t[e] = u.s[e] * a_dn;
+        else if (j < 28) u.s[e] = ALLMAX ? __builtin_fmaxf(u.s[e], u.t[e]) : (u.s[e] >= 0.0f ? u.s[e] : u.t[e]);
+        else if (j == 28) u.lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v4{u.s[0], u.s[1]}, h2));
+        else if (j == 29) u.hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v4{u.s[2], u.s[3]}, h2));
+        else {
+            unsigned a = (unsigned)(((((size_t)n * h + i) * w + x0 + rj) * NF + 4 * rc4) * 2);
+            asm volatile("" : "+v"(a));
+            __builtin_amdgcn_raw_buffer_store_b64(u2w{u.lo, u.hi}, out_rsrc, red_ok ? a : 0xFFFFFFFFu, 0, 0);
+            if (POST) *reinterpret_cast<u2w*>(orow + (i & 1) * U4_OROW + lr_off(rj, rc4 >> 1) + 8 * (rc4 & 1)) = u2w{u.lo, u.hi};
+        }
+        if (j < 20 || (j >= 24 && j < 28)) asm volatile("" : "+v"(u.s[e]));
+        else if (j < 24) asm volatile("" : "+v"(u.t[e]));
+        else if (j == 28) asm volatile("" : "+v"(u.lo));
+        else if (j == 29) asm volatile("" : "+v"(u.hi));
+    };
     auto reduce_store = [&](int i, const unsigned char* pbase) __attribute__((always_inline)) {
         f4 pr[4];
+        RedU u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) pr[k] = *reinterpret_cast<const f4*>(pbase + part_rd + k * PART_W_PITCH);
-        float s[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = 0.0f + pr[0][e];
-            v += pr[1][e];
-            v += pr[2][e];
-            v += pr[3][e];
-            v += bdn[e];
-            const float t = v * a_dn;
-            s[e] = ALLMAX ? __builtin_fmaxf(v, t) : (v >= 0.0f ? v : t);
-        }
-        const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v4{s[0], s[1]}, h2));
-        const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v4{s[2], s[3]}, h2));
-        unsigned a = (unsigned)(((((size_t)n * h + i) * w + x0 + rj) * NF + 4 * rc4) * 2);
-        asm volatile("" : "+v"(a));
-        __builtin_amdgcn_raw_buffer_store_b64(u2w{lo, hi}, out_rsrc, red_ok ? a : 0xFFFFFFFFu, 0, 0);
-        if (POST) *reinterpret_cast<u2w*>(orow + (i & 1) * U4_OROW + lr_off(rj, rc4 >> 1) + 8 * (rc4 & 1)) = u2w{lo, hi};
+        for (int j = 0; j < 31; ++j) red_stage(j, i, pr, u);
     };
     // POST: the next group's uptran 1x1 on finished row i (in orow[i & 1] since the barrier behind its reduce): this wave's quadrant
-    // (out-channel tile wv >> 1, pixel tile wv & 1) on the 16 x 16 x 32 shape -- k_utd3's arithmetic, bit-identical to the chain kernel
+    // (out-channel tile wv >> 1, pixel tile wv & 1) on the 16 x 16 x 32 shape -- k_utd3's arithmetic, bit-identical to the chain kernel.
+    // Stages: 0 operands from LDS, 1 MFMA, 2-3 convert, 4-5 slope multiply, 6-7 max / min, 8 store.
     const int ppx = 16 * pnt + l15;
     const bool post_px_ok = ppx < TX && x0 + ppx < w;
-    auto post_row = [&](int i) __attribute__((always_inline)) {
-        if (POST) {
-            const h8 b = *reinterpret_cast<const h8*>(orow + (i & 1) * U4_OROW + lr_off(ppx, g));
-            const h8 a = *reinterpret_cast<const h8*>(postw + (pmt * 64 + lane) * 16);
-            f4 acc = *reinterpret_cast<const f4*>(postw + 2048 + (16 * pmt + 4 * g) * 4);
-            acc = mfma16(a, b, acc);
-            const h2 c0 = __builtin_convertvector(f2v4{acc[0], acc[1]}, h2), c1 = __builtin_convertvector(f2v4{acc[2], acc[3]}, h2);
-            const h2 m0 = c0 * a_post2, m1 = c1 * a_post2;
-            const h2 q0 = post_max ? __builtin_elementwise_max(c0, m0) : __builtin_elementwise_min(c0, m0);
-            const h2 q1 = post_max ? __builtin_elementwise_max(c1, m1) : __builtin_elementwise_min(c1, m1);
+    struct PostU {
+        h8 a, b;
+        f4 acc;
+        h2 c[2], m[2], r[2];
+    };
+    auto post_stage = [&](int j, int i, PostU& u) __attribute__((always_inline)) {
+        if (j == 0) {
+            u.b = *reinterpret_cast<const h8*>(orow + (i & 1) * U4_OROW + lr_off(ppx, g));
+            u.a = *reinterpret_cast<const h8*>(postw + (pmt * 64 + lane) * 16);
+            u.acc = *reinterpret_cast<const f4*>(postw + 2048 + (16 * pmt + 4 * g) * 4);
+        } else if (j == 1) u.acc = mfma16(u.a, u.b, u.acc);
+        else if (j < 4) { u.c[j - 2] = __builtin_convertvector(f2v4{u.acc[2 * (j - 2)], u.acc[2 * (j - 2) + 1]}, h2); asm volatile("" : : "v"(u.c[j - 2])); }
+        else if (j < 6) { u.m[j - 4] = u.c[j - 4] * a_post2; asm volatile("" : : "v"(u.m[j - 4])); }
+        else if (j < 8) {
+            u.r[j - 6] = post_max ? __builtin_elementwise_max(u.c[j - 6], u.m[j - 6]) : __builtin_elementwise_min(u.c[j - 6], u.m[j - 6]);
+            asm volatile("" : : "v"(u.r[j - 6]));
+        } else {
             unsigned ad = (unsigned)(((((size_t)n * h + i) * w + x0 + ppx) * NF + 16 * pmt + 4 * g) * 2);
             asm volatile("" : "+v"(ad));
             const unsigned off = (post_px_ok && i >= r0 && i < r1) ? ad : 0xFFFFFFFFu;
-            __builtin_amdgcn_raw_buffer_store_b64(u2w{__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)}, out2_rsrc, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u2w{__builtin_bit_cast(unsigned, u.r[0]), __builtin_bit_cast(unsigned, u.r[1])}, out2_rsrc, off, 0, 0);
+        }
+    };
+    auto post_row = [&](int i) __attribute__((always_inline)) {
+        if (POST) {
+            PostU u;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) post_stage(j, i, u);
         }
     };
 
@@ -315,7 +382,7 @@ k_utd4(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
         *reinterpret_cast<u4w*>(lrr + lr_slot(r0 + 1) + lr_st) = fetch_lr(r0 + 1);
     }
     __syncthreads();
-    Op2 obP[4];   // this wave's HR row of the previous group, as down-conv operands [column phase]
+    Ob obP[4];   // this wave's HR row of the previous group, as down-conv operands [column phase]
     {
         const int i = r0 - 1, r_hr = 4 * i + 2 + wv;
         if (r_hr >= 0 && r_hr < 4 * h) {
@@ -332,31 +399,195 @@ k_utd4(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
 
     int s_i = lr_slot(r0), s_i1 = lr_slot(r0 + 1), s_i2 = lr_slot(r0 + 2);
     int part_cur = (r0 & 1) * PART_BUF;
-    h8 Bf[4][2];
-    load_lr_frags(s_i, s_i1, Bf);
-    // Step i:  [LR row i+3 requested; reduce of row i-3]  BARRIER  [POST of row i-3; deconv -> 1x1 of G(i); down conv over G(i-1); partial
-    //          tiles of row i-1; LR row i+3 -> the slot of row i; LR operands of step i+1]
-    for (int i = r0; i < r1; ++i) {
+    // A cold row (the first three of a march: nothing to reduce yet; for waves 2, 3 the image's last LR row): compiler-scheduled.
+    // Step i:  [LR operands of rows i, i+1 -> registers; LR row i+3 requested; reduce of row i-3]  BARRIER  [POST of row i-3; deconv -> 1x1 of
+    //          G(i); down conv over G(i-1); partial tiles of row i-1; LR row i+3 -> the slot of row i]
+    auto step_plain = [&](int i) __attribute__((always_inline)) {
         const u4w nxt = fetch_lr(i + 3);
         unsigned char* part_prev = part + (part_cur ^ PART_BUF);   // rows i-1 (written below) and i-3 (reduced here)
-        const int r_hr = 4 * i + 2 + wv;
-        const bool row_ok = r_hr < 4 * h;   // (waves 2, 3 on the image's last LR row: their HR row lies below the image)
+        const bool row_ok = 4 * i + 2 + wv < 4 * h;   // (waves 2, 3 on the image's last LR row: their HR row lies below the image)
+        h8 Bf[4][2];
+        load_lr_frags(s_i, s_i1, Bf);
         if (i - 3 >= r0) reduce_store(i - 3, part_prev);
         __syncthreads();
         if (i - 3 >= r0) post_row(i - 3);
-        Op2 obN[4];
+        Ob obN[4];
         if (row_ok) p1(Bf, obN);
         else zero_row(obN);
         f16v accd;
         down(obP, accd);   // (the partial row of i = r0 is row r0-1's: never reduced)
 #pragma unroll
         for (int px = 0; px < 4; ++px) obP[px] = obN[px];
-        load_lr_frags(s_i1, s_i2, Bf);
         store_partials(part_prev, accd);
         *reinterpret_cast<u4w*>(lrr + s_i + lr_st) = nxt;   // row i+3 -> slot of row i (lanes without a piece: a pad behind the rows)
         const int t = s_i; s_i = s_i1; s_i1 = s_i2; s_i2 = t;
         part_cur ^= PART_BUF;
-    }
+    };
+    // A row of the steady state, its 72 MFMAs of 32 cycles in a hand-placed order with at most ~5 single-issue instructions in each gap
+    // (which hide: MI355X_MICROARCH.md, "single-issue instructions HIDDEN per v_mfma_f32_32x32x16 gap"), fenced gap by gap:
+    //   phase 1 (32 gaps): the down conv over G(i-1) from obP -- column phases 0..3, taps px and px + 4 (the tile moved one pixel by 8 DPP
+    //     moves in the gaps before), [current row: K blocks 0, 1; next row: K blocks 0, 1] per tap.  Its gaps carry: the SECOND activation of
+    //     column phases 2, 3 of G(i-1) (pending from the step before, finishing obP[2], obP[3] before their taps), the reduce of row i-3,
+    //     the LR operands of G(i).
+    //   BARRIER (reduce reads and LR operand reads above; partial tiles and the LR row store below)
+    //   phase 2 (40 gaps): deconv of column phases 0..3 (8 MFMAs each) with the 1x1s (2 each) behind the phase after next:
+    //     D0 D1 T0 D2 T1 D3 T2 T3; gaps: partial tiles of row i-1, LR row i+3, POST of row i-3, first activations of phases 0..3, second
+    //     activations of phases 0, 1 (in place into obP[0], obP[1]: their taps are done).  The second activations of phases 2, 3 stay
+    //     pending in a2p[] for the next step's phase 1.
+    // (the carried sum alternates between `carry` and `carry2` from step to step -- PAR says which holds it on entry: the current row's
+    //  chain runs in place over the incoming one, the next row's chain starts in the other; carried in one variable the compiler moved
+    //  two 16-register tuples per row)
+    f16v a2p[2], carry2;
+    auto step_steady = [&](int i, auto pendc, auto edgec, auto parc) __attribute__((always_inline)) {
+        constexpr bool PEND = decltype(pendc)::value, EDGE = decltype(edgec)::value, PAR = decltype(parc)::value;
+        f16v& cin = PAR ? carry2 : carry;
+        f16v& cout = PAR ? carry : carry2;
+        const u4w nxt = fetch_lr(i + 3);
+        unsigned char* part_prev = part + (part_cur ^ PART_BUF);
+        f16v accd;
+        f4 pr[4];
+        RedU ru;
+        PostU pu;
+        Ob sh;
+        ActT tA, tB;
+        h8 Bf[4][2];
+        f16v z16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z16[r] = 0.0f;
+        VSR_FENCE();
+        // ---------------------------------------------------------------- phase 1
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int px = s >> 3, q = s & 7, sft = q >> 2, rr = q & 3, kb = rr & 1, kx = px + 4 * sft;
+            const h8 b = opk(sft ? sh : obP[px], kb);
+            if (rr < 2) accd = mfma32(Adn[1][kx][kb], b, s == 0 ? cin : accd);
+            else cout = mfma32(Adn[0][kx][kb], b, s == 2 ? z16 : cout);
+            VSR_FENCE();   // (the gap's MFMA first: ahead of it, a filler that reads the previous MFMA's result waits for it with s_nops)
+            if (s < 4) pr[s] = *reinterpret_cast<const f4*>(part_prev + part_rd + s * PART_W_PITCH);
+            if (PEND && s < 16) {   // second activation of column phases 2 (gaps 0-7) and 3 (gaps 8-15) of G(i-1): one chunk per gap
+#pragma unroll
+                for (int v = act_chunk_begin(s & 7); v < act_chunk_begin((s & 7) + 1); ++v) {
+                    if (s < 8) act_st<EDGE>(v, a2p[0], tA, obP[2], a_dt2, dt_max, col_ok[2]);
+                    else act_st<EDGE>(v, a2p[1], tB, obP[3], a_dt2, dt_max, col_ok[3]);
+                }
+            }
+            if (q < 4) {   // the tile of this column phase moved one pixel, for tap px + 4 (gaps 8 px + 4 ..)
+                sh.d[2 * q] = shift1d(obP[px].d[2 * q]);
+                sh.d[2 * q + 1] = shift1d(obP[px].d[2 * q + 1]);
+            }
+            if (s >= 16) {
+#pragma unroll
+                for (int v = ((s - 16) * 31) / 16; v < ((s - 15) * 31) / 16; ++v) red_stage(v, i - 3, pr, ru);
+            }
+            if (s >= 28) {   // LR operands of G(i): rows i (dy = 1) and i + 1 (dy = 0)
+#pragma unroll
+                for (int u = 2 * (s - 28); u < 2 * (s - 28) + 2; ++u) {
+                    const int t = u >> 1, kb2 = u & 1;
+                    Bf[t][kb2] = *reinterpret_cast<const h8*>(lrr + ((t >> 1) ? s_i : s_i1) + lr_b[t & 1][kb2]);
+                }
+            }
+            VSR_FENCE();
+        }
+        __syncthreads();
+        VSR_FENCE();
+        // ---------------------------------------------------------------- phase 2
+        f16v acc[4], a2[2];
+        Ob u[4];
+        ActT tU, tD;
+#pragma unroll
+        for (int t = 0; t < 40; ++t) {
+            // the MFMA of the gap
+            if (t < 8) acc[0] = mfma32(Aup[0][t >> 1][t & 1], Bf[t >> 1][t & 1], t == 0 ? bup : acc[0]);
+            else if (t < 16) acc[1] = mfma32(Aup[1][(t - 8) >> 1][t & 1], Bf[(t - 8) >> 1][t & 1], t == 8 ? bup : acc[1]);
+            else if (t < 18) a2[0] = mfma32(adt[t - 16], opk(u[0], t - 16), t == 16 ? bdt : a2[0]);
+            else if (t < 26) acc[2] = mfma32(Aup[2][(t - 18) >> 1][t & 1], Bf[(t - 18) >> 1][t & 1], t == 18 ? bup : acc[2]);
+            else if (t < 28) a2[1] = mfma32(adt[t - 26], opk(u[1], t - 26), t == 26 ? bdt : a2[1]);
+            else if (t < 36) acc[3] = mfma32(Aup[3][(t - 28) >> 1][t & 1], Bf[(t - 28) >> 1][t & 1], t == 28 ? bup : acc[3]);
+            else if (t < 38) a2p[0] = mfma32(adt[t - 36], opk(u[2], t - 36), t == 36 ? bdt : a2p[0]);
+            else {
+                if (t == 38) {   // (the tail of phase 3's first activation has no MFMA left to hide behind)
+#pragma unroll
+                    for (int v = 8; v < 24; ++v) act_st<false>(v, acc[3], tU, u[3], a_up2, up_max, true);
+                }
+                a2p[1] = mfma32(adt[t - 38], opk(u[3], t - 38), t == 38 ? bdt : a2p[1]);
+            }
+            VSR_FENCE();
+            // the gap's fillers
+            if (t < 4) *reinterpret_cast<f4*>(part_prev + part_wr + 32 * t) = f4{accd[4 * t], accd[4 * t + 1], accd[4 * t + 2], accd[4 * t + 3]};
+            if (t == 4) *reinterpret_cast<u4w*>(lrr + s_i + lr_st) = nxt;
+            if (POST) {
+                if (t == 1) post_stage(0, i - 3, pu);
+                else if (t == 3) post_stage(1, i - 3, pu);
+                else if (t >= 5 && t < 8) {
+#pragma unroll
+                    for (int v = 2 + (t - 5) * 7 / 3; v < 2 + (t - 4) * 7 / 3; ++v) post_stage(v, i - 3, pu);
+                }
+            }
+            // first activations: phase 0 a chunk per gap behind D1; phases 1, 2: 5 + 3 positions in their predecessor's two 1x1 gaps, then
+            // 2 per gap (AHEAD of the second activation's chunk, which ends with a convert); phase 3: 5 + 3, the rest in front of its 1x1
+            if (t >= 8 && t < 16) {
+#pragma unroll
+                for (int v = act_chunk_begin(t - 8); v < act_chunk_begin(t - 7); ++v) act_st<false>(v, acc[0], tU, u[0], a_up2, up_max, true);
+            } else if (t >= 16 && t < 26) {
+#pragma unroll
+                for (int v = (t == 16 ? 0 : t == 17 ? 5 : 8 + 2 * (t - 18)); v < (t == 16 ? 5 : t == 17 ? 8 : 10 + 2 * (t - 18)); ++v)
+                    act_st<false>(v, acc[1], tU, u[1], a_up2, up_max, true);
+            } else if (t >= 26 && t < 36) {
+#pragma unroll
+                for (int v = (t == 26 ? 0 : t == 27 ? 5 : 8 + 2 * (t - 28)); v < (t == 26 ? 5 : t == 27 ? 8 : 10 + 2 * (t - 28)); ++v)
+                    act_st<false>(v, acc[2], tU, u[2], a_up2, up_max, true);
+            } else if (t >= 36 && t < 38) {
+#pragma unroll
+                for (int v = (t == 36 ? 0 : 5); v < (t == 36 ? 5 : 8); ++v) act_st<false>(v, acc[3], tU, u[3], a_up2, up_max, true);
+            }
+            if (t >= 18 && t < 26) {           // second activation, phase 0 -> obP[0] in place: a chunk per gap
+#pragma unroll
+                for (int v = act_chunk_begin(t - 18); v < act_chunk_begin(t - 17); ++v) act_st<EDGE>(v, a2[0], tD, obP[0], a_dt2, dt_max, col_ok[0]);
+            } else if (t >= 28 && t < 36) {    // phase 1 -> obP[1]
+#pragma unroll
+                for (int v = act_chunk_begin(t - 28); v < act_chunk_begin(t - 27); ++v) act_st<EDGE>(v, a2[1], tD, obP[1], a_dt2, dt_max, col_ok[1]);
+            }
+            VSR_FENCE();
+        }
+        const int tt = s_i; s_i = s_i1; s_i1 = s_i2; s_i2 = tt;
+        part_cur ^= PART_BUF;
+    };
+    // the second activations a steady step left pending (column phases 2, 3 of the last group)
+    auto drain_pending = [&](auto edgec) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edgec)::value;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            Ob o = act16(a2p[k], a_dt2, dt_max);
+            if (EDGE) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d) o.d[d] = col_ok[2 + k] ? o.d[d] : h2{(_Float16)0.0f, (_Float16)0.0f};
+            }
+            obP[2 + k] = o;
+        }
+    };
+    auto march = [&](auto edgec) __attribute__((always_inline)) {
+        const int i_st = __builtin_amdgcn_readfirstlane(min(r0 + 3, r1));
+        const int i_en = __builtin_amdgcn_readfirstlane(max(i_st, min(r1, h - (wv >= 2 ? 1 : 0))));   // every row has one barrier on either path
+        int i = r0;
+        for (; i < i_st; ++i) step_plain(i);
+        if (i < i_en) {
+            step_steady(i, BoolC<false>{}, edgec, BoolC<false>{});   // (nothing pending behind a cold row; leaves the carried sum in carry2)
+            ++i;
+            for (; i + 1 < i_en; i += 2) {
+                step_steady(i, BoolC<true>{}, edgec, BoolC<true>{});
+                step_steady(i + 1, BoolC<true>{}, edgec, BoolC<false>{});
+            }
+            if (i < i_en) {
+                step_steady(i, BoolC<true>{}, edgec, BoolC<true>{});
+                ++i;
+            } else {
+                carry = carry2;
+            }
+            drain_pending(edgec);
+        }
+        for (; i < r1; ++i) step_plain(i);
+    };
+    if (edge_strip) march(BoolC<true>{}); else march(BoolC<false>{});
     // after the loop part_cur has the parity of r1.  Left over: rows r1-3 (tiles visible), r1-2 (tiles written in the last step),
     // r1-1 (group G(r1-1) in obP, not yet convolved)
     if (r1 - 3 >= r0) reduce_store(r1 - 3, part + (part_cur ^ PART_BUF));
