@@ -272,6 +272,12 @@ int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tai
  * then b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn as fp32); strips of vsr_sr_query(VSR_Q_UTD_S2_STRIP_WIDTH) = 30 LR columns. */
 int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                       vsr_stream_t stream);
+/* The same x2 stage on v_mfma_f32_32x32x16_f16 with one wave per SIMD (k_utd_s2w, csrc/sr_utd_s2w.hip: 38 matrix instructions per step
+ * instead of 76 in each of two waves that share a SIMD's issue port; the default build).  Arguments as vsr_sr_utd_s2_f16; blob packed by
+ * sr.py:pack_utd_s2_blob(layout=4) -- same regions and size, fragments in the 32 x 32 operand layout.  Same values up to the fp32
+ * summation order of the K dimension (not bit-identical). */
+int vsr_sr_utd_s2w_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                       vsr_stream_t stream);
 
 /* The tail for the scale-2 extension in one launch (csrc/sr_tail_s2.hip): `out` DeconvBlock (k6 s2 p2 + PReLU) -> conv_out 3x3
  * (32 -> 3, bias) -> raw planes [N,3,2h,2w] fp32 (decimate != 0: the pixels (2i, 2j) only -> [N,3,h,w]); the x2 map stays in

@@ -150,11 +150,14 @@ def _stage_reference_x2(m, j, a_nchw):
 
 @pytest.mark.parametrize("shape", [(2, 5, 7), (1, 9, 40), (3, 20, 70), (1, 2, 2), (1, 33, 31), (8, 12, 30), (1, 1, 61), (2, 47, 3)])
 @pytest.mark.parametrize("chain", [0, 3])
-def test_fused_x2_stage(shape, chain):
+@pytest.mark.parametrize("build", [2, 1])
+def test_fused_x2_stage(shape, chain, build):
+    """build 2: k_utd_s2w (v_mfma_f32_32x32x16_f16, one wave per SIMD, software-pipelined; the default); 1: k_utd_s2."""
     from video_super_resolution_amd import _lib as L
     from video_super_resolution_amd.sr import _UnfusedStage
     m, _ = sr_module(2)
     m.precision = "fp16"
+    m.utd_s2_build = build
     N, h, w = shape
     P = m._packed()
     st = P["stage"][chain]
@@ -175,8 +178,8 @@ def test_fused_x2_stage(shape, chain):
     lib = L.load()
     for rps in (1, 3, 16):
         out = torch.empty_like(got)
-        L.check(lib.vsr_sr_utd_s2_f16(L.dptr(a, torch.float16), L.dptr(st.blob, torch.uint8), L.dptr(out, torch.float16), N, h, w, rps, 1,
-                                      L.stream()))
+        fn = lib.vsr_sr_utd_s2w_f16 if st.wide else lib.vsr_sr_utd_s2_f16
+        L.check(fn(L.dptr(a, torch.float16), L.dptr(st.blob, torch.uint8), L.dptr(out, torch.float16), N, h, w, rps, 1, L.stream()))
         assert torch.equal(out, got), rps
 
 
@@ -227,6 +230,7 @@ def test_fused_x2_stage_flat_variant_bit_identical(shape):
     from video_super_resolution_amd import _lib as L
     m, _ = sr_module(2)
     m.precision = "fp16"
+    m.utd_s2_build = 1   # (k_utd_s2: the variants are its builds)
     N, h, w = shape
     st = m._packed()["stage"][0]
     a = torch.from_numpy((np.random.RandomState(h * 7 + w).randn(N, h, w, 32) * 20).astype(np.float16)).cuda()

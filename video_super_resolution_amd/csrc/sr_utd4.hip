@@ -98,6 +98,10 @@ __device__ __forceinline__ Ob shift1(const Ob& v) {
 }
 
 #define VSR_FENCE() __builtin_amdgcn_sched_barrier(0)
+// byte offset of (pixel p, 16-byte piece) inside an LR row slot for THIS kernel's operand reads -- 32 consecutive pixels, one piece per half
+// wave: the piece XOR pixel bits 2-3.  (lr_off's XOR of bits 1-2 serves 16-pixel x 4-piece reads; on this pattern it gives two-way bank
+// conflicts, 8 cycles per ds_read_b128 instead of 4: tools/lds_bank_sim.py.)
+__device__ __forceinline__ int lr_off32(int p, int chunk) { return p * 64 + ((chunk ^ ((p >> 2) & 3)) << 4); }
 
 template <bool ALLMAX, int POST>
 __global__ void __launch_bounds__(256)
@@ -196,7 +200,7 @@ k_utd4(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
 #pragma unroll
     for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) lr_b[dx][kb] = lr_off(j32 + 1 - dx, 2 * kb + kh);
+        for (int kb = 0; kb < 2; ++kb) lr_b[dx][kb] = lr_off32(j32 + 1 - dx, 2 * kb + kh);
     // reduce role (as k_utd3): output pixel tid >> 3 (32 of them), channels 4 (tid & 7) .. + 3
     const int rj = tid >> 3, rc4 = tid & 7;
     const f4 bdn = *reinterpret_cast<const f4*>(fpar + 64 + 4 * rc4);
@@ -207,7 +211,7 @@ k_utd4(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, 
     const bool lr_loader = tid < LR_COLS * 4;
     const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 1 + lr_px;
     const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
-    const int lr_st = lr_loader ? lr_off(lr_px, lr_ch) : LR_BYTES + 16 * (tid - LR_COLS * 4);
+    const int lr_st = lr_loader ? lr_off32(lr_px, lr_ch) : LR_BYTES + 16 * (tid - LR_COLS * 4);
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)n_planes * h * w * NF * 2), 0x00020000);
     auto fetch_lr = [&](int r) __attribute__((always_inline)) -> u4w {
         unsigned a = (unsigned)(((((size_t)n * h + r) * w + lr_col) * NF + lr_ch * 8) * 2);

@@ -196,7 +196,7 @@ class SRProjectionModule(nn.Module):
             def stage(j):
                 args = (b.upBlocks[j + 1], P["dt_w"][j + 1], _NF * (j + 2), P["dt_b"][j + 1], P["dt_a"][j + 1], b.downBlocks[j + 2])
                 if self.upscale_factor == 2 and self.fused_s2:
-                    return _FusedStageS2(*args, slopes_le_one=P["slopes_le_one"], rows_fn=self._rows_per_segment)
+                    return _FusedStageS2(*args, slopes_le_one=P["slopes_le_one"], rows_fn=self._rows_per_segment, wide=self.utd_s2_build == 2)
                 return _UnfusedStage(*args, self.upscale_factor)
             P["stage"] = {j: stage(j) for j in range(0, G - 2, 3)}
             P["out_deconv"] = _PhaseDeconv(self.out[0].weight, self.out[0].bias, P["out_a"], self.upscale_factor)
@@ -640,6 +640,7 @@ class SRProjectionModule(nn.Module):
     fused_s2 = True    # scale 2: the stage on k_utd_s2 (csrc/sr_utd_s2.hip); False: the unfused launches (cross-check).
                        # (read when the weights are packed: change it before the first forward or bump a parameter)
 
+    utd_s2_build = int(os.environ.get("VSR_UTD_S2_BUILD", "1"))   # x2 stage: 1 = k_utd_s2 (default), 2 = k_utd_s2w (32x32x16 MFMA, one wave per SIMD: measured 5 % slower, LAB_NOTES R5.8)
     fuse_uptran = os.environ.get("VSR_UTD_POST", "1") != "0"   # the uptran 1x1 between the two stages of a step inside the first stage's launch
                                                                 # (vsr_sr_utd_post_f16; False: its own chain launch -- the cross-check, bit-identical)
 
@@ -987,7 +988,7 @@ class _PhaseDeconv:
         return out
 
 
-def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a) -> torch.Tensor:
+def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a, layout: int = 1) -> torch.Tensor:
     """Weights of one fused x2 stage in the per-wave MFMA fragment order of csrc/sr_utd_s2.hip.  Wave (r, c) = (HR row parity,
     HR column parity): deconv tap (dy, dx) is kernel element (r + 2 dy, c + 2 dx) of the ConvTranspose2d weight
     [32(in),32(out),6,6]; conv slot (k, s) is kernel element (r + 2 k, c + 2 s) of the Conv2d weight [32(out),32(in),6,6]."""
@@ -1014,6 +1015,18 @@ def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn
     MT2 = torch.arange(2, device=dev).view(2, 1, 1)
     co2, ci2 = torch.broadcast_tensors(16 * MT2 + col_l.view(1, 64, 1), tr_col0 + perm[g].view(1, 64, 8))
     dt_frag = tr_w.detach().float()[co2, ci2].to(torch.float16).contiguous()
+    if layout == 4:
+        # k_utd_s2w (csrc/sr_utd_s2w.hip, v_mfma_f32_32x32x16_f16): [wave][.][.][K block 2][lane 64][8]; A[co = lane % 32][k = (kh = lane / 32, e)]:
+        # deconv in natural channel order (ci = 16 kb + 8 kh + e), conv / 1x1 in the 32 x 32 accumulator's (16 kb + 8 (e / 4) + 4 kh + e % 4)
+        KB = MT   # (same axis)
+        kh_, e_ = LN >> 5, J
+        ci, co_, ky_, kx_ = torch.broadcast_tensors(16 * KB + 8 * kh_ + e_, LN & 31, ky, kx)
+        up_frag = up_w.detach().float()[ci, co_, ky_, kx_].to(torch.float16).contiguous()
+        ci, co_, ky_, kx_ = torch.broadcast_tensors(16 * KB + 8 * (e_ >> 2) + 4 * kh_ + (e_ & 3), LN & 31, ky, kx)
+        dn_frag = dn_w.detach().float()[co_, ci, ky_, kx_].to(torch.float16).contiguous()
+        KB3, LN3, E3 = torch.arange(2, device=dev).view(2, 1, 1), lane.view(1, 64, 1), j8.view(1, 1, 8)
+        co2, ci2 = torch.broadcast_tensors(LN3 & 31, tr_col0 + 16 * KB3 + 8 * (E3 >> 2) + 4 * (LN3 >> 5) + (E3 & 3))
+        dt_frag = tr_w.detach().float()[co2, ci2].to(torch.float16).contiguous()
     blob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     o_dn, o_dt = 4 * 18 * 1024, 8 * 18 * 1024
     o_f = o_dt + 2 * 1024
@@ -1066,9 +1079,11 @@ def pack_tail_s2_blob(out_w, out_b, out_a, cv_w, cv_b) -> torch.Tensor:
 class _FusedStageS2:
     """up_i -> downtran slice -> down_j for upscale factor 2 in ONE launch (csrc/sr_utd_s2.hip: the x2 map stays in registers)."""
 
-    def __init__(self, up, dt_w, dt_col, dt_b, dt_a, dn, slopes_le_one, rows_fn):
+    def __init__(self, up, dt_w, dt_col, dt_b, dt_a, dn, slopes_le_one, rows_fn, wide=True):
+        # wide: k_utd_s2w (v_mfma_f32_32x32x16_f16, one wave per SIMD; the default) instead of k_utd_s2 (16x16x32, two workgroups per CU)
+        self.wide = bool(wide)
         self.blob = pack_utd_s2_blob(up[0].weight, up[0].bias, float(up[1].weight.detach()), dt_w, dt_col, dt_b, dt_a,
-                                     dn[0].weight, dn[0].bias, float(dn[1].weight.detach()))
+                                     dn[0].weight, dn[0].bias, float(dn[1].weight.detach()), layout=4 if self.wide else 1)
         self.slopes_le_one = bool(slopes_le_one)
         self.rows_fn = rows_fn
 
@@ -1080,9 +1095,10 @@ class _FusedStageS2:
         for n0 in range(0, N, nb):
             n = min(nb, N - n0)
             tok = L.TIMER.start(("sr_utd_s2_f16" if n == 8 else f"sr_utd_s2_f16_p{n}") + ("_side" if side else ""))
-            # two workgroups share a CU (256 registers per wave): twice the slots of the x4 kernel per round
-            rows = self.rows_fn(n, h, w, cus=512, strip=int(L.load().vsr_sr_query(L.Q_UTD_S2_STRIP_WIDTH)))
-            L.check(L.load().vsr_sr_utd_s2_f16(L.dptr(a[n0:n0 + n], torch.float16), L.dptr(self.blob, torch.uint8),
+            # k_utd_s2: two workgroups share a CU (256 registers per wave): twice the slots of the x4 kernel per round; k_utd_s2w: one
+            rows = self.rows_fn(n, h, w, cus=256 if self.wide else 512, strip=int(L.load().vsr_sr_query(L.Q_UTD_S2_STRIP_WIDTH)))
+            fn = L.load().vsr_sr_utd_s2w_f16 if self.wide else L.load().vsr_sr_utd_s2_f16
+            L.check(fn(L.dptr(a[n0:n0 + n], torch.float16), L.dptr(self.blob, torch.uint8),
                                                L.dptr(out[n0:n0 + n], torch.float16), n, h, w, rows, int(self.slopes_le_one), L.stream()),
                     "sr_utd_s2_f16")
             L.TIMER.stop(tok)
