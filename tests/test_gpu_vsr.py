@@ -274,6 +274,39 @@ def test_streaming_mode_is_bit_identical_to_per_window_evaluation(gpu_vsr_f16, h
         assert torch.equal(a, b), (t, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("hw", [(66, 70), (540, 960)])
+def test_graph_replay_is_bit_identical_to_eager(gpu_vsr_f16, hw):
+    """GraphedVSR (opt-in): the ~900 launches of an inference call on its four streams captured once and replayed as one HIP graph --
+    a recurrent clip (first call without, later calls with the previous output: two graphs), `high_frames[1]` written as
+    video_super_resolution.py:66 does; every frame equal to the eager call's bit for bit.  Training calls are refused."""
+    import copy
+    from video_super_resolution_amd import GraphedVSR
+    m = copy.deepcopy(gpu_vsr_f16)
+    h, w = hw
+    clip = torch.from_numpy(np.random.RandomState(8).randint(0, 256, (6, h, w, 3)).astype(np.float32)).cuda()
+    S = m.upscale_factor
+
+    def run(call):
+        est, outs = None, []
+        hf = torch.zeros((3, S * h, S * w, 3), dtype=torch.float32, device="cuda")
+        for t in range(4):
+            est, loss = call(clip[t:t + 3], None, hf, est, train=False)
+            assert loss is None and torch.equal(hf[1], est[0])
+            outs.append(est.clone())
+        torch.cuda.synchronize()
+        return outs
+    ref = run(m)
+    g = GraphedVSR(m)
+    got = run(g)
+    assert len(g._graphs) == 2
+    for t, (a, b) in enumerate(zip(got, ref)):
+        assert torch.equal(a, b), (t, float((a - b).abs().max()))
+    got2 = run(g)   # replays only
+    assert len(g._graphs) == 2 and all(torch.equal(a, b) for a, b in zip(got2, ref))
+    with pytest.raises(ValueError):
+        g(clip[:3], torch.zeros((1, S * h, S * w, 3), device="cuda"), None, None, train=True)
+
+
 def test_streaming_mode_matches_per_window_evaluation(gpu_vsr_f16):
     """VSR.temporal_cache (opt-in): depth predictions / flow pictures of the two frames consecutive windows share are kept
     across calls (bit-identity with the per-window evaluation: the test above).  Here: cache bookkeeping -- an in-place change of a

@@ -17,11 +17,12 @@ _os.environ.setdefault("MIOPEN_DEBUG_ENABLE_AI_IMMED_MODE_FALLBACK", "0")  # pla
 _os.environ.setdefault("MIOPEN_LOG_LEVEL", "2")  # errors only: the fallback heuristic is chatty at warning level
 
 from .vsr import VSR  # noqa: F401,E402
+from .graph import GraphedVSR  # noqa: F401,E402
 from .sr import SRProjectionModule  # noqa: F401,E402
 from .flownet import FlowProjectionModule, FlowNet2  # noqa: F401,E402
 from .depth import DepthProjectionModule  # noqa: F401,E402
 from .vos import VOSProjectionModule  # noqa: F401,E402
 from .ops import Resample2d, ChannelNorm, Correlation  # noqa: F401,E402
 
-__all__ = ["VSR", "SRProjectionModule", "FlowProjectionModule", "FlowNet2", "DepthProjectionModule",
+__all__ = ["VSR", "GraphedVSR", "SRProjectionModule", "FlowProjectionModule", "FlowNet2", "DepthProjectionModule",
            "VOSProjectionModule", "Resample2d", "ChannelNorm", "Correlation"]
