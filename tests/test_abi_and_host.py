@@ -206,3 +206,26 @@ def test_float32_trunk_host_logic_on_the_cpu():
     assert fr.shape == (16, 64)
     for r, lane in ((0, 0), (5, 37), (15, 63), (9, 31)):
         assert fr[r, lane] == w[lane % 32, 32 + 8 * (r // 4) + 4 * (lane // 32) + r % 4]
+
+
+def test_executor_cache_sees_in_place_updates_and_replaced_parameters():
+    """TrunkExecCache (one look-up per trunk call, ~6 per frame): the executor is rebuilt when a parameter / buffer is updated in place
+    (version counter), when a Parameter object is replaced, and not otherwise."""
+    import torch.nn as nn
+    from video_super_resolution_amd.trunk_exec import TrunkExecCache
+    net = nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4), nn.Sequential(nn.Conv2d(4, 2, 1, bias=False)))
+    built = []
+    cache = TrunkExecCache(net, lambda m: built.append(1) or object())
+    a = cache.get()
+    assert cache.get() is a and len(built) == 1
+    with torch.no_grad():
+        net[2][0].weight.mul_(2.0)                        # optimizer-style in-place update
+    b = cache.get()
+    assert b is not a and cache.get() is b and len(built) == 2
+    net[1].running_mean.add_(1.0)                         # a buffer
+    assert cache.get() is not b and len(built) == 3
+    net[0].bias = nn.Parameter(torch.zeros(4))            # a replaced Parameter object
+    c = cache.get()
+    assert len(built) == 4 and cache.get() is c
+    net.load_state_dict(net.state_dict())                 # copies in place: every version moves
+    assert cache.get() is not c and len(built) == 5

@@ -22,7 +22,7 @@ _ws = {}
 def _splitk_ws(device) -> torch.Tensor:
     """One fp32 scratch buffer per (device, stream) for split-K partial tiles: launches on one stream are ordered, so
     the buffer is reused; trunks running concurrently on different streams must not share it."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, L.raw_stream(device.index))
     if key not in _ws:
         _ws[key] = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
     return _ws[key]
@@ -46,7 +46,7 @@ def cached_zeros(owner, tag, shape, device) -> torch.Tensor:
     padding channels stay zero without a fill launch per call (the trunks issued ~100 of those per frame).  Safe because
     every owner produces one such tensor per executor call and its consumers run before the owner's next call."""
     d = owner.__dict__.setdefault("_bufs", {})
-    k = (tag, tuple(shape), device.index, torch.cuda.current_stream(device).cuda_stream)
+    k = (tag, tuple(shape), device.index, L.raw_stream(device.index))
     t = d.pop(k, None)
     if t is None:
         # bounded: a frame alternates between at most a few shapes per owner (batch of 4 / batch of 1, pass 1 / pass 2);

@@ -144,7 +144,12 @@ class SRProjectionModule(nn.Module):
 
     # ------------------------------------------------------------------ weight packing (cached)
     def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        # read through the sub-modules' own dictionaries (the constructor fixes the module tree): `parameters()` walks it with name
+        # bookkeeping on every call, and this key is taken ~6 times per frame
+        mods = self.__dict__.get("_key_mods")
+        if mods is None:
+            mods = self.__dict__["_key_mods"] = [m for m in self.modules() if m._parameters or m._buffers]
+        return tuple((t.data_ptr(), t._version) for m in mods for d in (m._parameters, m._buffers) for t in d.values() if t is not None)
 
     @staticmethod
     def _diag(ms: MeanShift):
