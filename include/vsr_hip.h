@@ -272,8 +272,14 @@ int vsr_sr_fc_planes_skip_f32(const float* raw, const float* x, const float* tai
  * then b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn as fp32); strips of vsr_sr_query(VSR_Q_UTD_S2_STRIP_WIDTH) = 30 LR columns. */
 int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                       vsr_stream_t stream);
+/* The same launch + the NEXT group's uptran slice (1x1 + PReLU, SRProjectionModule.py:55-61 under the zero-fill semantic) applied to
+ * every finished output row: out_post [N,h,w,32] fp16 = what vsr_sr_chain1x1_f16 would make of `out` (bit-identical), without the
+ * HBM round trip (at x2 that launch costs a sixth of the stage).  The blob carries the 1x1 behind the stage's parameters
+ * (sr.py:pack_utd_s2_blob(post=...): 2 fragments in natural channel order, b_post[32], slope_post). */
+int vsr_sr_utd_s2_post_f16(const void* in, const void* blob, void* out, void* out_post, int N, int h, int w, int rows_per_seg,
+                           int slopes_le_one, vsr_stream_t stream);
 /* The same x2 stage on v_mfma_f32_32x32x16_f16 with one wave per SIMD (k_utd_s2w, csrc/sr_utd_s2w.hip: 38 matrix instructions per step
- * instead of 76 in each of two waves that share a SIMD's issue port; the default build).  Arguments as vsr_sr_utd_s2_f16; blob packed by
+ * instead of 76 in each of two waves that share a SIMD's issue port; opt-in, measured 5 % slower).  Arguments as vsr_sr_utd_s2_f16; blob packed by
  * sr.py:pack_utd_s2_blob(layout=4) -- same regions and size, fragments in the 32 x 32 operand layout.  Same values up to the fp32
  * summation order of the K dimension (not bit-identical). */
 int vsr_sr_utd_s2w_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,

@@ -245,3 +245,59 @@ def test_fused_x2_stage_flat_variant_bit_identical(shape):
     finally:
         lib.vsr_sr_utd_s2_variant(0)
     assert torch.equal(got, ref) and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("shape,rps", [((2, 5, 7), 0), ((1, 9, 40), 3), ((3, 20, 70), 0), ((1, 2, 2), 1), ((1, 33, 31), 16), ((8, 12, 30), 5),
+                                       ((1, 1, 61), 0), ((2, 47, 3), 1), ((5, 64, 90), 7)])
+@pytest.mark.parametrize("slope", [None, 1.5])
+def test_fused_x2_stage_with_fused_uptran_bit_identical(shape, rps, slope):
+    """vsr_sr_utd_s2_post_f16 (k_utd_s2<.., POST>: the next group's uptran 1x1 + PReLU applied to every finished output row inside the x2
+    stage's launch) against the two launches it replaces -- vsr_sr_utd_s2_f16, then vsr_sr_chain1x1_f16 on its output: both tensors bit for
+    bit, over whole marches and row segments (1-row segments: every row is a segment's last row, reduced after the loop)."""
+    from video_super_resolution_amd import _lib as L
+    m, _ = sr_module(2)
+    m.precision = "fp16"
+    N, h, w = shape
+    if slope is not None:   # a slope > 1 in the fused 1x1: the select build (min instead of max)
+        with torch.no_grad():
+            m.block.uptranBlocks[3][1].weight.fill_(slope)
+    P = m._packed()
+    st = P["stage"][0]
+    assert st.has_post and not P["stage"][3].has_post      # six groups: stage 0 is followed by another stage, stage 3 is not
+    assert st.post_slopes_le_one == (slope is None)
+    le1 = int(st.post_slopes_le_one)
+    a = torch.from_numpy((np.random.RandomState(h * 100 + w + N).randn(N, h, w, 32) * 20).astype(np.float16)).cuda()
+    lib = L.load()
+    ref = torch.empty((N, h, w, 32), dtype=torch.float16, device="cuda")
+    L.check(lib.vsr_sr_utd_s2_f16(L.dptr(a, torch.float16), L.dptr(st.blob, torch.uint8), L.dptr(ref, torch.float16), N, h, w, rps or h, 1, L.stream()))
+    ref_post = m._chain([dict(ins=[(ref.view(N, h * w, 32), P["ut_w"][3], 32 * 4)], prev=None, bias=P["ut_b"][3], slope=P["ut_a"][3])], N, h * w, keep=[True])[0]
+    out = torch.full((N, h, w, 32), float("nan"), dtype=torch.float16, device="cuda")
+    post = torch.full((N, h, w, 32), float("nan"), dtype=torch.float16, device="cuda")
+    L.check(lib.vsr_sr_utd_s2_post_f16(L.dptr(a, torch.float16), L.dptr(st.blob, torch.uint8), L.dptr(out, torch.float16), L.dptr(post, torch.float16),
+                                       N, h, w, rps or h, le1, L.stream()))
+    assert torch.isfinite(post.float()).all() and (post < 0).any()
+    assert torch.equal(out, ref)
+    assert torch.equal(post.view(N, h * w, 32), ref_post)
+    o2, p2 = st(a, m._chain, post=True)      # (the host wrapper: its own segmentation)
+    assert torch.equal(o2, ref) and torch.equal(p2.view(N, h * w, 32), ref_post)
+
+
+@pytest.mark.parametrize("hw", [(12, 20), (37, 45)])
+def test_x2_forward_with_fused_uptran_bit_identical(hw):
+    """The whole x2 SR forward with the uptran slice fused into the first stage of every step (default) and as its own launch; also with
+    a slope > 1 in the fused 1x1 (the select build)."""
+    m, _ = sr_module(2)
+    m.precision = "fp16"
+    h, w = hw
+    x = torch.from_numpy(np.random.RandomState(h * 7 + w).randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    assert m.fuse_uptran
+    with torch.no_grad():
+        fused = m(x).clone()
+        m.fuse_uptran = False
+        apart = m(x).clone()
+        m.block.uptranBlocks[3][1].weight.fill_(1.5)
+        apart2 = m(x).clone()
+        m.fuse_uptran = True
+        fused2 = m(x).clone()
+    assert torch.equal(fused, apart)
+    assert not m._packed()["stage"][0].post_slopes_le_one and torch.equal(fused2, apart2)

@@ -35,7 +35,10 @@ constexpr int S2_BLOB_UP = 0;                           // [wave 4][tap 9 = dy*3
 constexpr int S2_BLOB_DN = 4 * 18 * 1024;               // [wave 4][kernel-row slot 3][shift 3][mt 2][lane 64][8] fp16
 constexpr int S2_BLOB_DT = S2_BLOB_DN + 4 * 18 * 1024;  // [mt 2][lane 64][8] fp16
 constexpr int S2_BLOB_F32 = S2_BLOB_DT + 2 * 1024;      // b_up[32] b_dt[32] b_dn[32] slope_up slope_dt slope_dn
-constexpr int S2_BLOB_BYTES = S2_BLOB_F32 + 512;
+constexpr int S2_BLOB_POST = S2_BLOB_F32 + 512;         // POST: [mt 2][lane 64][8] fp16 (natural channel order), then b_post[32], slope_post (64 floats)
+constexpr int S2_BLOB_BYTES = S2_BLOB_POST + 2048 + 256;
+constexpr int S2_OROW = 2048;                           // POST: a finished output row as fp16 [32 px][64 B], 16-byte pieces swizzled (lr_off)
+constexpr int S2_LDS_POST = 2 * S2_OROW + 2048 + 256;   // two rows + the 1x1's fragments + bias
 
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 
@@ -63,13 +66,20 @@ __device__ __forceinline__ void shift_tiles(const h8 (&T)[2], h8 (&B)[2]) {
 // FLAT: one basic block per step -- pairs outside the image are computed and zeroed (two steps per march), the partial tiles
 // are always stored and the reduce of a row that is not output stores to an out-of-range buffer offset -- so that the
 // compiler may schedule across what were branch boundaries (A/B: vsr_sr_utd_s2_variant).
-template <bool ALLMAX, bool FLAT>
+// POST: the NEXT group's uptran slice (1x1 + PReLU on this stage's output, SRProjectionModule.py:55-61 under the zero-fill semantic) applied
+// to every finished output row inside this launch and written to `out2` -- at x2 the separate 1x1 launch it replaces is HBM-bound and
+// costs a sixth of the stage (2.65 GB per 5 planes of 1080 x 1920).  The reduce leaves the row's fp16 values in LDS as well (orow);
+// two steps later each wave multiplies one 16 x 16 quadrant (out-channel tile wv / 2, pixel tile wv % 2): 1 MFMA + 6 VALU per wave and
+// step.  Same operation order as k_chain1x1_s (bias-seeded accumulator, K = 32 in one MFMA, fp16 PReLU): bit-identical.
+template <bool ALLMAX, bool FLAT, bool POST>
 __global__ void __launch_bounds__(256, 2)
 k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, _Float16* __restrict__ out, int h, int w,
-         int rows_per_seg) {
+         int rows_per_seg, _Float16* __restrict__ out2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const lrr = smem;
     unsigned char* const part = smem + S2_LR_BYTES;
+    unsigned char* const orow = smem + S2_LDS;          // (POST only: the launch allocates S2_LDS + S2_LDS_POST)
+    unsigned char* const postw = orow + 2 * S2_OROW;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,6 +116,15 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
     auto bup = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f4*>(bias_s + 16 * mt + 4 * g); };
     auto bdt = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f4*>(bias_s + 32 + 16 * mt + 4 * g); };
     const float a_up = fpar[96], a_dt = fpar[97], a_dn = fpar[98];
+    h2 a_post2 = {(_Float16)1.0f, (_Float16)1.0f};
+    bool post_max = true;
+    if (POST) {
+        const float* ppar = reinterpret_cast<const float*>(blob + S2_BLOB_POST + 2048);
+        if (tid < 128) *reinterpret_cast<u4v*>(postw + tid * 16) = *reinterpret_cast<const u4v*>(blob + S2_BLOB_POST + tid * 16);
+        else if (tid < 160) *reinterpret_cast<float*>(postw + 2048 + (tid - 128) * 4) = ppar[tid - 128];
+        a_post2 = h2{(_Float16)ppar[32], (_Float16)ppar[32]};
+        post_max = ALLMAX || ppar[32] <= 1.0f;
+    }
     const h2 a_up2 = {(_Float16)a_up, (_Float16)a_up}, a_dt2 = {(_Float16)a_dt, (_Float16)a_dt};
     const bool up_max = ALLMAX || a_up <= 1.0f, dt_max = ALLMAX || a_dt <= 1.0f;
 
@@ -144,6 +163,21 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
         const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{v[2], v[3]}, h2));
         const unsigned off = (red_ok && ok) ? (unsigned)(((((size_t)n * h + i) * w + x0 + rj) * NF + 4 * rc4) * 2) : 0xFFFFFFFFu;
         __builtin_amdgcn_raw_buffer_store_b64(u2v{lo, hi}, out_rsrc, off, 0, 0);
+        if (POST) *reinterpret_cast<u2v*>(orow + (i & 1) * S2_OROW + lr_off(rj, rc4 >> 1) + (rc4 & 1) * 8) = u2v{lo, hi};
+    };
+    // POST: the 1x1 on finished row i (its fp16 values lie in orow[i & 1] since the barrier that followed its reduce): this wave's quadrant
+    const __amdgpu_buffer_rsrc_t out2_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(POST ? out2 : out, 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    const int pmt = wv >> 1, ppx = 16 * (wv & 1) + l15;
+    const bool post_px_ok = ppx < S2_TX && x0 + ppx < w;
+    auto post_row = [&](int i) __attribute__((always_inline)) {
+        const h8 b = *reinterpret_cast<const h8*>(orow + (i & 1) * S2_OROW + lr_off(ppx, g));
+        const h8 a = *reinterpret_cast<const h8*>(postw + (pmt * 64 + lane) * 16);
+        const f4 e = mfma16(a, b, *reinterpret_cast<const f4*>(postw + 2048 + (16 * pmt + 4 * g) * 4));
+        const h2 p0 = prelu_h2(__builtin_convertvector(f2v{e[0], e[1]}, h2), a_post2, post_max);
+        const h2 p1 = prelu_h2(__builtin_convertvector(f2v{e[2], e[3]}, h2), a_post2, post_max);
+        const unsigned off = (post_px_ok && i >= r0 && i < r1) ? (unsigned)(((((size_t)n * h + i) * w + x0 + ppx) * NF + 16 * pmt + 4 * g) * 2) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b64(u2v{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)}, out2_rsrc, off, 0, 0);
     };
 
     // ---- prologue: LR rows r0-2, r0-1, r0 (the first pair, m = r0-1, reads them)
@@ -174,6 +208,8 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
     for (int m = r0 - 1; m <= r1; ++m) {
         const u4v nxt = fetch_lr(m + 2);
         const bool pair_ok = m >= 0 && m < h;   // (uniform) pairs outside the image are the conv's zero padding
+        // POST: the 1x1 of row m-3 (reduced at the end of step m-2: in orow since the barrier of step m-1) at the HEAD of the step, where its
+        // LDS round trip and the MFMA's latency lie under the deconvolution's; at the end of the step it was a serial tail (+ 12 %)
         if (FLAT || pair_ok) {
             // ---- deconv of HR row 2m+r, columns 2q+c: 9 taps
             f4 d[2][2];
@@ -255,6 +291,11 @@ k_utd_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob
         __syncthreads();
         if (FLAT) reduce_store(m - 1, pbase, row_out);
         else if (row_out) reduce_store(m - 1, pbase, true);
+        if (POST) post_row(m - 2);   // (reduced at the end of the previous step; rows outside [r0, r1): dropped)
+    }
+    if (POST) {
+        __syncthreads();
+        post_row(r1 - 1);
     }
 }
 
@@ -273,26 +314,40 @@ int vsr_sr_utd_s2_variant(int v) {
 #endif
 
 
-int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
-                      vsr_stream_t stream) {
+static int launch_utd_s2(const void* in, const void* blob, void* out, void* out2, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                         vsr_stream_t stream, const char* what) {
     VSR_REQUIRE(in && blob && out, "sr_utd_s2: null pointer");
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_utd_s2: bad shape");
     VSR_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(out) & 15) == 0, "sr_utd_s2: pointers must be 16-byte aligned");
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(out2) & 15) == 0, "sr_utd_s2: pointers must be 16-byte aligned");
     if ((size_t)N * h * w * NF * 2 >= (1ull << 32) - 16) return vsr::fail(VSR_E_UNSUPPORTED, "sr_utd_s2: tensors beyond 4 GiB");
     const unsigned strips = vsr::cdiv(w, S2_TX), segs = vsr::cdiv(h, rows_per_seg);
     VSR_REQUIRE(segs <= 65535, "sr_utd_s2: too many row segments");
-    typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int);
+    typedef void (*kern_t)(const _Float16*, const unsigned char*, _Float16*, int, int, int, _Float16*);
+    kern_t k;
+    if (out2) k = slopes_le_one ? k_utd_s2<true, false, true> : k_utd_s2<false, false, true>;
+    else {
 #if VSR_X   // (+ the branch-free "flat" build: bit-identical, measured level; cross-check library only)
-    static const kern_t kerns[4] = {k_utd_s2<false, false>, k_utd_s2<true, false>, k_utd_s2<false, true>, k_utd_s2<true, true>};
-    const int kidx = 2 * g_utd_s2_variant + (slopes_le_one ? 1 : 0);
+        static const kern_t kerns[4] = {k_utd_s2<false, false, false>, k_utd_s2<true, false, false>, k_utd_s2<false, true, false>, k_utd_s2<true, true, false>};
+        k = kerns[2 * g_utd_s2_variant + (slopes_le_one ? 1 : 0)];
 #else
-    static const kern_t kerns[2] = {k_utd_s2<false, false>, k_utd_s2<true, false>};
-    const int kidx = slopes_le_one ? 1 : 0;
+        k = slopes_le_one ? k_utd_s2<true, false, false> : k_utd_s2<false, false, false>;
 #endif
-    hipLaunchKernelGGL(kerns[kidx], dim3(strips, segs, N), dim3(256), S2_LDS, vsr::S(stream),
-                       (const _Float16*)in, (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg);
-    return vsr::launched("sr_utd_s2");
+    }
+    hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(256), S2_LDS + (out2 ? S2_LDS_POST : 0), vsr::S(stream),
+                       (const _Float16*)in, (const unsigned char*)blob, (_Float16*)out, h, w, rows_per_seg, (_Float16*)out2);
+    return vsr::launched(what);
+}
+
+int vsr_sr_utd_s2_f16(const void* in, const void* blob, void* out, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                      vsr_stream_t stream) {
+    return launch_utd_s2(in, blob, out, nullptr, N, h, w, rows_per_seg, slopes_le_one, stream, "sr_utd_s2");
+}
+
+int vsr_sr_utd_s2_post_f16(const void* in, const void* blob, void* out, void* out_post, int N, int h, int w, int rows_per_seg,
+                           int slopes_le_one, vsr_stream_t stream) {
+    VSR_REQUIRE(out_post, "sr_utd_s2_post: null pointer");
+    return launch_utd_s2(in, blob, out, out_post, N, h, w, rows_per_seg, slopes_le_one, stream, "sr_utd_s2_post");
 }
 
 }  // extern "C"

@@ -201,7 +201,9 @@ class SRProjectionModule(nn.Module):
             def stage(j):
                 args = (b.upBlocks[j + 1], P["dt_w"][j + 1], _NF * (j + 2), P["dt_b"][j + 1], P["dt_a"][j + 1], b.downBlocks[j + 2])
                 if self.upscale_factor == 2 and self.fused_s2:
-                    return _FusedStageS2(*args, slopes_le_one=P["slopes_le_one"], rows_fn=self._rows_per_segment, wide=self.utd_s2_build == 2)
+                    # (with the next group's uptran slice when another stage follows: applied inside the launch, `fuse_uptran`)
+                    post = (P["ut_w"][j + 3], _NF * (j + 4), P["ut_b"][j + 3], P["ut_a"][j + 3]) if j + 6 <= G else None
+                    return _FusedStageS2(*args, slopes_le_one=P["slopes_le_one"], rows_fn=self._rows_per_segment, wide=self.utd_s2_build == 2, post=post)
                 return _UnfusedStage(*args, self.upscale_factor)
             P["stage"] = {j: stage(j) for j in range(0, G - 2, 3)}
             P["out_deconv"] = _PhaseDeconv(self.out[0].weight, self.out[0].bias, P["out_a"], self.upscale_factor)
@@ -786,6 +788,9 @@ class SRProjectionModule(nn.Module):
                 elif self.upscale_factor == 4 and self.fuse_uptran and j in P.get("utd_post", {}) and not L._use_x:
                     o, a_next = self._utd_post(a, P["utd_post"][j], N, h, w, out=dst)
                     live[j + 3], a_next = o.view(N, hp, _NF), a_next.view(N, hp, _NF)
+                elif self.upscale_factor != 4 and self.fuse_uptran and getattr(P["stage"][j], "has_post", False) and not L._use_x:
+                    o, a_next = P["stage"][j](a.view(N, h, w, _NF), self._chain, out=dst, side=getattr(self, "_utd_side", False), post=True)
+                    live[j + 3], a_next = o.view(N, hp, _NF), a_next.view(N, hp, _NF)
                 else:
                     live[j + 3] = (self._utd(a, P["utd"][j], N, h, w, out=dst) if self.upscale_factor == 4 else
                                    P["stage"][j](a.view(N, h, w, _NF), self._chain, out=dst, side=getattr(self, "_utd_side", False))).view(N, hp, _NF)
@@ -993,10 +998,12 @@ class _PhaseDeconv:
         return out
 
 
-def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a, layout: int = 1) -> torch.Tensor:
+def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn_a, layout: int = 1, post=None) -> torch.Tensor:
     """Weights of one fused x2 stage in the per-wave MFMA fragment order of csrc/sr_utd_s2.hip.  Wave (r, c) = (HR row parity,
     HR column parity): deconv tap (dy, dx) is kernel element (r + 2 dy, c + 2 dx) of the ConvTranspose2d weight
-    [32(in),32(out),6,6]; conv slot (k, s) is kernel element (r + 2 k, c + 2 s) of the Conv2d weight [32(out),32(in),6,6]."""
+    [32(in),32(out),6,6]; conv slot (k, s) is kernel element (r + 2 k, c + 2 s) of the Conv2d weight [32(out),32(in),6,6].
+    post = (w [32,ld], col0, b [32], a): the 1x1 + PReLU that vsr_sr_utd_s2_post_f16 applies to every finished output row (the next
+    group's uptran slice), behind the stage's parameters."""
     dev = up_w.device
     nbytes = int(L.load().vsr_sr_query(L.Q_UTD_S2_BLOB_BYTES))
     lane = torch.arange(64, device=dev)
@@ -1042,6 +1049,15 @@ def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn
     fpar[0:32], fpar[32:64], fpar[64:96] = up_b.detach().float(), tr_b.detach().float(), dn_b.detach().float()
     fpar[96], fpar[97], fpar[98] = float(up_a), float(tr_a), float(dn_a)
     blob[o_f:o_f + 512] = fpar.view(torch.uint8)
+    if post is not None:
+        pw, pcol, pb, pa = post
+        o_p = o_f + 512
+        co2, ci2 = torch.broadcast_tensors(16 * MT2 + col_l.view(1, 64, 1), pcol + 8 * g.view(1, 64, 1) + j8.view(1, 1, 8))   # natural channel order
+        blob[o_p:o_p + 2048] = pw.detach().float()[co2, ci2].to(torch.float16).contiguous().view(torch.uint8).reshape(-1)
+        ppar = torch.zeros(64, dtype=torch.float32, device=dev)
+        ppar[0:32] = pb.detach().float()
+        ppar[32] = float(pa)
+        blob[o_p + 2048:o_p + 2048 + 256] = ppar.view(torch.uint8)
     return blob
 
 
@@ -1084,18 +1100,36 @@ def pack_tail_s2_blob(out_w, out_b, out_a, cv_w, cv_b) -> torch.Tensor:
 class _FusedStageS2:
     """up_i -> downtran slice -> down_j for upscale factor 2 in ONE launch (csrc/sr_utd_s2.hip: the x2 map stays in registers)."""
 
-    def __init__(self, up, dt_w, dt_col, dt_b, dt_a, dn, slopes_le_one, rows_fn, wide=True):
-        # wide: k_utd_s2w (v_mfma_f32_32x32x16_f16, one wave per SIMD; the default) instead of k_utd_s2 (16x16x32, two workgroups per CU)
+    def __init__(self, up, dt_w, dt_col, dt_b, dt_a, dn, slopes_le_one, rows_fn, wide=True, post=None):
+        # wide: k_utd_s2w (v_mfma_f32_32x32x16_f16, one wave per SIMD; opt-in, 5 % slower) instead of k_utd_s2 (16x16x32, two workgroups per CU)
+        # post = (w, col0, b, a): the next group's uptran slice, applied inside the launch when the caller asks for it (k_utd_s2 only)
         self.wide = bool(wide)
+        self.has_post = post is not None and not self.wide
         self.blob = pack_utd_s2_blob(up[0].weight, up[0].bias, float(up[1].weight.detach()), dt_w, dt_col, dt_b, dt_a,
-                                     dn[0].weight, dn[0].bias, float(dn[1].weight.detach()), layout=4 if self.wide else 1)
+                                     dn[0].weight, dn[0].bias, float(dn[1].weight.detach()), layout=4 if self.wide else 1,
+                                     post=post if self.has_post else None)
         self.slopes_le_one = bool(slopes_le_one)
+        self.post_slopes_le_one = self.slopes_le_one and (post is None or float(post[3]) <= 1.0)
         self.rows_fn = rows_fn
 
-    def __call__(self, a, chain, out=None, side=False):
+    def __call__(self, a, chain, out=None, side=False, post=False):
+        """-> out [N,h,w,32] fp16; post=True (has_post): (out, the next group's uptran slice of it)."""
         N, h, w, _ = a.shape
         if out is None:
             out = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
+        if post:
+            assert self.has_post
+            out2 = torch.empty((N, h, w, _NF), dtype=torch.float16, device=a.device)
+            nb = max(1, min(N, ((1 << 32) - 32) // (h * w * _NF * 2)))
+            for n0 in range(0, N, nb):
+                n = min(nb, N - n0)
+                tok = L.TIMER.start(("sr_utd_s2_f16" if n == 8 else f"sr_utd_s2_f16_p{n}") + ("_side" if side else ""))
+                rows = self.rows_fn(n, h, w, cus=512, strip=int(L.load().vsr_sr_query(L.Q_UTD_S2_STRIP_WIDTH)))
+                L.check(L.load().vsr_sr_utd_s2_post_f16(L.dptr(a[n0:n0 + n], torch.float16), L.dptr(self.blob, torch.uint8),
+                                                        L.dptr(out[n0:n0 + n], torch.float16), L.dptr(out2[n0:n0 + n], torch.float16), n, h, w, rows,
+                                                        int(self.post_slopes_le_one), L.stream()), "sr_utd_s2_post_f16")
+                L.TIMER.stop(tok)
+            return out, out2
         nb = max(1, min(N, ((1 << 32) - 32) // (h * w * _NF * 2)))   # planes per launch: the kernel's 32-bit byte offsets
         for n0 in range(0, N, nb):
             n = min(nb, N - n0)
