@@ -291,6 +291,12 @@ int vsr_sr_utd_s2w_f16(const void* in, const void* blob, void* out, int N, int h
  * vsr_sr_fc_planes_skip_scale_f32 (skip + add_mean + fusion MLP). */
 int vsr_sr_tail_s2_f16(const void* hid_nhwc, const void* blob, float* raw, int N, int h, int w, int rows_per_seg, int slopes_le_one,
                        int decimate, vsr_stream_t stream);
+/* The same with the FeedbackBlock's last compress_out (1x1 over the two live LR maps lr_a, lr_b [N,h,w,32] fp16 + the constant map
+ * cmap_nhwc [h*w,32] fp32 + PReLU, SRProjectionModule.py:99) applied in the kernel's LR load path instead of by a vsr_sr_chain1x1_f16
+ * launch: bit-identical planes (the 1x1 in that kernel's operation order, its output in natural channel order in LDS).  The blob
+ * carries the 1x1 behind the tail's parameters (sr.py:pack_tail_s2_blob(fold_co=...)). */
+int vsr_sr_tail_s2_fold_f16(const void* lr_a, const void* lr_b, const float* cmap_nhwc, const void* blob, float* raw, int N, int h, int w,
+                            int rows_per_seg, int slopes_le_one, int decimate, vsr_stream_t stream);
 
 /* Tail of the fp16 path for upscale factors other than the reference's x4 (scale extension, see vsr_sr_deconv_f32):
  * conv_out 3x3 (32->3, :121-123,142) over the `out` DeconvBlock's HR map [N,H,W,32] fp16 -> raw planes [N,3,Ho,Wo] fp32

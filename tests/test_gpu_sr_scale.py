@@ -301,3 +301,29 @@ def test_x2_forward_with_fused_uptran_bit_identical(hw):
         fused2 = m(x).clone()
     assert torch.equal(fused, apart)
     assert not m._packed()["stage"][0].post_slopes_le_one and torch.equal(fused2, apart2)
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (9, 40), (37, 33), (2, 2), (1, 7), (40, 64)])
+@pytest.mark.parametrize("decimate", [False, True])
+def test_x2_tail_with_folded_compress_out_bit_identical(hw, decimate):
+    """The FeedbackBlock's last compress_out applied inside k_tail_s2's LR load path (k_tail_s2<.., FOLD>, vsr_sr_tail_s2_fold_f16) against
+    its own chain launch followed by k_tail_s2: the 1x1 with the same operands in the same order, its output written to the ring in natural
+    channel order -- the frames are equal bit for bit (full frames and the decimated pass-1 output; with shared planes: the VSR tests)."""
+    m, _ = sr_module(2)
+    m.precision = "fp16"
+    h, w = hw
+    x = torch.from_numpy(np.random.RandomState(h * 17 + w).randint(0, 256, (8, 3, h, w)).astype(np.float32)).cuda()
+    m.fold_tail = True
+    assert m._packed()["tail_s2_fold"]
+    with torch.no_grad():
+        got = m(x, decimate=decimate).clone()
+        m.fold_tail = False
+        ref = m(x, decimate=decimate).clone()
+        # ... and with a slope > 1 in compress_out (min instead of max)
+        m.block.compress_out[1].weight.fill_(1.25)
+        ref2 = m(x, decimate=decimate).clone()
+        m.fold_tail = True
+        got2 = m(x, decimate=decimate).clone()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref)
+    assert torch.equal(got2, ref2)

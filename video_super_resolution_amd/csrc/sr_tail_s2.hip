@@ -13,6 +13,13 @@
 //     0-2 (M is 3/16 used: 18 of the step's 54 MFMAs per wave, against 36 for the deconvolution) and whose B operand is the
 //     ring row shifted by the tap; lanes 0-15 store the three channels.
 //   * `dec`: only the pixels (2i, 2j) leave (what the nearest x1/2 resize of pass 1 reads) -> raw [N,3,h,w].
+//   * FOLD: the FeedbackBlock's last compress_out (1x1 over the two live LR maps + constant map + PReLU, SRProjectionModule.py:99)
+//     applied in the LR load path, as k_tail3<.., FOLD> does at x4: a loader lane (pixel l15 of tile wv < 3, chunk g) fetches its 16-byte
+//     pieces of both maps -- which ARE the B operands of the 1x1's MFMAs -- and the two constant-map tiles of its pixel; bias + map,
+//     then the two products (k_chain1x1's order), PReLU, and the 32 channels go to the ring in NATURAL order (two 8-byte halves per
+//     lane), so the deconvolution reads what the separate launch would have written: bit-identical, and that launch (HBM-bound, a
+//     third of this kernel's time at LR 1080 x 1920) is gone.  The fold costs 48 registers (212: two workgroups per CU instead of three); a build
+//     with the 1x1's fragments in LDS held to 168 registers spilled and was slower (1.98 vs 1.72 ms; chain + plain tail: 1.85).
 #include "sr_f16_common.h"
 
 namespace {
@@ -30,7 +37,8 @@ constexpr int T2_LDS = T2_LR_BYTES + T2_HR_BYTES + T2_BIAS_BYTES;
 constexpr int T2_BLOB_UP = 0;                             // [wave 4][tap 9][mt 2][lane 64][8] fp16 (as k_utd_s2)
 constexpr int T2_BLOB_CV = 4 * 18 * 1024;                 // [dy 3][dx 3][lane 64][8] fp16: rows 0-2 = conv_out's channels
 constexpr int T2_BLOB_F32 = T2_BLOB_CV + 9 * 1024;        // b_out[32], b_cv[3], pad, slope_out at [96]
-constexpr int T2_BLOB_BYTES = T2_BLOB_F32 + 512;
+constexpr int T2_BLOB_CO = T2_BLOB_F32 + 512;             // FOLD: [map 2][mt 2][lane 64][8] fp16 (natural channel order), then b_co[32], slope_co (64 floats)
+constexpr int T2_BLOB_BYTES = T2_BLOB_CO + 4096 + 256;
 
 typedef unsigned int u4t __attribute__((ext_vector_type(4)));
 
@@ -38,10 +46,10 @@ typedef unsigned int u4t __attribute__((ext_vector_type(4)));
 // lanes (128-byte stride), the 3x3 reads 16 consecutive columns: chunk XOR column bits 1-2 spreads both over the banks
 __device__ __forceinline__ int hr_off(int xr, int chunk) { return xr * 64 + ((chunk ^ ((xr >> 1) & 3)) << 4); }
 
-template <bool ALLMAX>
+template <bool ALLMAX, bool FOLD>
 __global__ void __launch_bounds__(256, 2)
 k_tail_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blob, float* __restrict__ raw, int h, int w,
-          int rows_per_seg, int dec) {
+          int rows_per_seg, int dec, const _Float16* __restrict__ in2, const float* __restrict__ cmap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const lrr = smem;
     unsigned char* const hrr = smem + T2_LR_BYTES;
@@ -79,22 +87,79 @@ k_tail_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blo
 
     const __amdgpu_buffer_rsrc_t in_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
-    const bool lr_loader = tid < T2_LRC * 4;
-    const int lr_px = tid >> 2, lr_ch = tid & 3, lr_col = x0 - 2 + lr_px;
+    const __amdgpu_buffer_rsrc_t in2_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(FOLD ? in2 : in), 0, (int)((size_t)gridDim.z * h * w * NF * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cm_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FOLD ? cmap : fpar), 0, FOLD ? (int)((size_t)h * w * NF * 4) : 0, 0x00020000);
+    // FOLD: loader lanes are MFMA operand lanes -- pixel 16 wv + l15 (waves 0-2: 48 >= 34 columns), channel chunk g
+    const int lr_px = FOLD ? 16 * wv + l15 : tid >> 2, lr_ch = FOLD ? g : tid & 3, lr_col = x0 - 2 + lr_px;
+    const bool lr_loader = FOLD ? (wv < 3 && lr_px < T2_LRC) : tid < T2_LRC * 4;
     const bool lr_col_ok = lr_loader && lr_col >= 0 && lr_col < w;
     const int lr_st = lr_off(lr_px, lr_ch);
-    auto fetch_lr = [&](int row) __attribute__((always_inline)) -> u4t {
-        const unsigned off = (lr_col_ok && row >= 0 && row < h) ? (unsigned)(((((size_t)n * h + row) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
-        return __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+    // FOLD: where the two halves of a lane's activated tile pair (channels 4g..4g+3 and 16+4g..16+4g+3) lie in natural order
+    const int lr_st_lo = lr_off(lr_px, g >> 1) + (g & 1) * 8, lr_st_hi = lr_off(lr_px, 2 + (g >> 1)) + (g & 1) * 8;
+    struct RawRow {
+        u4t a, b, c0, c1;
+    };
+    h8 Aco[2][2];
+    f4 bco[2];
+    float a_co = 1.0f;
+    if (FOLD) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) Aco[t][mt] = *reinterpret_cast<const h8*>(blob + T2_BLOB_CO + ((t * 2 + mt) * 64 + lane) * 16);
+        const float* cpar = reinterpret_cast<const float*>(blob + T2_BLOB_CO + 4096);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) bco[mt] = *reinterpret_cast<const f4*>(cpar + 16 * mt + 4 * g);
+        a_co = cpar[32];
+    }
+    const h2 a_co2 = {(_Float16)a_co, (_Float16)a_co};
+    const bool co_max = a_co <= 1.0f;
+    auto fetch_lr = [&](int row) __attribute__((always_inline)) -> RawRow {
+        const bool ok = lr_col_ok && row >= 0 && row < h;
+        const unsigned off = ok ? (unsigned)(((((size_t)n * h + row) * w + lr_col) * NF + lr_ch * 8) * 2) : 0xFFFFFFFFu;
+        RawRow v;
+        v.a = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+        if (FOLD) {
+            v.b = __builtin_amdgcn_raw_buffer_load_b128(in2_rsrc, off, 0, 0);
+            const unsigned coff = ok ? (unsigned)((((size_t)row * w + lr_col) * NF + 4 * g) * 4) : 0xFFFFFFFFu;
+            v.c0 = __builtin_amdgcn_raw_buffer_load_b128(cm_rsrc, coff, 0, 0);
+            v.c1 = __builtin_amdgcn_raw_buffer_load_b128(cm_rsrc, ok ? coff + 64 : 0xFFFFFFFFu, 0, 0);
+        }
+        return v;
+    };
+    // LR row -> ring: the fetched piece, or (FOLD) PReLU(W_co [a; b] + b_co + cmap) of the lane's pixel -- bias + map, then the two
+    // products: k_chain1x1's order -- and zero outside the image (the deconvolution's padding applies to the 1x1's OUTPUT).  The MFMAs
+    // run on whole waves (wave-uniform guard), the stores on the loader lanes.
+    auto store_lr = [&](const RawRow& v, int row) __attribute__((always_inline)) {
+        unsigned char* const slot = lrr + ((row + 4) & 3) * T2_LR_SLOT;
+        if (!FOLD) {
+            if (lr_loader) *reinterpret_cast<u4t*>(slot + lr_st) = v.a;
+            return;
+        }
+        if (wv < 3) {
+            f4 acc[2] = {bco[0] + __builtin_bit_cast(f4, v.c0), bco[1] + __builtin_bit_cast(f4, v.c1)};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt] = mfma16(Aco[0][mt], __builtin_bit_cast(h8, v.a), acc[mt]);
+                acc[mt] = mfma16(Aco[1][mt], __builtin_bit_cast(h8, v.b), acc[mt]);
+            }
+            const u4t o = __builtin_bit_cast(u4t, act_pack(acc[0], acc[1], a_co2, co_max));
+            const bool ok = lr_col_ok && row >= 0 && row < h;
+            typedef unsigned int u2t __attribute__((ext_vector_type(2)));
+            if (lr_loader) {
+                *reinterpret_cast<u2t*>(slot + lr_st_lo) = u2t{ok ? o[0] : 0u, ok ? o[1] : 0u};
+                *reinterpret_cast<u2t*>(slot + lr_st_hi) = u2t{ok ? o[2] : 0u, ok ? o[3] : 0u};
+            }
+        }
     };
     auto lr_slot = [&](int row) __attribute__((always_inline)) { return ((row + 4) & 3) * T2_LR_SLOT; };
     auto hr_slot = [&](int Y) __attribute__((always_inline)) { return ((Y + 12) % T2_HR_ROWS) * T2_HR_ROW; };   // (Y >= -12)
 
-    if (lr_loader) {
-        *reinterpret_cast<u4t*>(lrr + lr_slot(r0 - 2) + lr_st) = fetch_lr(r0 - 2);
-        *reinterpret_cast<u4t*>(lrr + lr_slot(r0 - 1) + lr_st) = fetch_lr(r0 - 1);
-        *reinterpret_cast<u4t*>(lrr + lr_slot(r0) + lr_st) = fetch_lr(r0);
-    }
+    store_lr(fetch_lr(r0 - 2), r0 - 2);
+    store_lr(fetch_lr(r0 - 1), r0 - 1);
+    store_lr(fetch_lr(r0), r0);
     __syncthreads();
 
     bool col_ok[2];
@@ -113,7 +178,7 @@ k_tail_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blo
     float* const raw_n = raw + (size_t)n * 3 * plane;
 
     for (int m = r0 - 1; m <= r1; ++m) {
-        const u4t nxt = fetch_lr(m + 2);
+        const RawRow nxt = fetch_lr(m + 2);
         // ---- deconv of HR row 2m+r, columns 2q+c (zero rows outside the image: the 3x3's padding)
         h8 T[2];
         if (m >= 0 && m < h) {
@@ -157,7 +222,7 @@ k_tail_s2(const _Float16* __restrict__ in, const unsigned char* __restrict__ blo
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<h8*>(rowp + hr_off(2 * (16 * nt + l15) + c, g)) = T[nt];
         }
-        if (lr_loader) *reinterpret_cast<u4t*>(lrr + lr_slot(m + 2) + lr_st) = nxt;
+        store_lr(nxt, m + 2);
         __syncthreads();
         // ---- conv_out for the output rows 2m-1 and 2m (HR rows 2m-2 .. 2m+1 are in the ring)
 #pragma unroll
@@ -197,22 +262,32 @@ extern "C" {
 
 
 
-int vsr_sr_tail_s2_f16(const void* hid_nhwc, const void* blob, float* raw, int N, int h, int w, int rows_per_seg, int slopes_le_one,
-                       int decimate, vsr_stream_t stream) {
-    VSR_REQUIRE(hid_nhwc && blob && raw, "sr_tail_s2: null pointer");
+static int launch_tail_s2(const void* in, const void* in2, const float* cmap, const void* blob, float* raw, int N, int h, int w, int rows_per_seg,
+                          int slopes_le_one, int decimate, vsr_stream_t stream, const char* what) {
+    VSR_REQUIRE(in && blob && raw, "sr_tail_s2: null pointer");
     VSR_REQUIRE(N > 0 && h > 0 && w > 0 && rows_per_seg > 0 && N <= 65535, "sr_tail_s2: bad shape");
-    VSR_REQUIRE((reinterpret_cast<uintptr_t>(hid_nhwc) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob) & 15) == 0,
-                "sr_tail_s2: pointers must be 16-byte aligned");
+    VSR_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(in2) & 15) == 0 && (reinterpret_cast<uintptr_t>(blob) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(cmap) & 15) == 0, "sr_tail_s2: pointers must be 16-byte aligned");
     if ((size_t)N * h * w * NF * 2 >= (1ull << 32) - 16) return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail_s2: input beyond 4 GiB");
+    if (in2 && (size_t)h * w * NF * 4 >= (1ull << 32) - 16) return vsr::fail(VSR_E_UNSUPPORTED, "sr_tail_s2: constant map beyond 4 GiB");
     const unsigned strips = vsr::cdiv(w, T2_TX), segs = vsr::cdiv(h, rows_per_seg);
     VSR_REQUIRE(segs <= 65535, "sr_tail_s2: too many row segments");
-    if (slopes_le_one)
-        hipLaunchKernelGGL(k_tail_s2<true>, dim3(strips, segs, N), dim3(256), T2_LDS, vsr::S(stream), (const _Float16*)hid_nhwc,
-                           (const unsigned char*)blob, raw, h, w, rows_per_seg, decimate);
-    else
-        hipLaunchKernelGGL(k_tail_s2<false>, dim3(strips, segs, N), dim3(256), T2_LDS, vsr::S(stream), (const _Float16*)hid_nhwc,
-                           (const unsigned char*)blob, raw, h, w, rows_per_seg, decimate);
-    return vsr::launched("sr_tail_s2");
+    typedef void (*kern_t)(const _Float16*, const unsigned char*, float*, int, int, int, int, const _Float16*, const float*);
+    const kern_t k = in2 ? (slopes_le_one ? k_tail_s2<true, true> : k_tail_s2<false, true>) : (slopes_le_one ? k_tail_s2<true, false> : k_tail_s2<false, false>);
+    hipLaunchKernelGGL(k, dim3(strips, segs, N), dim3(256), T2_LDS, vsr::S(stream), (const _Float16*)in, (const unsigned char*)blob, raw, h, w,
+                       rows_per_seg, decimate, (const _Float16*)in2, cmap);
+    return vsr::launched(what);
+}
+
+int vsr_sr_tail_s2_f16(const void* hid_nhwc, const void* blob, float* raw, int N, int h, int w, int rows_per_seg, int slopes_le_one,
+                       int decimate, vsr_stream_t stream) {
+    return launch_tail_s2(hid_nhwc, nullptr, nullptr, blob, raw, N, h, w, rows_per_seg, slopes_le_one, decimate, stream, "sr_tail_s2");
+}
+
+int vsr_sr_tail_s2_fold_f16(const void* lr_a, const void* lr_b, const float* cmap_nhwc, const void* blob, float* raw, int N, int h, int w,
+                            int rows_per_seg, int slopes_le_one, int decimate, vsr_stream_t stream) {
+    VSR_REQUIRE(lr_b && cmap_nhwc, "sr_tail_s2_fold: null pointer");
+    return launch_tail_s2(lr_a, lr_b, cmap_nhwc, blob, raw, N, h, w, rows_per_seg, slopes_le_one, decimate, stream, "sr_tail_s2_fold");
 }
 
 }  // extern "C"

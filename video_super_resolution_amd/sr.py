@@ -209,7 +209,9 @@ class SRProjectionModule(nn.Module):
             P["out_deconv"] = _PhaseDeconv(self.out[0].weight, self.out[0].bias, P["out_a"], self.upscale_factor)
             if self.upscale_factor == 2 and self.fused_s2:
                 P["tail_s2"] = pack_tail_s2_blob(self.out[0].weight, self.out[0].bias, P["out_a"], self.conv_out[0].weight,
-                                                 self.conv_out[0].bias)
+                                                 self.conv_out[0].bias,
+                                                 fold_co=(P["co_w"], (_NF * 2, _NF * 5), P["co_b"], P["co_a"]) if G == 6 else None)
+                P["tail_s2_fold"] = G == 6   # compress_out reads exactly two live maps (lr3, lr6): folded into the tail's LR load path
             self._pack, self._pack_key = P, key
             self._const.clear()
             self._const_nhwc.clear()
@@ -643,7 +645,7 @@ class SRProjectionModule(nn.Module):
         L.TIMER.stop(tok)
         return out
 
-    fold_tail = True   # the last compress_out inside k_tail3's LR path (False: its own chain launch; cross-check)
+    fold_tail = os.environ.get("VSR_FOLD_TAIL", "1") != "0"   # the last compress_out inside the tail kernel's LR path (k_tail3 / k_tail_s2; False: its own chain launch, the cross-check)
     fused_s2 = True    # scale 2: the stage on k_utd_s2 (csrc/sr_utd_s2.hip); False: the unfused launches (cross-check).
                        # (read when the weights are packed: change it before the first forward or bump a parameter)
 
@@ -816,9 +818,11 @@ class SRProjectionModule(nn.Module):
                 shared["prefc_all"] = pre
             elif (pre is not None and self.upscale_factor != 4 and "tail_s2" in P and tuple(pre.shape) == (N_tot, 3, self.upscale_factor * h, self.upscale_factor * w) and
                   len(co(live)["ins"]) <= 2):
-                # scale 2: the same for the one-launch tail of csrc/sr_tail_s2.hip (compress_out of the kept maps first)
-                hid = self._chain([co(live)], N, hp, keep=[True])[0]
-                self._tail_raw(hid.view(N, h, w, _NF), P, False, pre[:N], cus=2 * getattr(self, "_utd_cus", 256))
+                # scale 2: the same for the one-launch tail of csrc/sr_tail_s2.hip (compress_out of the kept maps inside its LR load path,
+                # or -- cross-check -- as its own launch first)
+                fold = self._fold_s2(P, live, N, h, w, cmap_nhwc)
+                hid = fold[0] if fold else self._chain([co(live)], N, hp, keep=[True])[0].view(N, h, w, _NF)
+                self._tail_raw(hid, P, False, pre[:N], cus=2 * getattr(self, "_utd_cus", 256), fold=fold)
                 shared["prefc_all"] = pre
             return None
         if n_sh:
@@ -835,8 +839,12 @@ class SRProjectionModule(nn.Module):
             nt = n0 if (pre is not None and tuple(pre.shape) == (N, 3, S * h, S * w) and pre.device == dev and len(co(live)["ins"]) <= 2) else 0
             if nt:
                 live_t = {k: v[nt:] for k, v in live.items()}
-                hid = self._chain([co(live_t)], N - nt, hp, keep=[True])[0]
-                return self._tail_unfused(x, hid.view(N - nt, h, w, _NF), P, decimate, taps, pre=pre)
+                fold = self._fold_s2(P, live_t, N - nt, h, w, cmap_nhwc)
+                hid = fold[0] if fold else self._chain([co(live_t)], N - nt, hp, keep=[True])[0].view(N - nt, h, w, _NF)
+                return self._tail_unfused(x, hid, P, decimate, taps, pre=pre, fold=fold)
+            fold = self._fold_s2(P, live, N, h, w, cmap_nhwc) if taps is None else None
+            if fold:
+                return self._tail_unfused(x, fold[0], P, decimate, taps, fold=fold)
             hid = self._chain([co(live)], N, hp, keep=[True])[0] if len(co(live)["ins"]) <= 2 else \
                 self._c1h(co(live)["ins"], P["co_b"], P["co_a"], N, hp, cmap=cmap_nhwc)
             if taps is not None:
@@ -899,8 +907,15 @@ class SRProjectionModule(nn.Module):
             taps[f"prefc{self.num_steps - 1}"] = prefc
         return out
 
-    def _tail_raw(self, hid, P, decimate, raw, cus=512):
-        """`out` DeconvBlock -> conv_out 3x3 of the planes of `hid` [n,h,w,32] into `raw` [n,3,.,.] (rows of the caller's tensor)."""
+    def _fold_s2(self, P, live, N, h, w, cmap_nhwc):
+        """(lr3, lr6 as [N,h,w,32] views, constant map) when the x2 tail applies compress_out itself (vsr_sr_tail_s2_fold_f16), else None."""
+        if not (self.fold_tail and P.get("tail_s2_fold") and "tail_s2" in P and sorted(k for k in live if k > 0) == [3, 6]) or L._use_x:
+            return None
+        return live[3].view(N, h, w, _NF), live[6].view(N, h, w, _NF), cmap_nhwc
+
+    def _tail_raw(self, hid, P, decimate, raw, cus=512, fold=None):
+        """`out` DeconvBlock -> conv_out 3x3 of the planes of `hid` [n,h,w,32] into `raw` [n,3,.,.] (rows of the caller's tensor).
+        fold (scale 2, `_fold_s2`): `hid` is not materialised -- the kernel forms it from the two live maps."""
         lib = L.load()
         N, h, w, _ = hid.shape
         S = self.upscale_factor
@@ -911,8 +926,13 @@ class SRProjectionModule(nn.Module):
                 n = min(nbt, N - n0)
                 tok = L.TIMER.start("sr_tail_s2_dec_f16" if decimate else "sr_tail_s2_f16") if L.TIMER.enabled else None
                 rows = self._rows_per_segment(n, h, w, cus=cus, strip=30)
-                L.check(lib.vsr_sr_tail_s2_f16(L.dptr(hid[n0:n0 + n], torch.float16), L.dptr(P["tail_s2"], torch.uint8), L.dptr(raw[n0:n0 + n]),
-                                               n, h, w, rows, int(P["slopes_le_one"]), int(decimate), L.stream()), "sr_tail_s2_f16")
+                if fold:
+                    L.check(lib.vsr_sr_tail_s2_fold_f16(L.dptr(fold[0][n0:n0 + n], torch.float16), L.dptr(fold[1][n0:n0 + n], torch.float16), L.dptr(fold[2]),
+                                                        L.dptr(P["tail_s2"], torch.uint8), L.dptr(raw[n0:n0 + n]), n, h, w, rows,
+                                                        int(P["slopes_le_one"]), int(decimate), L.stream()), "sr_tail_s2_fold_f16")
+                else:
+                    L.check(lib.vsr_sr_tail_s2_f16(L.dptr(hid[n0:n0 + n], torch.float16), L.dptr(P["tail_s2"], torch.uint8), L.dptr(raw[n0:n0 + n]),
+                                                   n, h, w, rows, int(P["slopes_le_one"]), int(decimate), L.stream()), "sr_tail_s2_f16")
                 L.TIMER.stop(tok)
             nb = 0
         for n0 in (range(0, N, nb) if nb else ()):
@@ -923,7 +943,7 @@ class SRProjectionModule(nn.Module):
             L.TIMER.stop(tok)
             del hr
 
-    def _tail_unfused(self, x, hid, P, decimate, taps, pre=None):
+    def _tail_unfused(self, x, hid, P, decimate, taps, pre=None, fold=None):
         """`out` DeconvBlock -> conv_out 3x3 -> skip + add_mean + fusion MLP for upscale factors other than 4
         (SRProjectionModule.py:142-146): phase convolutions on the generic MFMA kernel, then csrc/sr_scale.hip.  `x`: all planes;
         `hid`: the LAST hid.shape[0] of them -- the first ones' raw tail output is rows 0.. of `pre` [planes,3,Sh,Sw] (evaluated
@@ -941,7 +961,7 @@ class SRProjectionModule(nn.Module):
             raw = torch.empty((N, 3, ho, wo), dtype=torch.float32, device=dev)
             if nt:
                 raw[:nt].copy_(pre[:nt, :, ::S, ::S])
-        self._tail_raw(hid, P, decimate, raw[nt:])
+        self._tail_raw(hid, P, decimate, raw[nt:], fold=fold)
         out = torch.empty((1, 3, ho, wo), dtype=torch.float32, device=dev)
         tok = L.TIMER.start("sr_fc_planes_skip_scale") if L.TIMER.enabled else None
         L.check(lib.vsr_sr_fc_planes_skip_scale_f32(L.dptr(raw), L.dptr(x), L.dptr(P["tail_par"]), L.dptr(P["fc_w1"]), L.dptr(P["fc_b1"]),
@@ -1061,10 +1081,11 @@ def pack_utd_s2_blob(up_w, up_b, up_a, tr_w, tr_col0, tr_b, tr_a, dn_w, dn_b, dn
     return blob
 
 
-def pack_tail_s2_blob(out_w, out_b, out_a, cv_w, cv_b) -> torch.Tensor:
+def pack_tail_s2_blob(out_w, out_b, out_a, cv_w, cv_b, fold_co=None) -> torch.Tensor:
     """Weights of the fused x2 tail (csrc/sr_tail_s2.hip): the `out` ConvTranspose2d [32,32,6,6] in k_utd_s2's per-wave
     fragment order, conv_out [3,32,3,3] as nine A fragments whose rows 0-2 are its output channels (k index in the
-    accumulator-derived channel order of the ring), then b_out[32], b_cv[3] and the PReLU slope."""
+    accumulator-derived channel order of the ring), then b_out[32], b_cv[3] and the PReLU slope.
+    fold_co = (w [32,ld], (col_a, col_b), b [32], a): compress_out over two live maps, for vsr_sr_tail_s2_fold_f16."""
     dev = out_w.device
     nbytes = int(L.load().vsr_sr_query(L.Q_TAIL_S2_BLOB_BYTES))
     lane = torch.arange(64, device=dev)
@@ -1094,6 +1115,18 @@ def pack_tail_s2_blob(out_w, out_b, out_a, cv_w, cv_b) -> torch.Tensor:
     fpar[32:35] = cv_b.detach().float()
     fpar[96] = float(out_a)
     blob[o_f:o_f + 512] = fpar.view(torch.uint8)
+    if fold_co is not None:
+        co_w, cols, co_b, co_a = fold_co
+        o_co = o_f + 512
+        T2 = torch.tensor(list(cols), device=dev).view(2, 1, 1, 1)
+        MT2 = torch.arange(2, device=dev).view(1, 2, 1, 1)
+        co_, ci_ = torch.broadcast_tensors(16 * MT2 + (lane & 15).view(1, 1, 64, 1),
+                                           T2 + 8 * (lane >> 4).view(1, 1, 64, 1) + torch.arange(8, device=dev).view(1, 1, 1, 8))   # natural order: the raw maps
+        blob[o_co:o_co + 4096] = co_w.detach().float()[co_, ci_].to(torch.float16).contiguous().view(torch.uint8).reshape(-1)
+        cpar = torch.zeros(64, dtype=torch.float32, device=dev)
+        cpar[0:32] = co_b.detach().float()
+        cpar[32] = float(co_a)
+        blob[o_co + 4096:o_co + 4096 + 256] = cpar.view(torch.uint8)
     return blob
 
 
