@@ -307,6 +307,23 @@ def test_graph_replay_is_bit_identical_to_eager(gpu_vsr_f16, hw):
         g(clip[:3], torch.zeros((1, S * h, S * w, 3), device="cuda"), None, None, train=True)
 
 
+def test_graph_replay_in_the_float32_configuration(gpu_vsr):
+    """GraphedVSR on the exact float32 configuration (own float32 kernels + the stock operators its trunks still route to, all on the
+    capturing streams): replayed frames equal the eager ones bit for bit."""
+    import copy
+    from video_super_resolution_amd import GraphedVSR
+    m = copy.deepcopy(gpu_vsr)
+    clip = torch.from_numpy(np.random.RandomState(9).randint(0, 256, (5, 66, 70, 3)).astype(np.float32)).cuda()
+    est, ref = None, []
+    for t in range(3):
+        est, _ = m(clip[t:t + 3], None, None, est, train=False)
+        ref.append(est.clone())
+    g, est = GraphedVSR(m), None
+    for t in range(3):
+        est, _ = g(clip[t:t + 3], None, None, est, train=False)
+        assert torch.equal(est, ref[t]), t
+
+
 def test_streaming_mode_matches_per_window_evaluation(gpu_vsr_f16):
     """VSR.temporal_cache (opt-in): depth predictions / flow pictures of the two frames consecutive windows share are kept
     across calls (bit-identity with the per-window evaluation: the test above).  Here: cache bookkeeping -- an in-place change of a
