@@ -305,6 +305,12 @@ def test_graph_replay_is_bit_identical_to_eager(gpu_vsr_f16, hw):
     assert len(g._graphs) == 2 and all(torch.equal(a, b) for a, b in zip(got2, ref))
     with pytest.raises(ValueError):
         g(clip[:3], torch.zeros((1, S * h, S * w, 3), device="cuda"), None, None, train=True)
+    if h < 100:   # a weight update (in place: the kernels read packed copies) must not be answered from the old graph
+        with torch.no_grad():
+            m.model.conv_out[0].bias.add_(3.0)
+        new_ref, _ = m(clip[:3], None, None, None, train=False)
+        new_got, _ = g(clip[:3], None, None, None, train=False)
+        assert torch.equal(new_got, new_ref) and not torch.equal(new_ref, ref[0]) and len(g._graphs) == 3
 
 
 def test_graph_replay_in_the_float32_configuration(gpu_vsr):

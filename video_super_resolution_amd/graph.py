@@ -6,9 +6,9 @@ join the capturing stream through the events `VSR.forward` already uses -- and r
 of ~900 Python -> ctypes -> HIP calls, same kernels, same values (tests/test_gpu_vsr.py::test_graph_replay_is_bit_identical_to_eager).
 
 Opt-in, inference only (`train=False`, no `target`): the reference's calling convention is kept (video_super_resolution.py:23,66-69),
-`high_frames[1] = out` is done after the replay.  A graph is bound to the input geometry, to whether a previous output is given and to
-the module's switches at capture time; parameters are read at replay time (in-place updates are seen), but packed weights are not
-re-packed inside a graph: call `reset()` after `load_state_dict` / an optimizer step.
+`high_frames[1] = out` is done after the replay.  A graph is bound to the input geometry, to whether a previous output is given, to the
+module's switches and to the (address, version) of every parameter and buffer at capture time -- the kernels read PACKED copies of the
+weights, so after `load_state_dict` / an optimizer step / `.half()` the next call captures afresh instead of replaying stale weights.
 """
 from __future__ import annotations
 
@@ -29,8 +29,9 @@ class GraphedVSR:
 
     def _key(self, data, est):
         m = self.model
+        weights = (m.model._weights_key(), m._flow_exec.key(), m._depth_exec.key(), m._vos_exec.key())
         return (tuple(data.shape), data.dtype, data.device.index, None if est is None else (tuple(est.shape), est.dtype),
-                m.precision, m.upscale_factor, m.share_planes, m.share_tail, m.overlap_shared, m.early_planes, m.depth_est_late)
+                m.precision, m.upscale_factor, m.share_planes, m.share_tail, m.overlap_shared, m.early_planes, m.depth_est_late, weights)
 
     def _capture(self, data, est):
         m = self.model
@@ -61,6 +62,8 @@ class GraphedVSR:
             key = self._key(data, estimated_image)
             ent = self._graphs.get(key)
             if ent is None:
+                if len(self._graphs) >= 8:     # (each graph owns its intermediates: a service that sees many geometries / weight versions keeps the latest)
+                    self._graphs.pop(next(iter(self._graphs)))
                 ent = self._graphs[key] = self._capture(data, estimated_image)
             g, sd, se, so = ent
             sd.copy_(data)

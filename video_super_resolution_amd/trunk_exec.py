@@ -618,13 +618,16 @@ class TrunkExecCache:
         self.master, self.factory = master, factory
         self._exec, self._key, self._mods = None, None, None
 
+    def key(self):
+        if self._mods is None:
+            self._mods = [m for m in self.master.modules() if m._parameters or m._buffers]
+        return tuple((t.data_ptr(), t._version) for m in self._mods for d in (m._parameters, m._buffers) for t in d.values() if t is not None)
+
     def get(self):
         # (address, version) of every parameter and buffer, read through the modules' own dictionaries -- a replaced Parameter object is
         # seen like an in-place update; `nn.Module.parameters()` walks the module tree with name bookkeeping, which cost ~0.4 ms per
         # look-up x 6 per frame.  The LIST of sub-modules is taken once: rebuild the cache object after adding / removing sub-modules.
-        if self._mods is None:
-            self._mods = [m for m in self.master.modules() if m._parameters or m._buffers]
-        key = tuple((t.data_ptr(), t._version) for m in self._mods for d in (m._parameters, m._buffers) for t in d.values() if t is not None)
+        key = self.key()
         if self._exec is None or key != self._key:
             self._exec, self._key = self.factory(self.master), key
         return self._exec
