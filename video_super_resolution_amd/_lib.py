@@ -193,6 +193,9 @@ class Chain1x1(ctypes.Structure):
     _fields_ = [("nstages", ctypes.c_int), ("stage", _ChainStage * 3)]
 
 
+_ROUTE_BATCH = os.environ.get("VSR_ROUTE_BATCH", "1") != "0"   # (A/B switch: 0 = every launcher follows the batch it is handed, as before round 5)
+
+
 class route_batch:
     """`with _lib.route_batch(num, den):` -- the convolution launchers inside choose kernel / tile width / split-K as if their batch N
     were N * num / den (vsr_conv2d_route_batch): a trunk evaluated on a part of its usual batch runs the usual kernels.  num == den or
@@ -200,7 +203,7 @@ class route_batch:
 
     def __init__(self, num: int, den: int):
         self.num, self.den = int(num), int(den)
-        self.on = self.den > 0 and self.num > 0 and self.num != self.den
+        self.on = self.den > 0 and self.num > 0 and self.num != self.den and _ROUTE_BATCH
 
     def __enter__(self):
         if self.on:
