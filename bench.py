@@ -557,7 +557,7 @@ def main():
                 # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
                 # gfx950 correction applied) -- a committed measurement of the same launch geometry, not taken in this run
                 # (file, planes of the profiled launch): the 5-plane flat-split launch has its own passes (round 3)
-                pmcs = {(540, 960, 4): (("r05_k_utd3_pmc_4planes.json", 4), ("r05_k_utd3_pmc_5planes.json", 5), ("r03_k_utd3_pmc.json", 5), ("r02_k_utd3_pmc.json", 8)),
+                pmcs = {(540, 960, 4): (("r05_k_utd4_post_pmc_4planes.json", 4), ("r05_k_utd3_pmc_4planes.json", 4), ("r05_k_utd3_pmc_5planes.json", 5), ("r03_k_utd3_pmc.json", 5), ("r02_k_utd3_pmc.json", 8)),
                         (1080, 1920, 2): (("r02_k_utd_s2_pmc.json", 8),),
                         (2160, 3840, 2): (("r04_c5_k_utd_s2_hbm_pmc.json", 5),)}
                 cands = sorted(pmcs.get((h, w, scale), ()), key=lambda fp: fp[1] != planes_dom)   # the launch's own geometry first
@@ -568,6 +568,11 @@ def main():
                             traffic = json.load(f)["hbm"]["traffic_bytes_per_launch"] * planes_dom / float(pl)
                         traffic_source = f"profiles/{pmc} (rocprofv3 --pmc, separate run of the {pl}-plane launch geometry" + \
                             (")" if planes_dom == pl else f", scaled to {planes_dom} planes: the traffic is per plane)")
+                        if "_post_" in pmc:
+                            # the profiled launch carries the fused uptran 1x1 (a second [planes,h,w,32] fp16 output); every other stage launch
+                            # of a pass does not: the timed launches are half and half
+                            traffic -= 0.5 * planes_dom * h * w * 64
+                            traffic_source += "; that launch writes the fused 1x1's second output, which half of the timed launches do not: minus half of it"
                         break
                 roof = dict(bound="mfma", kernel=name, achieved=round(achieved, 3), peak=FP16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / FP16_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
