@@ -558,7 +558,7 @@ def main():
                 # gfx950 correction applied) -- a committed measurement of the same launch geometry, not taken in this run
                 # (file, planes of the profiled launch): the 5-plane flat-split launch has its own passes (round 3)
                 pmcs = {(540, 960, 4): (("r05_k_utd4_post_pmc_4planes.json", 4), ("r05_k_utd3_pmc_4planes.json", 4), ("r05_k_utd3_pmc_5planes.json", 5), ("r03_k_utd3_pmc.json", 5), ("r02_k_utd3_pmc.json", 8)),
-                        (1080, 1920, 2): (("r02_k_utd_s2_pmc.json", 8),),
+                        (1080, 1920, 2): (("r05_k_utd_s2_post_pmc_8planes.json", 8), ("r05_k_utd_s2_pmc_8planes.json", 8), ("r02_k_utd_s2_pmc.json", 8)),
                         (2160, 3840, 2): (("r04_c5_k_utd_s2_hbm_pmc.json", 5),)}
                 cands = sorted(pmcs.get((h, w, scale), ()), key=lambda fp: fp[1] != planes_dom)   # the launch's own geometry first
                 for pmc, pl in cands:

@@ -16,18 +16,24 @@ a = (torch.randn(N, h, w, 32, device="cuda") * 20).half()
 from video_super_resolution_amd import _lib as L
 lib = L.load()
 VARS = tuple(int(v) for v in os.environ.get("S2_VARIANTS", "0,1").split(","))   # (0: shipping build, 1: branch-free build)
+POST = os.environ.get("S2_POST", "0") == "1"   # the launch with the next group's uptran 1x1 fused in (k_utd_s2<.., POST>; variant 0 only)
+if POST:
+    VARS = (0,)
+    run = lambda: st(a, m._chain, post=True)[0]
+else:
+    run = lambda: st(a, m._chain)
 outs = {}
 res = {v: [] for v in VARS}
 for v in VARS:
     lib.vsr_sr_utd_s2_variant(v)
-    for _ in range(2): outs[v] = st(a, m._chain).clone()
+    for _ in range(2): outs[v] = run().clone()
 torch.cuda.synchronize()
 for r in range(4):   # interleaved rounds on one device
     for v in VARS:
         lib.vsr_sr_utd_s2_variant(v)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps): st(a, m._chain)
+        for _ in range(reps): run()
         e1.record(); torch.cuda.synchronize()
         res[v].append(e0.elapsed_time(e1) / reps)
 lib.vsr_sr_utd_s2_variant(0)
